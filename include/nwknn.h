@@ -1,0 +1,121 @@
+/*
+ * nwknn.h -- C ABI of libnwknn.so: the MI355X (gfx950) brute-force kNN ground-truth engine.
+ *
+ * The reference (phact/neighborhoodwatch) has NO FFI for this path: its hot path is three Python call
+ * sites into CUDA wheels.  Each entry point below names the reference interface it stands in for
+ * (paths relative to /root/reference); INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 (NWKNN_OK) or a negative NWKNN_E* code; the message of the last failure on
+ *     the calling thread is available from nwknn_last_error().  No C++ exception crosses this boundary.
+ *     (The reference fails by `assert`: cu_knn.py:136,177,237,281.)
+ *   - the caller owns every buffer passed in or out; the library never frees or retains caller memory
+ *     after a call returns.  Device memory behind a handle belongs to the library until nwknn_destroy().
+ *   - a `location` argument says where a caller buffer lives: NWKNN_HOST or NWKNN_DEVICE (a HIP device
+ *     pointer on the handle's device, e.g. torch.Tensor.data_ptr()).
+ *   - matrices are dense row-major, C-contiguous.  Distances are float32, indices int64, exactly the tuple
+ *     the reference's operators return (cu_knn.py:243-245).
+ *   - one search at a time per handle; distinct handles are independent.
+ */
+#ifndef NWKNN_H
+#define NWKNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NWKNN_ABI_VERSION 1
+
+/* error codes */
+#define NWKNN_OK 0
+#define NWKNN_EINVAL (-1)   /* bad argument: null pointer, k > rows, unknown metric/dtype ... */
+#define NWKNN_EHIP (-2)     /* a HIP runtime call failed; see nwknn_last_error() */
+#define NWKNN_ENOMEM (-3)   /* device or host allocation failed */
+#define NWKNN_ESTATE (-4)   /* call order: e.g. search before set_base */
+#define NWKNN_ENODEV (-5)   /* no usable gfx950 device */
+
+/* metric (which reference engine's distance): */
+#define NWKNN_METRIC_SQEUCLIDEAN 0   /* engine='raft'  : pylibraft knn default, cu_knn.py:243-245, cu_knn_ds.py:213 */
+#define NWKNN_METRIC_ONE_MINUS_DOT 1 /* engine='torch' : 1 - q.b^T + topk,      cu_knn.py:256-257               */
+#define NWKNN_METRIC_COSINE 2        /* engine='cuvs'  : brute_force metric="cosine", cu_knn.py:247-248         */
+
+#define NWKNN_DTYPE_F32 0
+
+#define NWKNN_HOST 0
+#define NWKNN_DEVICE 1
+
+typedef struct nwknn_ctx* nwknn_handle;
+
+/* timing / accounting of the most recent nwknn_search on a handle (all times in milliseconds, measured
+ * with HIP events on the handle's stream when option "profile" is 1, else 0) */
+typedef struct nwknn_stats {
+    int64_t nq, nb;                /* shape of the last search */
+    int32_t d, k;
+    int32_t tile_launches;         /* launches of the distance-tile kernel */
+    int32_t compact_launches;      /* launches of the list compaction kernel */
+    int32_t rescan_launches;       /* distance-tile launches spent repairing overflowed lists */
+    int32_t overflowed_queries;    /* queries whose candidate list overflowed at least once */
+    double tile_ms;                /* sum of distance-tile kernel durations */
+    double compact_ms;             /* sum of compaction kernel durations */
+    double prep_ms;                /* base + query layout/norm kernels inside the last search/set_base */
+    double total_ms;               /* first launch to last launch of the search */
+    double tile_flops;             /* 2 * q_rows * b_rows * d summed over the distance-tile launches */
+} nwknn_stats;
+
+/* ---- library / device ------------------------------------------------------------------------------- */
+int nwknn_version(void);
+const char* nwknn_last_error(void);
+int nwknn_device_count(void);
+/* free/total bytes of HBM on a device.  Replaces the NVML query in tune_memory(), cu_knn.py:62-71 and
+ * get_gpu_memory(), cu_knn_ds.py:30-36. */
+int nwknn_mem_info(int device, size_t* free_bytes, size_t* total_bytes);
+
+/* ---- handle ------------------------------------------------------------------------------------------ */
+/* One handle = one GPU's share of the job (the reference hard-codes device 0, cu_knn.py:65). */
+int nwknn_create(nwknn_handle* out, int device);
+int nwknn_destroy(nwknn_handle h);
+/* Run all work of this handle on an existing HIP stream (hipStream_t, e.g. torch's current stream); NULL
+ * restores the handle's own stream. */
+int nwknn_set_stream(nwknn_handle h, void* hip_stream);
+/* Tunables: "capacity" (candidate slots per query, power of two >= 4k), "first_chunk", "max_chunk"
+ * (base rows per launch, multiples of 128), "profile" (0/1: per-kernel HIP-event timing into nwknn_stats). */
+int nwknn_set_option(nwknn_handle h, const char* name, int64_t value);
+int nwknn_get_stats(nwknn_handle h, nwknn_stats* out);
+/* Wait for everything queued on the handle's stream. */
+int nwknn_synchronize(nwknn_handle h);
+
+/* ---- dataset side: `dataset` argument of knn(dataset, queries, k), cu_knn.py:243; the arrow -> cuDF ->
+ *      DLPack -> CuPy row-major conversion of cu_knn.py:205-211 ends here ------------------------------ */
+/* Make rows [0, rows) x d of `base` the searchable set of this handle (this GPU's shard).  The library keeps
+ * its own MFMA-ready copy plus row norms; the caller's buffer is not referenced after return (for
+ * NWKNN_DEVICE the copy is queued on the handle's stream and the buffer may be reused after
+ * nwknn_synchronize or any later blocking call). */
+int nwknn_set_base(nwknn_handle h, const void* base, int64_t rows, int32_t d, int dtype, int location);
+
+/* ---- the operator: distances, indices = knn(dataset, queries, k)  (cu_knn.py:243-245) ------------------- */
+/* For each of the nq query rows: the k nearest rows of the base set, ascending by (distance, index),
+ * lower index first among equal distances.  out_idx = row number in the base set + index_offset
+ * (index_offset plays the role of `+ batch_offset`, cu_knn.py:273: pass the shard's first global row).
+ * Requires 0 < k <= base rows (cu_knn.py:177-178,237) and k <= 1024. */
+int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int location, int32_t k, int metric,
+                 int64_t index_offset, float* out_dist, int64_t* out_idx, int out_location);
+
+/* ---- merge of partial top-k lists: merge_indices_and_distances(), merge.py:56-101 ----------------------- */
+/* dists/idx: [n_lists][nq][k_in] (partial list l of query q at ((l*nq)+q)*k_in); idx < 0 marks an empty
+ * slot.  Writes the k_out smallest by (distance, index) into out_dist/out_idx [nq][k_out].
+ * All four buffers live in `location`. */
+int nwknn_merge(nwknn_handle h, const float* dists, const int64_t* idx, int32_t n_lists, int64_t nq, int32_t k_in,
+                int32_t k_out, float* out_dist, int64_t* out_idx, int location);
+
+/* ---- synthetic inputs (no reference counterpart: generate_dataset.py needs the network) ----------------- */
+/* Fill device buffer out[rows][d] (float32) with value(seed, row0 + r, c) in [-1,1) on a 2^-23 grid; the
+ * same integer recipe as oracle/cpu_oracle.gen_numpy, so hosts can regenerate any row for checking. */
+int nwknn_generate(nwknn_handle h, uint64_t seed, int64_t row0, int64_t rows, int32_t d, float* out_device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NWKNN_H */

@@ -1,0 +1,92 @@
+"""ctypes binding of libnwknn.so (C ABI in include/nwknn.h).
+
+The HIP library is the product: there is no CPU fallback.  Loading fails loudly when the shared
+object is missing (run ``python -c 'import __graft_entry__ as g; g.build()'`` or
+``python -m neighborhoodwatch_amd.build``), and creating a handle fails loudly without a gfx950 GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libnwknn.so"
+
+NWKNN_OK = 0
+HOST, DEVICE = 0, 1
+METRIC_IDS = {"sqeuclidean": 0, "one_minus_dot": 1, "cosine": 2}
+# the reference selects the distance through its `engine` argument (cu_knn.py:193-200,243-262)
+ENGINE_TO_METRIC = {"raft": "sqeuclidean", "torch": "one_minus_dot", "cuvs": "cosine", "hip": "sqeuclidean"}
+
+EXPORTS = [
+    "nwknn_version", "nwknn_last_error", "nwknn_device_count", "nwknn_mem_info", "nwknn_create", "nwknn_destroy",
+    "nwknn_set_stream", "nwknn_set_option", "nwknn_get_stats", "nwknn_synchronize", "nwknn_set_base", "nwknn_search",
+    "nwknn_merge", "nwknn_generate",
+]
+
+
+class NwknnStats(ctypes.Structure):
+    _fields_ = [
+        ("nq", c_int64), ("nb", c_int64), ("d", c_int32), ("k", c_int32),
+        ("tile_launches", c_int32), ("compact_launches", c_int32), ("rescan_launches", c_int32),
+        ("overflowed_queries", c_int32),
+        ("tile_ms", c_double), ("compact_ms", c_double), ("prep_ms", c_double), ("total_ms", c_double),
+        ("tile_flops", c_double),
+    ]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class NwknnError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libnwknn.so once and declare every prototype of include/nwknn.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise NwknnError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. "
+            "Build it with `python -m neighborhoodwatch_amd.build` (needs hipcc); there is no CPU fallback.")
+    L = ctypes.CDLL(str(LIB_PATH))
+    L.nwknn_version.restype = c_int
+    L.nwknn_last_error.restype = c_char_p
+    L.nwknn_device_count.restype = c_int
+    L.nwknn_mem_info.argtypes = [c_int, POINTER(c_size_t), POINTER(c_size_t)]
+    L.nwknn_create.argtypes = [POINTER(c_void_p), c_int]
+    L.nwknn_destroy.argtypes = [c_void_p]
+    L.nwknn_set_stream.argtypes = [c_void_p, c_void_p]
+    L.nwknn_set_option.argtypes = [c_void_p, c_char_p, c_int64]
+    L.nwknn_get_stats.argtypes = [c_void_p, POINTER(NwknnStats)]
+    L.nwknn_synchronize.argtypes = [c_void_p]
+    L.nwknn_set_base.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int, c_int]
+    L.nwknn_search.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int32, c_int, c_int64, c_void_p, c_void_p, c_int]
+    L.nwknn_merge.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int]
+    L.nwknn_generate.argtypes = [c_void_p, c_uint64, c_int64, c_int64, c_int32, c_void_p]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if name not in ("nwknn_last_error",):
+            fn.restype = c_int
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    """Map a negative NWKNN_E* code to a Python exception (ValueError for bad arguments, like the
+    reference's assertions at cu_knn.py:136,177,237; RuntimeError otherwise)."""
+    if rc == NWKNN_OK:
+        return
+    msg = load().nwknn_last_error().decode("utf-8", "replace")
+    text = f"{what} failed (code {rc}): {msg}"
+    if rc == -1:
+        raise ValueError(text)
+    if rc == -3:
+        raise MemoryError(text)
+    raise NwknnError(text)

@@ -1,0 +1,511 @@
+// nwknn_api.cpp -- C ABI (include/nwknn.h) and host-side orchestration of the kNN hot path.
+//
+// Reference call stack this file stands in for (paths relative to /root/reference):
+//   neighborhoodwatch/cu_knn.py:193-287  process_batches(): base tiles x query tiles, knn() per pair, + batch_offset
+//   neighborhoodwatch/cu_knn.py:54-109   tune_memory(): NVML memory probe            -> nwknn_mem_info
+//   neighborhoodwatch/merge.py:56-101    fold of partial lists                         -> nwknn_merge
+// Instead of materialising per-tile top-k tables and folding them on the CPU, one search keeps a running
+// per-query candidate list on the device and walks the base in growing chunks.
+#include "../../include/nwknn.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "nwknn_internal.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                             \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess)                                                                                    \
+            return fail(e_ == hipErrorOutOfMemory ? NWKNN_ENOMEM : NWKNN_EHIP, "%s failed: %s (%s:%d)", #expr,   \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                              \
+    } while (0)
+
+#define RCCHK(expr)                \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != NWKNN_OK) return rc_; \
+    } while (0)
+
+static inline long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return NWKNN_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) { p = nullptr; return fail(NWKNN_ENOMEM, "hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(e)); }
+        bytes = need;
+        return NWKNN_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct EvPair { hipEvent_t a, b; int kind; };   // kind: 0 tile, 1 compact, 2 prep
+
+struct nwknn_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // base shard
+    DevBuf bp, bn, braw;
+    long long nb = 0, nb_pad = 0;
+    int d = 0, dp = 0;
+    // query side
+    DevBuf qraw, qp, qn;
+    // running top-k state
+    DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
+    // options
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0;
+    // profiling
+    std::vector<EvPair> ev_pool;
+    size_t ev_used = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    double base_prep_ms = 0.0;
+    nwknn_stats stats;
+};
+
+static int use_device(nwknn_ctx* h)
+{
+    HIPCHK(hipSetDevice(h->device));
+    return NWKNN_OK;
+}
+
+// ---- profiling helpers ------------------------------------------------------------------------------
+static EvPair* ev_begin(nwknn_ctx* h, int kind)
+{
+    if (!h->opt_profile) return nullptr;
+    if (h->ev_used == h->ev_pool.size()) {
+        EvPair e;
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return nullptr;
+        h->ev_pool.push_back(e);
+    }
+    EvPair* e = &h->ev_pool[h->ev_used++];
+    e->kind = kind;
+    (void)hipEventRecord(e->a, h->stream);
+    return e;
+}
+static void ev_end(nwknn_ctx* h, EvPair* e)
+{
+    if (e) (void)hipEventRecord(e->b, h->stream);
+}
+static void ev_collect(nwknn_ctx* h, double* tile_ms, double* compact_ms, double* prep_ms)
+{
+    *tile_ms = *compact_ms = *prep_ms = 0.0;
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b) != hipSuccess) continue;
+        if (h->ev_pool[i].kind == 0) *tile_ms += ms;
+        else if (h->ev_pool[i].kind == 1) *compact_ms += ms;
+        else *prep_ms += ms;
+    }
+    h->ev_used = 0;
+}
+
+// ---- library / device -------------------------------------------------------------------------------
+extern "C" int nwknn_version(void) { return NWKNN_ABI_VERSION; }
+extern "C" const char* nwknn_last_error(void) { return g_err.c_str(); }
+
+extern "C" int nwknn_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int nwknn_mem_info(int device, size_t* free_bytes, size_t* total_bytes)
+{
+    if (!free_bytes || !total_bytes) return fail(NWKNN_EINVAL, "nwknn_mem_info: null output pointer");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemGetInfo(free_bytes, total_bytes));
+    return NWKNN_OK;
+}
+
+extern "C" int nwknn_create(nwknn_handle* out, int device)
+{
+    if (!out) return fail(NWKNN_EINVAL, "nwknn_create: null handle pointer");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(NWKNN_ENODEV, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(NWKNN_EINVAL, "device %d out of range (have %d)", device, n);
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(NWKNN_ENODEV, "device %d is %s; libnwknn is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    nwknn_ctx* h = new (std::nothrow) nwknn_ctx();
+    if (!h) return fail(NWKNN_ENOMEM, "out of host memory");
+    h->device = device;
+    memset(&h->stats, 0, sizeof h->stats);
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreate(&h->own_stream));
+    h->stream = h->own_stream;
+    HIPCHK(hipEventCreate(&h->ev_begin));
+    HIPCHK(hipEventCreate(&h->ev_end));
+    *out = h;
+    return NWKNN_OK;
+}
+
+extern "C" int nwknn_destroy(nwknn_handle h)
+{
+    if (!h) return NWKNN_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (DevBuf* b : {&h->bp, &h->bn, &h->braw, &h->qraw, &h->qp, &h->qn, &h->tau, &h->cnt, &h->buf, &h->ovf, &h->ovf_any, &h->qtiles,
+                      &h->out_d, &h->out_i, &h->mrg_d, &h->mrg_i})
+        b->release();
+    for (EvPair& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
+    if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return NWKNN_OK;
+}
+
+extern "C" int nwknn_set_stream(nwknn_handle h, void* hip_stream)
+{
+    if (!h) return fail(NWKNN_EINVAL, "null handle");
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return NWKNN_OK;
+}
+
+extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
+{
+    if (!h || !name) return fail(NWKNN_EINVAL, "null handle or option name");
+    if (!strcmp(name, "capacity")) {
+        if (value != 0 && (value < 256 || value > 4096 || (value & (value - 1)))) return fail(NWKNN_EINVAL, "capacity must be 0 (auto) or a power of two in [256, 4096]");
+        h->opt_capacity = value;
+    } else if (!strcmp(name, "first_chunk")) {
+        if (value < 0 || value % NWK_TILE_ROWS) return fail(NWKNN_EINVAL, "first_chunk must be a non-negative multiple of %d", NWK_TILE_ROWS);
+        h->opt_first_chunk = value;
+    } else if (!strcmp(name, "max_chunk")) {
+        if (value < NWK_TILE_ROWS || value % NWK_TILE_ROWS) return fail(NWKNN_EINVAL, "max_chunk must be a positive multiple of %d", NWK_TILE_ROWS);
+        h->opt_max_chunk = value;
+    } else if (!strcmp(name, "profile")) {
+        h->opt_profile = value ? 1 : 0;
+    } else {
+        return fail(NWKNN_EINVAL, "unknown option '%s'", name);
+    }
+    return NWKNN_OK;
+}
+
+extern "C" int nwknn_get_stats(nwknn_handle h, nwknn_stats* out)
+{
+    if (!h || !out) return fail(NWKNN_EINVAL, "null handle or output");
+    *out = h->stats;
+    return NWKNN_OK;
+}
+
+extern "C" int nwknn_synchronize(nwknn_handle h)
+{
+    if (!h) return fail(NWKNN_EINVAL, "null handle");
+    RCCHK(use_device(h));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NWKNN_OK;
+}
+
+// ---- dataset side -----------------------------------------------------------------------------------
+// Stages a caller matrix onto the device (if it is on the host) and runs the prep kernel into dst/norms.
+static int stage_and_prep(nwknn_ctx* h, const void* src, int location, long long rows, int d, long long rows_pad, int dp, DevBuf& raw,
+                          float* dst, float* norms)
+{
+    const float* dsrc = (const float*)src;
+    if (location == NWKNN_HOST) {
+        // slab-wise so the raw staging copy stays small next to a 288 GB shard
+        const long long slab_rows = std::max<long long>(NWK_TILE_ROWS, ((256ll << 20) / ((long long)d * 4)) / NWK_TILE_ROWS * NWK_TILE_ROWS);
+        RCCHK(raw.ensure((size_t)std::min(slab_rows, std::max<long long>(rows, 1)) * d * 4));
+        for (long long r0 = 0; r0 < rows_pad; r0 += slab_rows) {
+            const long long pad_here = std::min(slab_rows, rows_pad - r0);
+            const long long real_here = std::max<long long>(0, std::min(slab_rows, rows - r0));
+            if (real_here > 0)
+                HIPCHK(hipMemcpyAsync(raw.p, (const char*)src + (size_t)r0 * d * 4, (size_t)real_here * d * 4, hipMemcpyHostToDevice, h->stream));
+            EvPair* e = ev_begin(h, 2);
+            HIPCHK(nwk_launch_prep(h->stream, raw.as<float>(), real_here, d, pad_here, dp, dst + r0 * dp, norms + r0));
+            ev_end(h, e);
+            HIPCHK(hipStreamSynchronize(h->stream));    // the slab is reused by the next copy
+        }
+        return NWKNN_OK;
+    }
+    EvPair* e = ev_begin(h, 2);
+    HIPCHK(nwk_launch_prep(h->stream, dsrc, rows, d, rows_pad, dp, dst, norms));
+    ev_end(h, e);
+    return NWKNN_OK;
+}
+
+extern "C" int nwknn_set_base(nwknn_handle h, const void* base, int64_t rows, int32_t d, int dtype, int location)
+{
+    if (!h || !base) return fail(NWKNN_EINVAL, "nwknn_set_base: null handle or base pointer");
+    if (dtype != NWKNN_DTYPE_F32) return fail(NWKNN_EINVAL, "nwknn_set_base: unsupported dtype %d (only float32)", dtype);
+    if (rows <= 0 || d <= 0) return fail(NWKNN_EINVAL, "nwknn_set_base: rows=%lld d=%d must be positive", (long long)rows, d);
+    if (rows >= (1ll << 32) - NWK_TILE_ROWS) return fail(NWKNN_EINVAL, "nwknn_set_base: a shard holds at most 2^32-129 rows");
+    if (location != NWKNN_HOST && location != NWKNN_DEVICE) return fail(NWKNN_EINVAL, "bad location %d", location);
+    RCCHK(use_device(h));
+    const long long rows_pad = round_up(rows, NWK_TILE_ROWS);
+    const int dp = (int)round_up(d, NWK_K_ALIGN);
+    RCCHK(h->bp.ensure((size_t)rows_pad * dp * 4));
+    RCCHK(h->bn.ensure((size_t)rows_pad * 4));
+    h->ev_used = 0;
+    RCCHK(stage_and_prep(h, base, location, rows, d, rows_pad, dp, h->braw, h->bp.as<float>(), h->bn.as<float>()));
+    h->nb = rows; h->nb_pad = rows_pad; h->d = d; h->dp = dp;
+    if (h->opt_profile) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        double t, c, p;
+        ev_collect(h, &t, &c, &p);
+        h->base_prep_ms = p;
+    }
+    return NWKNN_OK;
+}
+
+// ---- search -----------------------------------------------------------------------------------------
+struct SearchPlan { int cap; long long first, max_chunk, safe; };
+
+static int make_plan(nwknn_ctx* h, int k, SearchPlan* pl)
+{
+    long long cap = h->opt_capacity;
+    if (cap == 0) { cap = 1024; while (cap < 4ll * k) cap <<= 1; }
+    if (cap < 2ll * k + NWK_TILE_ROWS) return fail(NWKNN_EINVAL, "capacity %lld too small for k=%d (need >= 2k+%d)", cap, k, NWK_TILE_ROWS);
+    if (cap > 4096) return fail(NWKNN_EINVAL, "k=%d needs capacity %lld > 4096", k, cap);
+    long long first = h->opt_first_chunk ? h->opt_first_chunk : cap / 2;
+    first = std::max<long long>(first, round_up(k, NWK_TILE_ROWS));
+    first = std::min<long long>(first, cap / NWK_TILE_ROWS * NWK_TILE_ROWS);
+    pl->cap = (int)cap;
+    pl->first = first;
+    pl->max_chunk = h->opt_max_chunk;
+    pl->safe = (cap - k) / NWK_TILE_ROWS * NWK_TILE_ROWS;      // a range this small cannot overflow a compacted list
+    return NWKNN_OK;
+}
+
+static NwkTileParams tile_params(nwknn_ctx* h, const SearchPlan& pl, long long nq_pad)
+{
+    NwkTileParams p;
+    memset(&p, 0, sizeof p);
+    p.qp = h->qp.as<float>(); p.bp = h->bp.as<float>(); p.qn = h->qn.as<float>(); p.bn = h->bn.as<float>();
+    p.tau = h->tau.as<u64>(); p.cnt = h->cnt.as<u32>(); p.buf = h->buf.as<u64>();
+    p.qtile_list = nullptr;
+    p.nb_valid = h->nb;
+    p.n_qtiles = (int)(nq_pad / NWK_TILE_ROWS);
+    p.dp = h->dp; p.cap = pl.cap;
+    return p;
+}
+
+static NwkCompactParams compact_params(nwknn_ctx* h, const SearchPlan& pl, int k)
+{
+    NwkCompactParams c;
+    memset(&c, 0, sizeof c);
+    c.buf = h->buf.as<u64>(); c.cnt = h->cnt.as<u32>(); c.tau = h->tau.as<u64>();
+    c.ovf = h->ovf.as<u32>(); c.ovf_any = h->ovf_any.as<u32>();
+    c.cap = pl.cap; c.k = k;
+    return c;
+}
+
+static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long long nq_pad, long long lo, long long rows, bool dense,
+                     const int* qtile_list, int n_list_tiles, bool dedupe, bool rescan)
+{
+    NwkTileParams tp = tile_params(h, pl, nq_pad);
+    tp.bt0 = (int)(lo / NWK_TILE_ROWS);
+    tp.n_btiles = (int)(rows / NWK_TILE_ROWS);
+    tp.dense_col0 = lo;
+    if (qtile_list) { tp.qtile_list = qtile_list; tp.n_qtiles = n_list_tiles; }
+    EvPair* e = ev_begin(h, 0);
+    HIPCHK(nwk_launch_tile(h->stream, tp, metric, dense));
+    ev_end(h, e);
+    h->stats.tile_launches += 1;
+    if (rescan) h->stats.rescan_launches += 1;
+    h->stats.tile_flops += 2.0 * (double)tp.n_qtiles * NWK_TILE_ROWS * (double)rows * (double)h->d;
+
+    NwkCompactParams cp = compact_params(h, pl, k);
+    cp.dense_count = dense ? (int)rows : 0;
+    cp.dedupe = dedupe ? 1 : 0;
+    cp.qtile_list = qtile_list;
+    const long long nqc = qtile_list ? (long long)n_list_tiles * NWK_TILE_ROWS : nq_pad;
+    e = ev_begin(h, 1);
+    HIPCHK(nwk_launch_compact(h->stream, cp, nqc));
+    ev_end(h, e);
+    h->stats.compact_launches += 1;
+    return NWKNN_OK;
+}
+
+// Overflow repair: re-walk row range [lo,hi) for the query tiles whose lists overflowed, halving the range
+// until it fits.  A range of <= pl.safe rows can add at most pl.safe entries to a compacted (<= k) list, so it
+// cannot overflow: the recursion terminates.
+static int repair(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long long nq_pad)
+{
+    const long long n_tiles_all = nq_pad / NWK_TILE_ROWS;
+    std::vector<u32> flags((size_t)nq_pad);
+    HIPCHK(hipMemcpy(flags.data(), h->ovf.p, (size_t)nq_pad * 4, hipMemcpyDeviceToHost));
+    std::vector<int> tiles;
+    int nflag = 0;
+    for (long long t = 0; t < n_tiles_all; ++t) {
+        bool any = false;
+        for (int j = 0; j < NWK_TILE_ROWS; ++j) if (flags[(size_t)t * NWK_TILE_ROWS + j]) { any = true; ++nflag; }
+        if (any) tiles.push_back((int)t);
+    }
+    h->stats.overflowed_queries += nflag;
+    RCCHK(h->qtiles.ensure((size_t)n_tiles_all * 4 * 2));
+
+    struct Work { long long lo, hi; std::vector<int> tiles; };
+    std::vector<Work> stack;
+    for (long long lo = h->nb_pad; lo > 0;) {            // pushed high-to-low so ranges pop in ascending order
+        const long long hi = lo;
+        lo = std::max<long long>(0, hi - pl.max_chunk);
+        stack.push_back({lo, hi, tiles});
+    }
+    while (!stack.empty()) {
+        Work w = std::move(stack.back());
+        stack.pop_back();
+        if (w.tiles.empty()) continue;
+        HIPCHK(hipMemsetAsync(h->ovf.p, 0, (size_t)nq_pad * 4, h->stream));
+        HIPCHK(hipMemsetAsync(h->ovf_any.p, 0, 4, h->stream));
+        HIPCHK(hipMemcpyAsync(h->qtiles.p, w.tiles.data(), w.tiles.size() * 4, hipMemcpyHostToDevice, h->stream));
+        RCCHK(run_chunk(h, pl, metric, k, nq_pad, w.lo, w.hi - w.lo, false, h->qtiles.as<int>(), (int)w.tiles.size(), true, true));
+        u32 any = 0;
+        HIPCHK(hipMemcpyAsync(&any, h->ovf_any.p, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (!any) continue;
+        if (w.hi - w.lo <= pl.safe) return fail(NWKNN_EHIP, "internal: list overflow on a %lld-row range (safe size %lld)", w.hi - w.lo, pl.safe);
+        HIPCHK(hipMemcpy(flags.data(), h->ovf.p, (size_t)nq_pad * 4, hipMemcpyDeviceToHost));
+        std::vector<int> again;
+        for (int t : w.tiles) {
+            bool a = false;
+            for (int j = 0; j < NWK_TILE_ROWS; ++j) a |= flags[(size_t)t * NWK_TILE_ROWS + j] != 0;
+            if (a) again.push_back(t);
+        }
+        const long long mid = w.lo + round_up((w.hi - w.lo) / 2, NWK_TILE_ROWS);
+        stack.push_back({mid, w.hi, again});
+        stack.push_back({w.lo, mid, again});
+    }
+    return NWKNN_OK;
+}
+
+extern "C" int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int location, int32_t k, int metric, int64_t index_offset,
+                            float* out_dist, int64_t* out_idx, int out_location)
+{
+    if (!h || !queries || !out_dist || !out_idx) return fail(NWKNN_EINVAL, "nwknn_search: null argument");
+    if (!h->bp.p || h->nb <= 0) return fail(NWKNN_ESTATE, "nwknn_search: call nwknn_set_base first");
+    if (nq <= 0) return fail(NWKNN_EINVAL, "nwknn_search: nq=%lld must be positive", (long long)nq);
+    if (k <= 0 || k > h->nb) return fail(NWKNN_EINVAL, "nwknn_search: k=%d must satisfy 0 < k <= %lld base rows", k, h->nb);   // cu_knn.py:237
+    if (k > 1024) return fail(NWKNN_EINVAL, "nwknn_search: k=%d exceeds the supported maximum 1024", k);
+    if (metric < 0 || metric > 2) return fail(NWKNN_EINVAL, "nwknn_search: unknown metric %d", metric);
+    if ((location != NWKNN_HOST && location != NWKNN_DEVICE) || (out_location != NWKNN_HOST && out_location != NWKNN_DEVICE))
+        return fail(NWKNN_EINVAL, "nwknn_search: bad location");
+    RCCHK(use_device(h));
+    SearchPlan pl;
+    RCCHK(make_plan(h, k, &pl));
+
+    const long long nq_pad = round_up(nq, NWK_TILE_ROWS);
+    RCCHK(h->qp.ensure((size_t)nq_pad * h->dp * 4));
+    RCCHK(h->qn.ensure((size_t)nq_pad * 4));
+    RCCHK(h->tau.ensure((size_t)nq_pad * 8));
+    RCCHK(h->cnt.ensure((size_t)nq_pad * 4));
+    RCCHK(h->ovf.ensure((size_t)nq_pad * 4));
+    RCCHK(h->ovf_any.ensure(16));
+    RCCHK(h->buf.ensure((size_t)nq_pad * pl.cap * 8));
+
+    memset(&h->stats, 0, sizeof h->stats);
+    h->stats.nq = nq; h->stats.nb = h->nb; h->stats.d = h->d; h->stats.k = k;
+    h->ev_used = 0;
+    if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_begin, h->stream));
+
+    RCCHK(stage_and_prep(h, queries, location, nq, h->d, nq_pad, h->dp, h->qraw, h->qp.as<float>(), h->qn.as<float>()));
+    HIPCHK(hipMemsetAsync(h->tau.p, 0xFF, (size_t)nq_pad * 8, h->stream));
+    HIPCHK(hipMemsetAsync(h->cnt.p, 0, (size_t)nq_pad * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->ovf.p, 0, (size_t)nq_pad * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->ovf_any.p, 0, 4, h->stream));
+
+    // walk the base: one dense chunk, then filtered chunks that double (tau from n rows admits ~k*m/n of the next m)
+    long long seen = std::min(h->nb_pad, pl.first);
+    RCCHK(run_chunk(h, pl, metric, k, nq_pad, 0, seen, true, nullptr, 0, false, false));
+    while (seen < h->nb_pad) {
+        const long long m = std::min(std::min(pl.max_chunk, seen), h->nb_pad - seen);
+        RCCHK(run_chunk(h, pl, metric, k, nq_pad, seen, m, false, nullptr, 0, false, false));
+        seen += m;
+    }
+
+    u32 any = 0;
+    HIPCHK(hipMemcpyAsync(&any, h->ovf_any.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (any) RCCHK(repair(h, pl, metric, k, nq_pad));
+
+    float* od = out_dist;
+    long long* oi = (long long*)out_idx;
+    if (out_location == NWKNN_HOST) {
+        RCCHK(h->out_d.ensure((size_t)nq * k * 4));
+        RCCHK(h->out_i.ensure((size_t)nq * k * 8));
+        od = h->out_d.as<float>(); oi = h->out_i.as<long long>();
+    }
+    HIPCHK(nwk_launch_finalize(h->stream, h->buf.as<u64>(), h->cnt.as<u32>(), pl.cap, k, nq, index_offset, od, oi));
+    if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_end, h->stream));
+    if (out_location == NWKNN_HOST) {
+        HIPCHK(hipMemcpyAsync(out_dist, od, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(out_idx, oi, (size_t)nq * k * 8, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->opt_profile) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev_begin, h->ev_end));
+        h->stats.total_ms = ms;
+        ev_collect(h, &h->stats.tile_ms, &h->stats.compact_ms, &h->stats.prep_ms);
+    }
+    return NWKNN_OK;
+}
+
+// ---- merge ------------------------------------------------------------------------------------------
+extern "C" int nwknn_merge(nwknn_handle h, const float* dists, const int64_t* idx, int32_t n_lists, int64_t nq, int32_t k_in, int32_t k_out,
+                           float* out_dist, int64_t* out_idx, int location)
+{
+    if (!h || !dists || !idx || !out_dist || !out_idx) return fail(NWKNN_EINVAL, "nwknn_merge: null argument");
+    if (n_lists <= 0 || nq <= 0 || k_in <= 0 || k_out <= 0) return fail(NWKNN_EINVAL, "nwknn_merge: sizes must be positive");
+    if ((long long)n_lists * k_in > 4096) return fail(NWKNN_EINVAL, "nwknn_merge: n_lists*k_in=%lld exceeds 4096; fold in groups", (long long)n_lists * k_in);
+    if (location != NWKNN_HOST && location != NWKNN_DEVICE) return fail(NWKNN_EINVAL, "bad location %d", location);
+    RCCHK(use_device(h));
+    const size_t nin = (size_t)n_lists * nq * k_in, nout = (size_t)nq * k_out;
+    const float* dd = dists; const long long* di = (const long long*)idx;
+    float* od = out_dist; long long* oi = (long long*)out_idx;
+    if (location == NWKNN_HOST) {
+        RCCHK(h->mrg_d.ensure(nin * 4)); RCCHK(h->mrg_i.ensure(nin * 8));
+        RCCHK(h->out_d.ensure(nout * 4)); RCCHK(h->out_i.ensure(nout * 8));
+        HIPCHK(hipMemcpyAsync(h->mrg_d.p, dists, nin * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->mrg_i.p, idx, nin * 8, hipMemcpyHostToDevice, h->stream));
+        dd = h->mrg_d.as<float>(); di = h->mrg_i.as<long long>(); od = h->out_d.as<float>(); oi = h->out_i.as<long long>();
+    }
+    HIPCHK(nwk_launch_merge(h->stream, dd, di, n_lists, nq, k_in, k_out, od, oi));
+    if (location == NWKNN_HOST) {
+        HIPCHK(hipMemcpyAsync(out_dist, od, nout * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(out_idx, oi, nout * 8, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NWKNN_OK;
+}
+
+// ---- synthetic inputs -------------------------------------------------------------------------------
+extern "C" int nwknn_generate(nwknn_handle h, uint64_t seed, int64_t row0, int64_t rows, int32_t d, float* out_device)
+{
+    if (!h || !out_device) return fail(NWKNN_EINVAL, "nwknn_generate: null argument");
+    if (rows <= 0 || d <= 0 || row0 < 0) return fail(NWKNN_EINVAL, "nwknn_generate: bad shape");
+    RCCHK(use_device(h));
+    HIPCHK(nwk_launch_gen(h->stream, seed, row0, rows, d, out_device));
+    return NWKNN_OK;
+}

@@ -1,0 +1,52 @@
+// nwknn_internal.h -- shared between nwknn_kernels.hip (device + launchers) and nwknn_api.cpp (C ABI, orchestration).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NWKNN_METRIC_SQEUCLIDEAN 0
+#define NWKNN_METRIC_ONE_MINUS_DOT 1
+#define NWKNN_METRIC_COSINE 2
+
+#define NWK_TILE_ROWS 128          // query rows / base rows per workgroup tile
+#define NWK_K_ALIGN 32             // prepared rows are zero padded to a multiple of this many floats
+
+struct NwkTileParams {
+    const float* qp;               // prepared queries [nq_pad][dp]
+    const float* bp;               // prepared base    [nb_pad][dp]
+    const float* qn;               // squared norms of the queries [nq_pad]
+    const float* bn;               // squared norms of the base    [nb_pad]
+    const unsigned long long* tau; // current k-th key per query (~0 = "fewer than k seen")
+    unsigned int* cnt;             // entries in each query's candidate list
+    unsigned long long* buf;       // candidate lists [nq_pad][cap]
+    const int* qtile_list;         // optional indirection (rescans); nullptr = tiles 0..n_qtiles-1
+    long long nb_valid;            // base rows >= nb_valid are zero padding and never listed
+    long long dense_col0;          // dense mode: list slot = column - dense_col0
+    int n_qtiles;
+    int bt0;                       // first base tile of this launch
+    int n_btiles;
+    int n_super_b;                 // filled in by the launcher
+    int dp;
+    int cap;
+};
+
+struct NwkCompactParams {
+    unsigned long long* buf;
+    unsigned int* cnt;
+    unsigned long long* tau;
+    unsigned int* ovf;             // per query: set to 1 when its list overflowed in this launch
+    unsigned int* ovf_any;         // one word: OR of all overflows
+    const int* qtile_list;         // optional: compact only the queries of these tiles (grid = n_tiles*128)
+    int cap;
+    int k;
+    int dense_count;               // > 0: every list holds exactly this many entries (first chunk)
+    int dedupe;
+};
+
+hipError_t nwk_launch_gen(hipStream_t st, uint64_t seed, long long row0, long long rows, int d, float* out);
+hipError_t nwk_launch_prep(hipStream_t st, const float* raw, long long rows, int d, long long rows_pad, int dp, float* prepared, float* norms);
+hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool dense);
+hipError_t nwk_launch_compact(hipStream_t st, const NwkCompactParams& p, long long n_queries);
+hipError_t nwk_launch_finalize(hipStream_t st, const unsigned long long* buf, const unsigned int* cnt, int cap, int k, long long nq,
+                               long long index_offset, float* out_d, long long* out_i);
+hipError_t nwk_launch_merge(hipStream_t st, const float* dists, const long long* idx, int n_lists, long long nq, int k_in, int k_out,
+                            float* out_d, long long* out_i);

@@ -1,0 +1,197 @@
+"""Python face of the HIP engine: a thin, typed wrapper over the C ABI.
+
+``knn(dataset, queries, k)`` keeps the positional order and the ``(distances, indices)`` return tuple of
+``pylibraft.neighbors.brute_force.knn`` as the reference calls it (cu_knn.py:243-245); ``KnnEngine`` is the
+persistent form (upload a base shard once, search many query sets) that ``process_batches`` and the
+multi-GPU driver use.  numpy arrays are host buffers; torch CUDA tensors are passed by device pointer
+(torch is plumbing for memory and streams only -- no torch op touches the data).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import DEVICE, ENGINE_TO_METRIC, HOST, METRIC_IDS, NwknnStats, check
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+def resolve_metric(metric: Optional[str] = None, engine: Optional[str] = None) -> str:
+    """`engine` values of the reference ('raft' | 'cuvs' | 'torch') are accepted as metric aliases."""
+    if metric is None:
+        metric = ENGINE_TO_METRIC.get(engine or "raft")
+        if metric is None:
+            raise ValueError(f"unknown engine {engine!r}; expected one of {sorted(ENGINE_TO_METRIC)}")
+    if metric not in METRIC_IDS:
+        raise ValueError(f"unknown metric {metric!r}; expected one of {sorted(METRIC_IDS)}")
+    return metric
+
+
+class KnnEngine:
+    """One GPU's share of a brute-force kNN job (the reference uses device 0 only, cu_knn.py:65)."""
+
+    def __init__(self, device: int = 0, profile: bool = False):
+        self._L = _lib.load()
+        self._h = ctypes.c_void_p()
+        check(self._L.nwknn_create(ctypes.byref(self._h), int(device)), "nwknn_create")
+        self.device = int(device)
+        self.rows = 0
+        self.dim = 0
+        if profile:
+            self.set_option("profile", 1)
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.nwknn_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- knobs ------------------------------------------------------------------------------------
+    def set_option(self, name: str, value: int) -> None:
+        check(self._L.nwknn_set_option(self._h, name.encode(), int(value)), f"nwknn_set_option({name})")
+
+    def set_stream(self, stream_ptr: int) -> None:
+        check(self._L.nwknn_set_stream(self._h, ctypes.c_void_p(int(stream_ptr) or None)), "nwknn_set_stream")
+
+    def synchronize(self) -> None:
+        check(self._L.nwknn_synchronize(self._h), "nwknn_synchronize")
+
+    def stats(self) -> dict:
+        s = NwknnStats()
+        check(self._L.nwknn_get_stats(self._h, ctypes.byref(s)), "nwknn_get_stats")
+        return s.as_dict()
+
+    # -- data -------------------------------------------------------------------------------------
+    @staticmethod
+    def _matrix(x, what: str):
+        """-> (pointer, rows, dim, location, keepalive)"""
+        if _is_torch(x):
+            import torch
+            if x.dtype != torch.float32:
+                x = x.to(torch.float32)          # dataset.astype(np.float32), cu_knn.py:243
+            if x.dim() != 2:
+                raise ValueError(f"{what} must be 2-D, got shape {tuple(x.shape)}")
+            x = x.contiguous()
+            loc = DEVICE if x.is_cuda else HOST
+            return x.data_ptr(), x.shape[0], x.shape[1], loc, x
+        a = np.ascontiguousarray(x, dtype=np.float32)
+        if a.ndim != 2:
+            raise ValueError(f"{what} must be 2-D, got shape {a.shape}")
+        return a.ctypes.data, a.shape[0], a.shape[1], HOST, a
+
+    def set_base(self, dataset) -> None:
+        ptr, rows, dim, loc, keep = self._matrix(dataset, "dataset")
+        if rows == 0 or dim == 0:
+            raise ValueError("dataset is empty")
+        if loc == DEVICE:
+            import torch
+            torch.cuda.current_stream(keep.device).synchronize()
+        check(self._L.nwknn_set_base(self._h, ctypes.c_void_p(ptr), rows, dim, 0, loc), "nwknn_set_base")
+        if loc == DEVICE:
+            self.synchronize()               # the caller may free/overwrite its tensor right after we return
+        self.rows, self.dim = rows, dim
+        del keep
+
+    def search(self, queries, k: int, metric: str = "sqeuclidean", index_offset: int = 0, out_device: Optional[bool] = None):
+        """-> (distances float32 [q,k], indices int64 [q,k]); torch CUDA tensors if the queries were, else numpy."""
+        metric = resolve_metric(metric)
+        ptr, nq, dim, loc, keep = self._matrix(queries, "queries")
+        if self.rows == 0:
+            raise _lib.NwknnError("search before set_base")
+        if dim != self.dim:
+            raise ValueError(f"queries have dimension {dim}, dataset has {self.dim}")
+        if not (0 < int(k) <= self.rows):
+            raise ValueError(f"k={k} must satisfy 0 < k <= {self.rows} dataset rows")      # cu_knn.py:237
+        if nq == 0:
+            raise ValueError("queries are empty")
+        want_dev = (loc == DEVICE) if out_device is None else bool(out_device)
+        if want_dev:
+            import torch
+            dev = keep.device if loc == DEVICE else torch.device("cuda", self.device)
+            od = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            oi = torch.empty((nq, k), dtype=torch.int64, device=dev)
+            torch.cuda.current_stream(dev).synchronize()
+            pd_, pi_, oloc = od.data_ptr(), oi.data_ptr(), DEVICE
+        else:
+            od = np.empty((nq, k), dtype=np.float32)
+            oi = np.empty((nq, k), dtype=np.int64)
+            pd_, pi_, oloc = od.ctypes.data, oi.ctypes.data, HOST
+        check(self._L.nwknn_search(self._h, ctypes.c_void_p(ptr), nq, loc, int(k), METRIC_IDS[metric], int(index_offset),
+                                   ctypes.c_void_p(pd_), ctypes.c_void_p(pi_), oloc), "nwknn_search")
+        del keep
+        return od, oi
+
+    def merge(self, dists, idx, k: int):
+        """dists/idx: [n_lists, Q, k_in] -> top-k by (distance, index), [Q, k] (merge.py:56-101 on the GPU)."""
+        if _is_torch(dists):
+            import torch
+            d = dists.contiguous().to(torch.float32); i = idx.contiguous().to(torch.int64)
+            n, q, kin = d.shape
+            od = torch.empty((q, k), dtype=torch.float32, device=d.device)
+            oi = torch.empty((q, k), dtype=torch.int64, device=d.device)
+            torch.cuda.current_stream(d.device).synchronize()
+            check(self._L.nwknn_merge(self._h, ctypes.c_void_p(d.data_ptr()), ctypes.c_void_p(i.data_ptr()), n, q, kin, int(k),
+                                      ctypes.c_void_p(od.data_ptr()), ctypes.c_void_p(oi.data_ptr()), DEVICE), "nwknn_merge")
+            return od, oi
+        d = np.ascontiguousarray(dists, dtype=np.float32); i = np.ascontiguousarray(idx, dtype=np.int64)
+        n, q, kin = d.shape
+        od = np.empty((q, k), dtype=np.float32); oi = np.empty((q, k), dtype=np.int64)
+        check(self._L.nwknn_merge(self._h, ctypes.c_void_p(d.ctypes.data), ctypes.c_void_p(i.ctypes.data), n, q, kin, int(k),
+                                  ctypes.c_void_p(od.ctypes.data), ctypes.c_void_p(oi.ctypes.data), HOST), "nwknn_merge")
+        return od, oi
+
+    def generate(self, seed: int, row0: int, rows: int, dim: int):
+        """Seeded synthetic rows straight into HBM (torch CUDA tensor [rows, dim], float32)."""
+        import torch
+        out = torch.empty((rows, dim), dtype=torch.float32, device=torch.device("cuda", self.device))
+        torch.cuda.current_stream(out.device).synchronize()
+        check(self._L.nwknn_generate(self._h, ctypes.c_uint64(seed), int(row0), int(rows), int(dim), ctypes.c_void_p(out.data_ptr())),
+              "nwknn_generate")
+        self.synchronize()
+        return out
+
+
+_default_engines: dict = {}
+
+
+def default_engine(device: int = 0) -> KnnEngine:
+    eng = _default_engines.get(device)
+    if eng is None:
+        eng = _default_engines[device] = KnnEngine(device)
+    return eng
+
+
+def knn(dataset, queries, k: int, metric: Optional[str] = None, engine: Optional[str] = None, device: int = 0) -> Tuple:
+    """Drop-in for ``pylibraft.neighbors.brute_force.knn(dataset, queries, k)`` as used at cu_knn.py:243-245:
+    returns ``(distances float32 [q,k], indices int64 [q,k])``, ascending, indices local to ``dataset``."""
+    eng = default_engine(device)
+    eng.set_base(dataset)
+    return eng.search(queries, k, resolve_metric(metric, engine))
+
+
+def device_count() -> int:
+    return int(_lib.load().nwknn_device_count())
+
+
+def mem_info(device: int = 0) -> Tuple[int, int]:
+    """(free, total) bytes of HBM -- stands in for the NVML query of tune_memory (cu_knn.py:62-71)."""
+    f, t = ctypes.c_size_t(), ctypes.c_size_t()
+    check(_lib.load().nwknn_mem_info(int(device), ctypes.byref(f), ctypes.byref(t)), "nwknn_mem_info")
+    return int(f.value), int(t.value)
