@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the brute-force kNN hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|dev]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): queries/s (+ pairwise-distance TFLOP/s) for 100k queries x 10M base rows, d=1024, k=100,
+fp32 squared-L2 ("c3"; 41 GB of base fits one 288 GB MI355X, so N=1 runs the same job).  One *step* is one
+complete ground-truth job: raw row-major float32 queries + base resident in HBM -> layout/norm prep -> distance
+tiles fused with the running top-k -> (N>1: one RCCL all-gather of the [Q,k] partial lists + merge) -> final
+[Q,k] distances+indices in host memory on rank 0.  With N ranks the base rows are sharded N ways (total work
+fixed: strong scaling); queries are replicated.  Inputs are seeded synthetic embeddings generated on device.
+
+The JSON line also carries
+  roofline     -- distance-tile kernel: algorithmic FLOPs (2*Q*B*d per launch set) / its summed HIP-event time,
+                  against the 157.3 TFLOP/s dense f32 MFMA peak of MI355X_MICROARCH.md;
+  cpu_baseline -- numpy/BLAS brute force (oracle.cpu_oracle.knn_blas_fp32) on a bounded sample, rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+WORKLOADS = {
+    # name: (Q, B, d, k, metric, description)
+    "c3": (100_000, 10_000_000, 1024, 100, "sqeuclidean", "C3: 100k queries x 10M base, d=1024 (e5-large-v2 shape), k=100, fp32 sqeuclidean"),
+    "c2": (10_000, 1_000_000, 768, 100, "sqeuclidean", "C2: 10k queries x 1M base, d=768, k=100, fp32 sqeuclidean"),
+    "dev": (4_096, 262_144, 256, 100, "sqeuclidean", "dev: 4k x 256k, d=256, k=100 (not a headline number)"),
+}
+SEED_BASE, SEED_QUERY = 0x6E770001, 0x6E770002
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+
+
+def cpu_baseline(eng, base_dev, queries_dev, k, metric, full_b):
+    """numpy/BLAS brute force on a bounded sample of the same workload, timed on this box's host cores."""
+    import numpy as np
+    from oracle import cpu_oracle
+    cores = len(os.sched_getaffinity(0))
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [cores])
+    except Exception:
+        blas_threads = cores
+    d = base_dev.shape[1]
+    bs = min(base_dev.shape[0], max(10_000, int(2.5e11 / (512 * d))))      # ~0.25 TFLOP per 512 queries
+    qs = min(queries_dev.shape[0], 512)
+    base = base_dev[:bs].cpu().numpy()
+    qry = queries_dev[:qs].cpu().numpy()
+    cpu_oracle.knn_blas_fp32(base[: min(bs, 20000)], qry[:64], min(k, 100), metric)      # warm-up
+    t0 = time.perf_counter()
+    cpu_oracle.knn_blas_fp32(base, qry, k, metric)
+    dt = time.perf_counter() - t0
+    scale = bs / float(full_b)                                                   # brute force is linear in B
+    return {
+        "value": qs / dt * scale, "unit": "queries/s", "cores": int(blas_threads), "kind": "port",
+        "sample": f"{qs} queries x first {bs} of {full_b} base rows in {dt:.2f}s (numpy sgemm + argpartition, "
+                  f"oracle.cpu_oracle.knn_blas_fp32); rate scaled by {bs}/{full_b} to the full base",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as td
+    from neighborhoodwatch_amd import KnnEngine
+    from neighborhoodwatch_amd.distributed import shard_bounds, sharded_search
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    Q, B, d, k, metric, desc = WORKLOADS[args.workload]
+    lo, hi = shard_bounds(B, world, rank)
+    eng = KnnEngine(local_rank, profile=True)
+    base_raw = eng.generate(SEED_BASE, lo, hi - lo, d)            # this rank's shard, raw row-major f32 in HBM
+    queries = eng.generate(SEED_QUERY, 0, Q, d)                   # replicated
+    host_d = torch.empty((Q, k), dtype=torch.float32).pin_memory() if rank == 0 else None
+    host_i = torch.empty((Q, k), dtype=torch.int64).pin_memory() if rank == 0 else None
+
+    def search_shard(qs, kk, offset):
+        eng.set_base(base_raw)                                    # layout + norms are part of every job
+        return eng.search(qs, kk, metric, index_offset=offset)
+
+    agg = {"tile_ms": 0.0, "tile_flops": 0.0, "tile_launches": 0, "compact_ms": 0.0, "prep_ms": 0.0, "rescan_launches": 0,
+           "overflowed_queries": 0}
+
+    def step(record):
+        dist, idx = sharded_search(search_shard, eng.merge, queries, k, lo, None)
+        if rank == 0:
+            host_d.copy_(dist, non_blocking=True)
+            host_i.copy_(idx, non_blocking=True)
+        torch.cuda.synchronize()
+        if record:
+            s = eng.stats()
+            for key in agg:
+                agg[key] += s[key]
+        return dist, idx
+
+    def fence():
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+        fl = torch.tensor([agg["tile_flops"], agg["tile_ms"]], dtype=torch.float64, device="cuda")
+        td.all_reduce(fl, op=td.ReduceOp.SUM)
+        sum_flops, sum_ms = float(fl[0]), float(fl[1])
+    else:
+        sum_flops, sum_ms = agg["tile_flops"], agg["tile_ms"]
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        qps = Q * args.steps / elapsed
+        achieved = (sum_flops / 1e12) / (sum_ms / 1e3) / world if sum_ms > 0 else 0.0       # per-GPU TFLOP/s of the tile kernel
+        out = {
+            "metric": "queries/sec + pairwise-dist TFLOP/s, 100k x 10M d=1024 k=100" if args.workload == "c3" else f"queries/sec ({args.workload})",
+            "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (seeded counter-based embeddings in [-1,1), generated on device)",
+            "pairwise_tflops": 2.0 * Q * B * d * args.steps / elapsed / 1e12,
+            "config": {"workload": desc, "queries": Q, "base_rows": B, "dim": d, "k": k, "metric": metric,
+                       "parallelism": f"base rows sharded x{world}" + (" + RCCL all-gather of [Q,k] partials + merge" if world > 1 else "")},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "nwk_tile_kernel", "launches": agg["tile_launches"],
+                         "avg_launch_ms": agg["tile_ms"] / max(agg["tile_launches"], 1),
+                         "flops_per_launch": agg["tile_flops"] / max(agg["tile_launches"], 1)},
+            "breakdown_ms_per_step": {"tile": agg["tile_ms"] / args.steps, "compact": agg["compact_ms"] / args.steps,
+                                      "prep": agg["prep_ms"] / args.steps, "rescan_launches": agg["rescan_launches"],
+                                      "overflowed_queries": agg["overflowed_queries"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(eng, base_raw, queries, k, metric, B)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -468,6 +468,8 @@ extern "C" int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int
         HIPCHK(hipEventElapsedTime(&ms, h->ev_begin, h->ev_end));
         h->stats.total_ms = ms;
         ev_collect(h, &h->stats.tile_ms, &h->stats.compact_ms, &h->stats.prep_ms);
+        h->stats.prep_ms += h->base_prep_ms;      // the base layout/norm pass that preceded this search
+        h->base_prep_ms = 0.0;
     }
     return NWKNN_OK;
 }
