@@ -1,0 +1,203 @@
+"""kNN driver, pyarrow.Table flavour -- same entry points as the reference's ``neighborhoodwatch/cu_knn.py``.
+
+    compute_knn(data_dir, model_name, dimensions, query_filename, query_count, base_filename, base_count,
+                mem_tune=False, k=100, initial_batch_size=100000, max_memory_threshold=0.1, split=True)
+    process_batches(data_dir, base_table, query_table, batch_count, batch_size, k, split, engine='raft')
+    tune_memory(table, batch_size, max_memory_threshold, rmm)
+    stream_cudf_to_parquet(filename, df, chunk_size) / cleanup(*args)
+
+Same argument meaning, same failure behaviour (assertions at cu_knn.py:136,177,237,281) and the same on-disk
+result: one ``partial/distances<i>.parquet`` / ``partial/indices<i>.parquet`` pair per base tile, k columns named
+"0".."k-1", float32 / int64, row groups of 100 000 (cu_knn.py:278-285).  What changes is everything between the
+parquet files and the numbers: instead of arrow -> cuDF -> DLPack -> CuPy -> pylibraft per (base tile x query
+tile) with a D2H/H2D bounce per call (cu_knn.py:205-276), a base tile is uploaded once into the HIP engine and
+all queries are searched against it in one call; the engine's running top-k makes the reference's query
+splitting (cu_knn.py:216-225) unnecessary -- ``split`` is accepted and does not change the result.
+
+The reference's ``engine`` argument ('raft' | 'cuvs' | 'torch') selects the distance exactly as there:
+sqeuclidean, cosine, 1 - dot (cu_knn.py:243-262).
+"""
+from __future__ import annotations
+
+import gc
+import math
+from typing import Optional
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.parquet as pq
+
+from .engine import KnnEngine, default_engine, mem_info, resolve_metric
+from .nw_utils import (get_full_filename, get_partial_distances_filename, get_partial_indices_filename,
+                       output_dimension_validity_check)
+
+PARQUET_ROW_GROUP = 100000          # cu_knn.py:284-285
+
+
+# ---- parquet out ---------------------------------------------------------------------------------------
+def _as_arrow_table(df) -> pa.Table:
+    if isinstance(df, pa.Table):
+        return df
+    if isinstance(df, np.ndarray):
+        if df.ndim != 2:
+            raise ValueError("expected a 2-D array")
+        cols = [pa.array(np.ascontiguousarray(df[:, j])) for j in range(df.shape[1])]
+        return pa.Table.from_arrays(cols, names=[str(j) for j in range(df.shape[1])])      # cu_knn.py:278-279
+    return pa.Table.from_pandas(df, preserve_index=False)
+
+
+def stream_cudf_to_parquet(filename, df, chunk_size):
+    """Write a frame as ONE parquet file in ``chunk_size``-row row groups (cu_knn.py:26-51).  ``df`` may be a
+    numpy [rows, k] array (columns get the names "0".."k-1"), a pandas DataFrame or a pyarrow Table."""
+    table = _as_arrow_table(df)
+    writer = pq.ParquetWriter(filename, table.schema)
+    try:
+        for start in range(0, max(len(table), 1), chunk_size):
+            writer.write_table(table.slice(start, chunk_size))
+    finally:
+        writer.close()
+
+
+stream_to_parquet = stream_cudf_to_parquet
+
+
+# ---- parquet in ----------------------------------------------------------------------------------------
+def load_table(data_dir, filename, start, end):
+    """cu_knn.py:112-114 (reads the whole file, then slices)."""
+    return pq.read_table(get_full_filename(data_dir, filename)).slice(start, end)
+
+
+def drop_columns(table, keep_columns):
+    keep = set(keep_columns)
+    return table.select([name for name in table.schema.names if name in keep])             # cu_knn.py:117-123
+
+
+def get_embedding_count(table):
+    return sum(1 for name in table.schema.names if name.startswith("embedding_"))
+
+
+def prep_table(data_dir, model_name, filename, count, dimension):
+    """Load, slice to ``count`` rows, check the number of embedding_* columns, keep only those (cu_knn.py:132-148)."""
+    table = load_table(data_dir, filename, 0, count)
+    total_dimensions = sum("embedding_" in c for c in table.column_names)
+    assert output_dimension_validity_check(model_name, dimension, total_dimensions), \
+        f"Expected {dimension} values, got {total_dimensions} for model {model_name} [filename: {filename}]"
+    return drop_columns(table, [f"embedding_{i}" for i in range(total_dimensions)])
+
+
+def table_to_matrix(table) -> np.ndarray:
+    """Float columns of an arrow table -> dense row-major float32 [rows, d] (the job of
+    ``cp.from_dlpack(df.select_dtypes(float).to_dlpack()).copy(order='C')`` + ``.astype(np.float32)``,
+    cu_knn.py:208-211,243)."""
+    fields = [f for f in table.schema if pa.types.is_float32(f.type) or pa.types.is_float64(f.type)]
+    rows = len(table)
+    out = np.empty((rows, len(fields)), dtype=np.float32)
+    block = 64
+    for j0 in range(0, len(fields), block):
+        cols = [table.column(f.name).to_numpy() for f in fields[j0:j0 + block]]
+        out[:, j0:j0 + len(cols)] = np.stack(cols, axis=1)
+    return out
+
+
+# ---- memory tuning -------------------------------------------------------------------------------------
+def tune_memory(table, batch_size, max_memory_threshold, rmm=None, device: int = 0):
+    """Base-tile rows from the GPU's memory size -- the arithmetic of cu_knn.py:54-109 without the probing
+    allocations: footprint of a tile = rows x (bytes per row of the float columns); first jump by
+    ``ceil(0.2*total/used)``, then the reference's loop, whose only reachable outcomes are
+    ``num_rows`` (tile >= table), ``int(0.8*tile)`` (over the threshold) or -- because ``batch_size *= 1.2`` turns it
+    into a float that ``table.slice`` rejects (cu_knn.py:102-107) -- ``int(0.8*1.2*tile)``.
+    ``rmm`` is accepted for signature compatibility and unused.  Total memory comes from hipMemGetInfo
+    (nwknn_mem_info) instead of NVML (cu_knn.py:62-71)."""
+    num_rows = len(table)
+    print(f"Tuning memory settings (num rows: {num_rows}; initial batch size: {batch_size}) ...")
+    _, total_gpu_memory = mem_info(device)
+    print("-- total memory:", total_gpu_memory)
+    row_bytes = sum(f.type.bit_width // 8 for f in table.schema if pa.types.is_floating(f.type)) or 4
+    memory_used = min(batch_size, num_rows) * row_bytes
+    print(f"-- memory_used {memory_used}")
+    factor = math.ceil((total_gpu_memory * .2) / memory_used)
+    print(f"-- factor {factor}")
+    batch_size *= factor
+    if num_rows < batch_size:
+        print(f"-- the calculated batch size {batch_size} is bigger than total rows {num_rows}. Use total rows as the target batch size!")
+        return num_rows
+    memory_used = batch_size * row_bytes
+    if memory_used > max_memory_threshold * total_gpu_memory:
+        batch_size = int(0.8 * batch_size)
+        print(f"-- found threshold {batch_size}")
+        return batch_size
+    grown = batch_size * 1.2
+    if num_rows < grown:
+        return num_rows
+    batch_size = int(0.8 * grown)
+    print(f"-- max batch size {batch_size}")
+    return batch_size
+
+
+def cleanup(*args):
+    """cu_knn.py:183-190 without RMM: drop references and collect."""
+    del args
+    gc.collect()
+
+
+# ---- the driver ----------------------------------------------------------------------------------------
+def compute_knn(data_dir,
+                model_name,
+                dimensions,
+                query_filename,
+                query_count,
+                base_filename,
+                base_count,
+                mem_tune=False,
+                k=100,
+                initial_batch_size=100000,
+                max_memory_threshold=0.1,
+                split=True,
+                *,
+                engine='raft',
+                metric: Optional[str] = None,
+                device: int = 0):
+    batch_size = initial_batch_size
+    print("-- prepare query source table for brute-force KNN computation.")
+    query_table = prep_table(data_dir, model_name, query_filename, query_count, dimensions)
+    print("-- prepare base source table for brute-force KNN computation.")
+    base_table = prep_table(data_dir, model_name, base_filename, base_count, dimensions)
+
+    if mem_tune:
+        batch_size = tune_memory(base_table, batch_size, max_memory_threshold, None, device)
+
+    batch_count = math.ceil(len(base_table) / batch_size)
+    assert (len(base_table) % batch_size == 0) or k <= (len(base_table) % batch_size), \
+        f"Cannot generate k of {k} with only {len(base_table)} rows and batch_size of {batch_size}."      # cu_knn.py:177-178
+
+    process_batches(data_dir, base_table, query_table, batch_count, batch_size, k, split, engine, metric=metric, device=device)
+
+
+def process_batches(data_dir,
+                    base_table,
+                    query_table,
+                    batch_count,
+                    batch_size,
+                    k,
+                    split,
+                    engine='raft',
+                    *,
+                    metric: Optional[str] = None,
+                    device: int = 0):
+    """One partial (distances, indices) parquet pair per base tile (cu_knn.py:193-287)."""
+    metric = resolve_metric(metric, engine)
+    eng: KnnEngine = default_engine(device)
+    queries = table_to_matrix(query_table)                      # uploaded once per tile call, not once per split
+    for start in range(0, batch_count):
+        batch_offset = start * batch_size
+        batch_length = batch_size if start != batch_count - 1 else len(base_table) - batch_offset
+        dataset = table_to_matrix(base_table.slice(batch_offset, batch_length))
+        assert (k <= len(dataset))                              # cu_knn.py:237
+        print(f"Dataset shape: {dataset.shape}, Query shape: {queries.shape}")
+        eng.set_base(dataset)
+        distances, indices = eng.search(queries, k, metric, index_offset=batch_offset)     # + batch_offset, cu_knn.py:273
+        assert (len(distances) == len(query_table))             # cu_knn.py:281-282
+        assert (len(indices) == len(query_table))
+        stream_cudf_to_parquet(get_partial_distances_filename(data_dir, start), distances, PARQUET_ROW_GROUP)
+        stream_cudf_to_parquet(get_partial_indices_filename(data_dir, start), indices, PARQUET_ROW_GROUP)
+        cleanup(dataset, distances, indices)

@@ -31,8 +31,12 @@ def allgather_partials(dist, idx, group=None):
     world = td.get_world_size(group)
     gd = torch.empty((world,) + tuple(dist.shape), dtype=dist.dtype, device=dist.device)
     gi = torch.empty((world,) + tuple(idx.shape), dtype=idx.dtype, device=idx.device)
-    td.all_gather_into_tensor(gd, dist.contiguous(), group=group)
-    td.all_gather_into_tensor(gi, idx.contiguous(), group=group)
+    if td.get_backend(group) == "nccl":              # RCCL: one ncclAllGather per array straight into the stacked buffer
+        td.all_gather_into_tensor(gd, dist.contiguous(), group=group)
+        td.all_gather_into_tensor(gi, idx.contiguous(), group=group)
+    else:                                            # gloo (CPU tests): list form over views of the same buffer
+        td.all_gather(list(gd.unbind(0)), dist.contiguous(), group=group)
+        td.all_gather(list(gi.unbind(0)), idx.contiguous(), group=group)
     return gd, gi
 
 

@@ -1,0 +1,83 @@
+"""CPU: the C-ABI library loads and exports exactly what include/nwknn.h declares; the product fails loudly
+without a GPU and never reaches for the oracle."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def declared_functions():
+    text = (ROOT / "include" / "nwknn.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nwknn_[a-z_]+)\s*\(", text)))
+
+
+def test_header_and_library_agree():
+    from neighborhoodwatch_amd import _lib
+    L = _lib.load()
+    names = declared_functions()
+    assert len(names) >= 14
+    for name in names:
+        assert hasattr(L, name), f"{name} declared in include/nwknn.h but not exported by libnwknn.so"
+    assert sorted(_lib.EXPORTS) == names
+    assert L.nwknn_version() == 1
+    out = ctypes.string_at(L.nwknn_last_error())
+    assert isinstance(out, bytes)
+
+
+def test_stats_struct_matches_header():
+    from neighborhoodwatch_amd._lib import NwknnStats
+    text = (ROOT / "include" / "nwknn.h").read_text()
+    body = text[text.index("typedef struct nwknn_stats {"):text.index("} nwknn_stats;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        _, names = decl.split(None, 1)
+        fields += [n.strip() for n in names.split(",")]
+    assert fields == [n for n, _ in NwknnStats._fields_]
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    from neighborhoodwatch_amd import _lib
+    L = _lib.load()
+    assert L.nwknn_create(None, 0) == -1                       # NWKNN_EINVAL, message retrievable
+    assert b"null" in L.nwknn_last_error()
+    assert L.nwknn_set_option(None, b"capacity", 1024) == -1
+    assert L.nwknn_search(None, None, 1, 0, 1, 0, 0, None, None, 0) == -1
+    assert L.nwknn_destroy(None) == 0
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from neighborhoodwatch_amd import KnnEngine, knn
+    from neighborhoodwatch_amd._lib import NwknnError
+    import numpy as np
+    with pytest.raises(NwknnError):
+        KnnEngine(0)
+    with pytest.raises(NwknnError):
+        knn(np.zeros((4, 4), np.float32), np.zeros((1, 4), np.float32), 1)
+
+
+def test_missing_library_is_reported(monkeypatch, tmp_path):
+    from neighborhoodwatch_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "libnwknn.so")
+    with pytest.raises(_lib.NwknnError, match="has not been built"):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    for path in (ROOT / "neighborhoodwatch_amd").rglob("*.py"):
+        src = path.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{path} imports the oracle"
+        assert "libnwknn_oracle" not in src
+    for path in (ROOT / "neighborhoodwatch_amd" / "csrc").iterdir():
+        assert "oracle/" not in path.read_text().replace("oracle/nwknn_oracle.c", "").replace("oracle/cpu_oracle", ""), path

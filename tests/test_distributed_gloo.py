@@ -1,0 +1,59 @@
+"""CPU, world_size 2, gloo: the multi-rank path (shard -> search with global ids -> all-gather -> merge).
+The GPU kernels are replaced by the oracle HERE ONLY (tests may use it); production passes KnnEngine.search/merge."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as td
+    from neighborhoodwatch_amd.distributed import shard_bounds, sharded_search
+    from oracle import cpu_oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    B, Q, d, k = 1003, 21, 40, 16
+    lo, hi = shard_bounds(B, world, rank)
+    base = orc.gen(orc.SEED_BASE, lo, hi - lo, d)          # every rank generates only its shard
+    queries = torch.from_numpy(orc.gen(orc.SEED_QUERY, 0, Q, d))
+
+    def search_shard(qs, kk, offset):
+        dd, ii = orc.knn_canonical(base, qs.numpy(), kk, "sqeuclidean")
+        return torch.from_numpy(dd), torch.from_numpy(ii + offset)
+
+    def merge(gd, gi, kk):
+        dd, ii = orc.merge_partials(gd.numpy(), gi.numpy(), kk)
+        return torch.from_numpy(dd), torch.from_numpy(ii)
+
+    dist, idx = sharded_search(search_shard, merge, queries, k, lo, None)
+    np.savez(Path(out_dir) / f"rank{rank}.npz", dist=dist.numpy(), idx=idx.numpy())
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_sharded_search_equals_single_shard(tmp_path, oracle):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    base = oracle.gen(oracle.SEED_BASE, 0, 1003, 40)
+    queries = oracle.gen(oracle.SEED_QUERY, 0, 21, 40)
+    rd, ri = oracle.knn_canonical(base, queries, 16, "sqeuclidean")
+    for r in range(world):
+        g = np.load(tmp_path / f"rank{r}.npz")
+        assert np.array_equal(g["idx"], ri), f"rank {r}: merged ids differ from the single-shard result"
+        assert np.array_equal(g["dist"].view(np.uint32), rd.view(np.uint32))

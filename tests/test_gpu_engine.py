@@ -1,0 +1,186 @@
+"""GPU: the HIP path through the C ABI -- golden fixtures, edge cases, error behaviour, the overflow/rescan slow path,
+the merge kernel, virtual multi-shard runs, determinism."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from test_oracle_golden import KNN_CASES, golden_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_bits(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+
+
+@pytest.mark.parametrize("name", sorted(KNN_CASES))
+def test_hip_reproduces_golden_fixtures(engine, oracle, name):
+    g = np.load(GOLDEN / f"knn_{name}.npz")
+    base, queries = golden_inputs(oracle, name)
+    engine.set_base(base)
+    d, i = engine.search(queries, int(g["k"]), str(g["metric"]))
+    n = g["canon_idx"].shape[0]
+    assert np.array_equal(i[:n], g["canon_idx"].astype(np.int64))
+    assert _same_bits(d[:n], g["canon_dist"])
+    exact_d, _ = oracle.knn_exact_fp64(base, queries, int(g["k"]), str(g["metric"]))
+    oracle.check_against_exact(base, queries, d, i, exact_d, str(g["metric"]))     # 1e-5 bar vs float64 truth
+
+
+def test_exact_duplicates_resolve_to_the_lower_index(engine, oracle):
+    base, queries = golden_inputs(oracle, "g3_dups_d100")
+    engine.set_base(base)
+    d, i = engine.search(queries, 16, "sqeuclidean")
+    # every row 350+j is a copy of row j: both must appear, lower id first, identical distance
+    for r in range(len(queries)):
+        for a in range(15):
+            if d[r, a] == d[r, a + 1]:
+                assert i[r, a] < i[r, a + 1]
+    assert (d[-5:, 0] == 0).all() and (i[-5:, 0] == np.arange(5)).all() and (i[-5:, 1] == np.arange(5) + 350).all()
+
+
+def test_operator_contract_and_one_shot_knn(oracle):
+    """knn(dataset, queries, k) -> (distances f32 C-contiguous [q,k], indices i64 [q,k]), ascending (cu_knn.py:243-245)."""
+    from neighborhoodwatch_amd import knn
+    base, queries = oracle.gen(21, 0, 900, 48), oracle.gen(22, 0, 30, 48)
+    d, i = knn(base, queries, 12)
+    assert d.dtype == np.float32 and i.dtype == np.int64 and d.shape == i.shape == (30, 12)
+    assert d.flags["C_CONTIGUOUS"] and i.flags["C_CONTIGUOUS"]
+    assert (np.diff(d, axis=1) >= 0).all()
+    rd, ri = oracle.knn_canonical(base, queries, 12)
+    assert np.array_equal(i, ri) and _same_bits(d, rd)
+    d64, i64_ = knn(base.astype(np.float64), queries.astype(np.float64), 12, engine="torch")     # float64 tolerated, cast (cu_knn.py:243)
+    rd, ri = oracle.knn_canonical(base, queries, 12, "one_minus_dot")
+    assert np.array_equal(i64_, ri) and _same_bits(d64, rd)
+
+
+def test_errors_mirror_the_reference_assertions(engine, oracle):
+    base = oracle.gen(1, 0, 50, 16)
+    engine.set_base(base)
+    with pytest.raises(ValueError):            # assert k <= len(dataset), cu_knn.py:237
+        engine.search(oracle.gen(2, 0, 3, 16), 51)
+    with pytest.raises(ValueError):
+        engine.search(oracle.gen(2, 0, 3, 16), 0)
+    with pytest.raises(ValueError):            # dimension mismatch
+        engine.search(oracle.gen(2, 0, 3, 17), 5)
+    with pytest.raises(ValueError):
+        engine.search(np.zeros((0, 16), np.float32), 5)
+    with pytest.raises(ValueError):
+        engine.set_base(np.zeros((0, 16), np.float32))
+    with pytest.raises(ValueError):
+        engine.set_option("capacity", 1000)     # not a power of two
+    with pytest.raises(ValueError):
+        engine.search(oracle.gen(2, 0, 3, 16), 5, "manhattan")
+    d, i = engine.search(oracle.gen(2, 0, 3, 16), 50)         # k == rows is allowed
+    assert sorted(i[0].tolist()) == list(range(50))
+
+
+def test_index_offset_is_added_like_batch_offset(engine, oracle):
+    base, queries = oracle.gen(31, 0, 400, 24), oracle.gen(32, 0, 10, 24)
+    engine.set_base(base)
+    d0, i0 = engine.search(queries, 7)
+    d1, i1 = engine.search(queries, 7, index_offset=5_000_000_000)        # beyond int32: ids are int64 (cu_knn.py:273)
+    assert np.array_equal(i1, i0 + 5_000_000_000) and _same_bits(d0, d1)
+
+
+def test_device_resident_inputs_and_outputs(engine, oracle):
+    import torch
+    base, queries = oracle.gen(41, 0, 2500, 96), oracle.gen(42, 0, 130, 96)
+    tb, tq = torch.from_numpy(base).cuda(), torch.from_numpy(queries).cuda()
+    engine.set_base(tb)
+    d, i = engine.search(tq, 20, "cosine")
+    assert d.is_cuda and i.is_cuda and d.dtype == torch.float32 and i.dtype == torch.int64
+    rd, ri = oracle.knn_canonical(base, queries, 20, "cosine")
+    assert np.array_equal(i.cpu().numpy(), ri) and _same_bits(d.cpu().numpy(), rd)
+
+
+def test_device_generator_equals_host_generator(engine, oracle):
+    x = engine.generate(oracle.SEED_BASE, 12345, 300, 130).cpu().numpy()
+    assert np.array_equal(x, oracle.gen_numpy(oracle.SEED_BASE, 12345, 300, 130))
+
+
+@pytest.mark.parametrize("order", ["approaching", "random"])
+def test_list_overflow_is_repaired_exactly(oracle, order):
+    """Adversarial arrival order: every later base row is closer to the query than all earlier ones, so every row
+    passes the threshold filter and the small candidate lists overflow; the repair pass must still give the exact result."""
+    from neighborhoodwatch_amd import KnnEngine
+    d, B, Q, k = 32, 6000, 140, 10
+    rng = np.random.default_rng(5)
+    centre = rng.standard_normal(d).astype(np.float32)
+    base = (centre[None, :] + rng.standard_normal((B, d)).astype(np.float32) * np.linspace(4.0, 0.05, B, dtype=np.float32)[:, None]).astype(np.float32)
+    if order == "random":
+        base = base[rng.permutation(B)]
+    queries = (centre[None, :] + 0.01 * rng.standard_normal((Q, d))).astype(np.float32)
+    with KnnEngine(0) as eng:
+        eng.set_option("capacity", 256)
+        eng.set_option("first_chunk", 128)
+        eng.set_base(base)
+        dist, idx = eng.search(queries, k)
+        st = eng.stats()
+    rd, ri = oracle.knn_canonical(base, queries, k)
+    assert np.array_equal(idx, ri) and _same_bits(dist, rd)
+    if order == "approaching":
+        assert st["overflowed_queries"] > 0 and st["rescan_launches"] > 0, "the test did not reach the repair path"
+
+
+def test_small_chunks_do_not_change_the_result(oracle):
+    from neighborhoodwatch_amd import KnnEngine
+    base, queries = oracle.gen(51, 0, 9000, 64), oracle.gen(52, 0, 257, 64)
+    rd, ri = oracle.knn_canonical(base, queries, 33)
+    for max_chunk, first in [(128, 128), (1024, 256), (1 << 20, 0)]:
+        with KnnEngine(0) as eng:
+            eng.set_option("max_chunk", max_chunk)
+            eng.set_option("first_chunk", first)
+            eng.set_base(base)
+            d, i = eng.search(queries, 33)
+        assert np.array_equal(i, ri) and _same_bits(d, rd)
+
+
+def test_large_k(engine, oracle):
+    base, queries = oracle.gen(61, 0, 6000, 40), oracle.gen(62, 0, 20, 40)
+    engine.set_base(base)
+    for k in (1000, 1024):
+        d, i = engine.search(queries, k, "one_minus_dot")        # ck runs 1 - dot (colbert_knn.py:94)
+        rd, ri = oracle.knn_canonical(base, queries, k, "one_minus_dot")
+        assert np.array_equal(i, ri) and _same_bits(d, rd)
+    with pytest.raises(ValueError):
+        engine.search(queries, 1025)
+
+
+@pytest.mark.parametrize("name", ["basic", "ties", "single", "nine"])
+def test_merge_kernel_matches_reference_merge_outputs(engine, oracle, name):
+    g = np.load(GOLDEN / f"merge_{name}.npz")          # produced by the reference's merge.py
+    k = int(g["k"])
+    d, i = engine.merge(g["in_dist"], g["in_idx"], k)
+    assert _same_bits(d, g["out_dist"])
+    od, oi = oracle.merge_partials(g["in_dist"], g["in_idx"], k)
+    assert np.array_equal(i, oi) and _same_bits(d, od)     # (distance, index) order, identical to the oracle
+    if name != "ties":
+        assert np.array_equal(i, g["out_idx"])             # no equal distances: ids equal the reference's too
+
+
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_virtual_shards_on_one_gpu_equal_the_single_shard_result(engine, oracle, shards):
+    """The N-rank path on one device: search each contiguous shard with its global offset, merge on the GPU."""
+    from neighborhoodwatch_amd.distributed import shard_bounds
+    base, queries = oracle.gen(71, 0, 5003, 72), oracle.gen(72, 0, 64, 72)
+    k = 25
+    pd, pi = [], []
+    for r in range(shards):
+        lo, hi = shard_bounds(len(base), shards, r)
+        engine.set_base(base[lo:hi])
+        d, i = engine.search(queries, k, index_offset=lo)
+        pd.append(d); pi.append(i)
+    md, mi = engine.merge(np.stack(pd), np.stack(pi), k)
+    engine.set_base(base)
+    d1, i1 = engine.search(queries, k)
+    assert np.array_equal(mi, i1) and _same_bits(md, d1)
+    rd, ri = oracle.knn_canonical(base, queries, k)
+    assert np.array_equal(mi, ri) and _same_bits(md, rd)
+
+
+def test_runs_are_bitwise_reproducible(engine, oracle):
+    base, queries = oracle.gen(81, 0, 20000, 128), oracle.gen(82, 0, 500, 128)
+    engine.set_base(base)
+    a = engine.search(queries, 100)
+    b = engine.search(queries, 100)
+    assert np.array_equal(a[1], b[1]) and _same_bits(a[0], b[0])

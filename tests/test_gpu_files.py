@@ -1,0 +1,121 @@
+"""GPU: the on-disk contract end to end -- source parquet -> compute_knn / compute_knn_ds -> partial parquet ->
+merge_indices_and_distances -> final parquet, compared with the oracle on the whole base."""
+import numpy as np
+import pyarrow as pa
+import pyarrow.parquet as pq
+import pytest
+
+from neighborhoodwatch_amd import cu_knn, cu_knn_ds, merge, nw_utils, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _final(data_dir):
+    fi = pq.read_table(nw_utils.get_partial_indices_filename(data_dir, -1))
+    fd = pq.read_table(nw_utils.get_partial_distances_filename(data_dir, -1))
+    return fd, fi
+
+
+def _arr(t, dtype):
+    return np.stack([t.column(j).to_numpy() for j in range(t.num_columns)], axis=1).astype(dtype)
+
+
+@pytest.fixture()
+def dataset(tmp_path):
+    data_dir = nw_utils.setup_model_output_folder(str(tmp_path), "intfloat/e5-small-v2", 300, 2600, 10)
+    qf = nw_utils.get_source_query_dataset_filename(data_dir, "intfloat/e5-small-v2", 300, 384)
+    bf = nw_utils.get_source_base_dataset_filename(data_dir, "intfloat/e5-small-v2", 2600, 384)
+    synth.write_source_parquet(qf, 0x71, 300, 384, normalize=True)
+    synth.write_source_parquet(bf, 0x72, 2600, 384, normalize=True, chunk_rows=700)
+    return data_dir, qf, bf
+
+
+def test_compute_knn_then_merge_equals_oracle(dataset, oracle):
+    data_dir, qf, bf = dataset
+    # 2600 base rows in tiles of 1000 -> 3 partial pairs (1000, 1000, 600), cu_knn.py:176,201-205
+    cu_knn.compute_knn(data_dir, "intfloat/e5-small-v2", 384, qf, 300, bf, 2600, False, 10, 1000)
+    assert merge.get_file_count(f"{data_dir}/partial") == 3
+    p1 = pq.read_table(nw_utils.get_partial_indices_filename(data_dir, 1))
+    assert p1.schema.names == [str(c) for c in range(10)] and len(p1) == 300             # cu_knn.py:278-282
+    assert all(pa.types.is_int64(f.type) for f in p1.schema)
+    ids1 = _arr(p1, np.int64)
+    assert ids1.min() >= 1000 and ids1.max() < 2000                                       # + batch_offset, cu_knn.py:273
+    pd1 = pq.read_table(nw_utils.get_partial_distances_filename(data_dir, 1))
+    assert all(pa.types.is_float32(f.type) for f in pd1.schema)
+
+    merge.merge_indices_and_distances(data_dir, k=10)
+    fd, fi = _final(data_dir)
+    assert fd.schema.names == fi.schema.names == [str(c) for c in range(10)]
+    assert all(pa.types.is_float32(f.type) for f in fd.schema) and all(pa.types.is_int64(f.type) for f in fi.schema)
+    base = synth.gen_unit_rows(0x72, 0, 2600, 384); queries = synth.gen_unit_rows(0x71, 0, 300, 384)
+    rd, ri = oracle.knn_canonical(base, queries, 10)
+    assert np.array_equal(_arr(fi, np.int64), ri)
+    assert np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
+    # the reference's own validator: isclose(1 - dot(q, b), distance / 2)   (parquet_to_format.py:368-373)
+    d = _arr(fd, np.float32); i = _arr(fi, np.int64)
+    for r in range(0, 300, 29):
+        assert np.isclose(1.0 - base[i[r]].astype(np.float64) @ queries[r].astype(np.float64), d[r] / 2.0).all()
+
+
+def test_single_tile_merge_is_a_pass_through(dataset, oracle):
+    data_dir, qf, bf = dataset
+    cu_knn.compute_knn(data_dir, "intfloat/e5-small-v2", 384, qf, 300, bf, 2600, False, 10, 100000, engine="torch")
+    assert merge.get_file_count(f"{data_dir}/partial") == 1
+    merge.merge_indices_and_distances(data_dir, k=10)                                     # merge.py:67-69
+    fd, fi = _final(data_dir)
+    base = synth.gen_unit_rows(0x72, 0, 2600, 384); queries = synth.gen_unit_rows(0x71, 0, 300, 384)
+    rd, ri = oracle.knn_canonical(base, queries, 10, "one_minus_dot")
+    assert np.array_equal(_arr(fi, np.int64), ri) and np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
+
+
+def test_row_counts_slice_the_files(dataset, oracle):
+    data_dir, qf, bf = dataset
+    cu_knn.compute_knn(data_dir, "intfloat/e5-small-v2", 384, qf, 120, bf, 1500, False, 10, 500, engine="cuvs")   # .slice(0,count), cu_knn.py:114
+    merge.merge_indices_and_distances(data_dir, k=10)
+    fd, fi = _final(data_dir)
+    base = synth.gen_unit_rows(0x72, 0, 1500, 384); queries = synth.gen_unit_rows(0x71, 0, 120, 384)
+    rd, ri = oracle.knn_canonical(base, queries, 10, "cosine")
+    assert len(fi) == 120 and np.array_equal(_arr(fi, np.int64), ri)
+    assert np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
+
+
+def test_dataset_api_writes_the_final_tables_once(dataset, oracle):
+    data_dir, qf, bf = dataset
+    cu_knn_ds.compute_knn_ds(data_dir, 384, qf, 300, bf, 2600, False, 10, 800)            # 4 base batches: 800,800,800,200
+    assert merge.get_file_count(f"{data_dir}/partial") == 0
+    merge.merge_indices_and_distances(data_dir, k=10)                                     # no partial files: no-op, merge.py:40-42
+    fd, fi = _final(data_dir)
+    base = synth.gen_unit_rows(0x72, 0, 2600, 384); queries = synth.gen_unit_rows(0x71, 0, 300, 384)
+    rd, ri = oracle.knn_canonical(base, queries, 10)
+    assert np.array_equal(_arr(fi, np.int64), ri) and np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
+
+
+def test_merge_drops_rownum_and_handles_many_lists(tmp_path, oracle):
+    """tests/test_03_merge.py:14-24 writes a RowNum column next to the k columns."""
+    import pandas as pd
+    rng = np.random.default_rng(8)
+    n, q, k = 50, 33, 100                              # 50*100 = 5000 entries per query: folded in groups on the GPU
+    (tmp_path / "partial").mkdir()
+    ds, is_ = [], []
+    for l in range(n):
+        d = np.sort(rng.random((q, k)).astype(np.float32), axis=1)
+        i = rng.integers(0, 10 ** 9, size=(q, k)).astype(np.int64)
+        ds.append(d); is_.append(i)
+        ddf = pd.DataFrame(d, columns=[str(c) for c in range(k)]); ddf["RowNum"] = np.arange(q)
+        idf = pd.DataFrame(i, columns=[str(c) for c in range(k)]); idf["RowNum"] = np.arange(q)
+        ddf.to_parquet(tmp_path / "partial" / f"distances{l}.parquet"); idf.to_parquet(tmp_path / "partial" / f"indices{l}.parquet")
+    merge.merge_indices_and_distances(str(tmp_path), k=k)
+    fd, fi = _final(str(tmp_path))
+    assert fd.schema.names == [str(c) for c in range(k)]
+    rd, ri = oracle.merge_partials(np.stack(ds), np.stack(is_), k)
+    assert np.array_equal(_arr(fi, np.int64), ri) and np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
+
+
+def test_cli_end_to_end(tmp_path, oracle):
+    from neighborhoodwatch_amd.neighborhoodwatch import main
+    assert main(["200", "3000", "-k", "20", "-m", "intfloat/e5-small-v2", "--data-dir", str(tmp_path), "--disable-memory-tuning"]) == 0
+    data_dir = nw_utils.get_model_data_homedir(str(tmp_path), "intfloat/e5-small-v2", 200, 3000, 20)
+    fd, fi = _final(data_dir)
+    base = synth.gen_rows(synth.SEED_BASE, 0, 3000, 384); queries = synth.gen_rows(synth.SEED_QUERY, 0, 200, 384)
+    rd, ri = oracle.knn_canonical(base, queries, 20)
+    assert np.array_equal(_arr(fi, np.int64), ri) and np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))

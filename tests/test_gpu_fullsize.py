@@ -1,0 +1,40 @@
+"""GPU: BASELINE.json config 2 at full size (10k x 1M, d=768, k=100) checked through size-independent properties and
+a sampled recomputation on the CPU oracle against the WHOLE base."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.timeout(900)
+def test_c2_full_size_properties_and_sampled_parity(oracle):
+    import torch
+    from neighborhoodwatch_amd import KnnEngine
+    Q, B, d, k = 10_000, 1_000_000, 768, 100
+    with KnnEngine(0) as eng:
+        base = eng.generate(oracle.SEED_BASE, 0, B, d)
+        queries = eng.generate(oracle.SEED_QUERY, 0, Q, d)
+        eng.set_base(base)
+        dist, idx = eng.search(queries, k)
+        dist2, idx2 = eng.search(queries, k)
+        st = eng.stats()
+        # queries that ARE base rows must find themselves first at distance exactly 0
+        probe = base[123_456:123_456 + 64].clone()
+        pd_, pi_ = eng.search(probe, 3)
+    assert torch.equal(idx, idx2) and torch.equal(dist, dist2)                      # deterministic
+    assert st["overflowed_queries"] == 0
+    di, ii = dist.cpu().numpy(), idx.cpu().numpy()
+    assert (np.diff(di, axis=1) >= 0).all()                                          # ascending (merge.py:104)
+    assert ii.min() >= 0 and ii.max() < B
+    srt = np.sort(ii, axis=1)
+    assert (srt[:, 1:] != srt[:, :-1]).all()                                         # no duplicate neighbours
+    assert (pi_[:, 0].cpu().numpy() == np.arange(123_456, 123_456 + 64)).all() and (pd_[:, 0].cpu().numpy() == 0).all()
+    # sampled parity: 48 query rows recomputed by the canonical CPU oracle against all 1M base rows, bit for bit
+    rows = np.linspace(0, Q - 1, 48).astype(np.int64)
+    hb = base.cpu().numpy()
+    hq = queries[torch.from_numpy(rows).cuda()].cpu().numpy()
+    rd, ri = oracle.knn_canonical(hb, hq, k)
+    assert np.array_equal(ii[rows], ri)
+    assert np.array_equal(di[rows].view(np.uint32), rd.view(np.uint32))
+    # regenerated on the host, the inputs are what the device generator wrote
+    assert np.array_equal(hb[777_000:777_004], oracle.gen_numpy(oracle.SEED_BASE, 777_000, 4, d))

@@ -1,0 +1,172 @@
+"""CPU: host-side mirror of the reference interface -- naming contract, memory-tuning arithmetic, parquet schema,
+CLI surface, sharding arithmetic.  No GPU compute is invoked."""
+import inspect
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.parquet as pq
+import pytest
+
+from neighborhoodwatch_amd import cu_knn, cu_knn_ds, merge, nw_utils, synth
+from neighborhoodwatch_amd.distributed import shard_bounds
+from neighborhoodwatch_amd.engine import resolve_metric
+
+
+def test_partial_and_final_filenames():
+    # nw_utils.py:94-107 -- the names are the API between the kNN stage and the merge stage
+    assert nw_utils.get_partial_indices_filename("/d/m/q1_b2_k3", 0) == "/d/m/q1_b2_k3/partial/indices0.parquet"
+    assert nw_utils.get_partial_distances_filename("/d/m/q1_b2_k3", 12) == "/d/m/q1_b2_k3/partial/distances12.parquet"
+    assert nw_utils.get_partial_indices_filename("x", -1) == "x/partial/final_indices.parquet"
+    assert nw_utils.get_partial_distances_filename("x", -1) == "x/partial/final_distances.parquet"
+
+
+def test_output_folder_and_source_names(tmp_path):
+    d = nw_utils.setup_model_output_folder(str(tmp_path), "intfloat/e5-small-v2", 1000, 10000, 100)
+    assert d == f"{tmp_path}/intfloat_e5-small-v2/q1000_b10000_k100"                         # nw_utils.py:62-73
+    assert (tmp_path / "intfloat_e5-small-v2" / "q1000_b10000_k100" / "partial").is_dir()
+    assert nw_utils.get_source_query_dataset_filename(d, "intfloat/e5-small-v2", 1000, 384).endswith(
+        "/intfloat_e5-small-v2_384_query_vector_data_1000.parquet")                         # nw_utils.py:76-82
+    assert nw_utils.get_source_base_dataset_filename(d, "voyage-3-large", 5, 1024, "int8").endswith(
+        "/voyage-3-large_1024_int8_base_vector_data_5.parquet")
+    assert nw_utils.get_full_filename("a/b", "c.parquet") == "a/b/c.parquet"
+    assert nw_utils.get_full_filename("a/b", "a/b/c.parquet") == "a/b/c.parquet"
+
+
+def test_model_dimension_table():
+    # model_generator.py:61-113
+    assert nw_utils.get_default_model_dimension_size("intfloat/e5-small-v2") == 384
+    assert nw_utils.get_default_model_dimension_size("intfloat/e5-large-v2") == 1024
+    assert nw_utils.get_default_model_dimension_size("text-embedding-ada-002") == 1536
+    assert nw_utils.get_default_model_dimension_size("colbertv2.0") == 128
+    assert nw_utils.get_effective_embedding_size("text-embedding-3-large", 256) == 256
+    assert nw_utils.get_effective_embedding_size("intfloat/e5-base-v2", 256) == 768        # size ignored
+    with pytest.raises(AssertionError):
+        nw_utils.get_effective_embedding_size("text-embedding-3-small", 4096)
+    assert len(nw_utils.get_valid_model_name_list()) == 15
+    assert nw_utils.output_dimension_validity_check("voyage-3-large", 1024, 128)
+    assert not nw_utils.output_dimension_validity_check("intfloat/e5-base-v2", 768, 96)
+
+
+def test_signatures_match_the_reference():
+    # cu_knn.py:151-162, :193-200, :54, cu_knn_ds.py:136-146, merge.py:39
+    p = list(inspect.signature(cu_knn.compute_knn).parameters.values())
+    assert [x.name for x in p[:12]] == ["data_dir", "model_name", "dimensions", "query_filename", "query_count", "base_filename",
+                                        "base_count", "mem_tune", "k", "initial_batch_size", "max_memory_threshold", "split"]
+    assert [x.default for x in p[7:12]] == [False, 100, 100000, 0.1, True]
+    assert all(x.kind is inspect.Parameter.KEYWORD_ONLY for x in p[12:])
+    p = list(inspect.signature(cu_knn.process_batches).parameters.values())
+    assert [x.name for x in p[:8]] == ["data_dir", "base_table", "query_table", "batch_count", "batch_size", "k", "split", "engine"]
+    assert p[7].default == "raft"
+    p = list(inspect.signature(cu_knn_ds.compute_knn_ds).parameters.values())
+    assert [x.name for x in p[:11]] == ["data_dir", "dimensions", "query_filename", "query_count", "base_filename", "base_count",
+                                        "mem_tune", "k", "initial_batch_size", "max_memory_threshold", "split"]
+    assert [x.default for x in p[6:11]] == [False, 100, 200000, 0.2, True]
+    p = list(inspect.signature(merge.merge_indices_and_distances).parameters.values())
+    assert [x.name for x in p[:2]] == ["data_dir", "k"] and p[1].default == 100
+    assert [x.name for x in inspect.signature(cu_knn.tune_memory).parameters.values()][:4] == ["table", "batch_size", "max_memory_threshold", "rmm"]
+
+
+def test_engine_names_select_the_reference_distances():
+    assert resolve_metric(None, "raft") == "sqeuclidean"       # cu_knn.py:243-245
+    assert resolve_metric(None, "cuvs") == "cosine"            # cu_knn.py:247-248
+    assert resolve_metric(None, "torch") == "one_minus_dot"    # cu_knn.py:256-257
+    with pytest.raises(ValueError):
+        resolve_metric(None, "faiss")
+    with pytest.raises(ValueError):
+        resolve_metric("manhattan")
+
+
+def test_tune_memory_reproduces_the_readme_run(monkeypatch):
+    """docs/cli.png: 16 GiB card, 100k-row probe of d=1536 float32 = 614 400 000 B, factor 6, threshold 480 000."""
+    monkeypatch.setattr(cu_knn, "mem_info", lambda device=0: (0, 17179869184))
+    table = pa.table({f"embedding_{i}": pa.array(np.zeros(4, np.float32)) for i in range(1536)})
+
+    class Big:                       # 4M-row table without allocating it
+        schema = table.schema
+        def __len__(self): return 4_000_000
+    assert cu_knn.tune_memory(Big(), 100000, 0.1, None) == 480000
+    class Small(Big):
+        def __len__(self): return 300_000
+    assert cu_knn.tune_memory(Small(), 100000, 0.1, None) == 300_000       # tile >= table -> whole table
+    # under the threshold the reference's float batch size trips table.slice and lands on 0.8*1.2 (cu_knn.py:100-107)
+    assert cu_knn.tune_memory(Big(), 100000, 0.5, None) == int(0.8 * (600000 * 1.2))
+
+
+def test_tune_memory_on_a_288gb_card(monkeypatch):
+    monkeypatch.setattr(cu_knn, "mem_info", lambda device=0: (0, 288 * 2 ** 30))
+    schema = pa.schema([(f"embedding_{i}", pa.float32()) for i in range(1024)])
+    class Base:
+        def __len__(self): return 10_000_000
+    Base.schema = schema
+    assert cu_knn.tune_memory(Base(), 100000, 0.1, None) == 10_000_000     # the whole C3 base is one tile
+
+
+def test_get_file_count_counts_only_numbered_index_files(tmp_path):
+    p = tmp_path / "partial"; p.mkdir()
+    for name in ["indices0.parquet", "indices1.parquet", "indices12.parquet", "final_indices.parquet", "distances0.parquet",
+                 "indicesX.parquet", "indices3.parquet.tmp"]:
+        (p / name).write_bytes(b"")
+    assert merge.get_file_count(str(p)) == 3                              # merge.py:15-27
+    assert merge.get_file_count(str(tmp_path / "nothing")) == 0
+
+
+def test_stream_to_parquet_contract(tmp_path):
+    a = np.arange(250 * 7, dtype=np.float32).reshape(250, 7)
+    f = tmp_path / "distances0.parquet"
+    cu_knn.stream_cudf_to_parquet(str(f), a, 100)
+    md = pq.ParquetFile(f)
+    assert md.metadata.num_row_groups == 3 and md.metadata.num_rows == 250   # chunk_size rows per group, cu_knn.py:26-51
+    t = pq.read_table(f)
+    assert t.schema.names == [str(i) for i in range(7)]                      # cu_knn.py:278-279
+    assert all(pa.types.is_float32(x.type) for x in t.schema)
+    i = np.arange(20, dtype=np.int64).reshape(4, 5)
+    cu_knn.stream_cudf_to_parquet(str(tmp_path / "i.parquet"), i, 100000)
+    assert all(pa.types.is_int64(x.type) for x in pq.read_table(tmp_path / "i.parquet").schema)
+
+
+def test_prep_table_and_matrix(tmp_path):
+    f = synth.write_source_parquet(str(tmp_path / "m_8_base_vector_data_30.parquet"), 5, 30, 8, chunk_rows=16)
+    t = cu_knn.prep_table(str(tmp_path), "m", "m_8_base_vector_data_30.parquet", 20, 8)
+    assert t.schema.names == [f"embedding_{i}" for i in range(8)] and len(t) == 20      # cu_knn.py:132-148
+    m = cu_knn.table_to_matrix(t)
+    assert m.dtype == np.float32 and m.flags["C_CONTIGUOUS"] and np.array_equal(m, synth.gen_rows(5, 0, 20, 8))
+    with pytest.raises(AssertionError, match="Expected 9 values, got 8"):
+        cu_knn.prep_table(str(tmp_path), "m", "m_8_base_vector_data_30.parquet", 20, 9)  # cu_knn.py:136-137
+    full = pq.read_table(f)
+    assert full.schema.names[:4] == ["document_id_idx", "text", "title", "document_id"]  # tests/test_02_cu_knn.py:15-22
+
+
+def test_compute_knn_rejects_a_last_tile_smaller_than_k(tmp_path):
+    synth.write_source_parquet(str(tmp_path / "q.parquet"), 1, 4, 8)
+    synth.write_source_parquet(str(tmp_path / "b.parquet"), 2, 105, 8)
+    with pytest.raises(AssertionError, match="Cannot generate k of 10 with only 105 rows and batch_size of 100"):
+        cu_knn.compute_knn(str(tmp_path), "m", 8, "q.parquet", 4, "b.parquet", 105, False, 10, 100)   # cu_knn.py:177-178
+
+
+def test_shard_bounds_cover_the_base_exactly():
+    for n, w in [(10_000_000, 8), (1003, 7), (5, 5), (130, 2)]:
+        edges = [shard_bounds(n, w, r) for r in range(w)]
+        assert edges[0][0] == 0 and edges[-1][1] == n
+        assert all(edges[r][1] == edges[r + 1][0] for r in range(w - 1))
+        sizes = [hi - lo for lo, hi in edges]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+def test_product_generator_equals_the_oracle_generator(oracle):
+    assert np.array_equal(synth.gen_rows(synth.SEED_BASE, 11, 40, 50), oracle.gen_numpy(oracle.SEED_BASE, 11, 40, 50))
+    assert np.array_equal(synth.gen_unit_rows(9, 0, 40, 384), oracle.gen_unit_rows(9, 0, 40, 384))
+    u = synth.gen_unit_rows(9, 0, 40, 384)
+    assert np.abs(np.linalg.norm(u.astype(np.float64), axis=1) - 1).max() < 2e-7        # tests/test_02_cu_knn.py:38-41
+
+
+def test_cli_keeps_the_reference_flags():
+    from neighborhoodwatch_amd.neighborhoodwatch import build_parser
+    a = build_parser().parse_args(["1000", "10000", "-k", "100", "-m", "intfloat/e5-small-v2", "--disable-memory-tuning"])
+    assert (a.query_count, a.base_count, a.k, a.model_name) == (1000, 10000, 100, "intfloat/e5-small-v2")
+    assert a.enable_memory_tuning is False and a.use_dataset_api is False and a.gen_hdf5 is True and a.post_validation is False
+    assert a.data_dir == "knn_dataset" and a.output_dtype == "float" and a.output_dimension_size is None
+    a = build_parser().parse_args(["1", "2", "-m", "x", "--enable-memory-tuning", "--use-dataset-api", "--no-gen-hdf5", "-ods", "256",
+                                   "-odt", "int8", "--data-dir", "/tmp/x", "--post-validation"])
+    assert a.enable_memory_tuning and a.use_dataset_api and not a.gen_hdf5 and a.output_dimension_size == 256 and a.post_validation
