@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option (nwknn_set_option), dev use")
     args = ap.parse_args()
 
     import torch
@@ -96,6 +97,10 @@ def main():
     Q, B, d, k, metric, desc = WORKLOADS[args.workload]
     lo, hi = shard_bounds(B, world, rank)
     eng = KnnEngine(local_rank, profile=True)
+    for kvs in args.opt:
+        for kv in kvs.split(","):
+            name, value = kv.split("=")
+            eng.set_option(name, int(value))
     base_raw = eng.generate(SEED_BASE, lo, hi - lo, d)            # this rank's shard, raw row-major f32 in HBM
     queries = eng.generate(SEED_QUERY, 0, Q, d)                   # replicated
     host_d = torch.empty((Q, k), dtype=torch.float32).pin_memory() if rank == 0 else None

@@ -46,6 +46,28 @@ class NwknnError(RuntimeError):
 _lib = None
 
 
+def _bind_to_torch_rocm_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64 (SONAME libamdhip64.so.7, the same as the
+    system one).  A process must hold ONE HIP/HSA runtime: if libnwknn.so pulled in /opt/rocm's copy first, a later
+    `import torch` would load a second runtime and fail with "No HIP GPUs are available", and device pointers could
+    not be shared.  Loading torch's copy first (by path, RTLD_GLOBAL) makes libnwknn.so's NEEDED libamdhip64.so.7
+    resolve to it, so torch tensors' data_ptr() and our streams/kernels live in the same runtime.  Without torch
+    installed the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+    if cand.exists():
+        try:
+            ctypes.CDLL(str(cand), mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load() -> ctypes.CDLL:
     """Load libnwknn.so once and declare every prototype of include/nwknn.h."""
     global _lib
@@ -55,6 +77,7 @@ def load() -> ctypes.CDLL:
         raise NwknnError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. "
             "Build it with `python -m neighborhoodwatch_amd.build` (needs hipcc); there is no CPU fallback.")
+    _bind_to_torch_rocm_runtime()
     L = ctypes.CDLL(str(LIB_PATH))
     L.nwknn_version.restype = c_int
     L.nwknn_last_error.restype = c_char_p

@@ -81,7 +81,8 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_variant = 0, opt_dbg_ptr = 0, opt_stagger = 0;
+    int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
     size_t ev_used = 0;
@@ -159,6 +160,7 @@ extern "C" int nwknn_create(nwknn_handle* out, int device)
     nwknn_ctx* h = new (std::nothrow) nwknn_ctx();
     if (!h) return fail(NWKNN_ENOMEM, "out of host memory");
     h->device = device;
+    h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     memset(&h->stats, 0, sizeof h->stats);
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreate(&h->own_stream));
@@ -206,6 +208,14 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
         h->opt_max_chunk = value;
     } else if (!strcmp(name, "profile")) {
         h->opt_profile = value ? 1 : 0;
+    } else if (!strcmp(name, "stagger")) {
+        if (value < 0 || value > 10000000) return fail(NWKNN_EINVAL, "stagger out of range");
+        h->opt_stagger = value;
+    } else if (!strcmp(name, "dbg_ptr")) {
+        h->opt_dbg_ptr = value;          // dev: device buffer of >= grid*64 bytes receiving per-workgroup cycle stamps
+    } else if (!strcmp(name, "variant")) {
+        if (value < 0 || value > 20) return fail(NWKNN_EINVAL, "variant out of range");
+        h->opt_variant = value;
     } else {
         return fail(NWKNN_EINVAL, "unknown option '%s'", name);
     }
@@ -308,6 +318,8 @@ static NwkTileParams tile_params(nwknn_ctx* h, const SearchPlan& pl, long long n
     p.nb_valid = h->nb;
     p.n_qtiles = (int)(nq_pad / NWK_TILE_ROWS);
     p.dp = h->dp; p.cap = pl.cap;
+    p.stagger = (int)h->opt_stagger;
+    p.dbg = h->opt_dbg_ptr ? (unsigned long long*)(uintptr_t)h->opt_dbg_ptr : nullptr;
     return p;
 }
 
@@ -330,7 +342,7 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
     tp.dense_col0 = lo;
     if (qtile_list) { tp.qtile_list = qtile_list; tp.n_qtiles = n_list_tiles; }
     EvPair* e = ev_begin(h, 0);
-    HIPCHK(nwk_launch_tile(h->stream, tp, metric, dense));
+    HIPCHK(nwk_launch_tile(h->stream, tp, metric, dense, (int)h->opt_variant));
     ev_end(h, e);
     h->stats.tile_launches += 1;
     if (rescan) h->stats.rescan_launches += 1;

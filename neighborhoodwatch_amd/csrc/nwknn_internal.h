@@ -25,8 +25,12 @@ struct NwkTileParams {
     int bt0;                       // first base tile of this launch
     int n_btiles;
     int n_super_b;                 // filled in by the launcher
+    int n_super_q;                 // "  (persistent kernel)
+    int sb_shift;                  // "  super-tile = (64 >> sb_shift) query tiles x (1 << sb_shift) base tiles
     int dp;
     int cap;
+    int stagger;                   // cycles the second-round workgroups (blocks 256..511) wait before their first tile
+    unsigned long long* dbg;       // dev builds only: per-workgroup stamps {t_start, t_loop, t_loop_end, t_end, rt_start, rt_end, xcc, 0}
 };
 
 struct NwkCompactParams {
@@ -44,7 +48,7 @@ struct NwkCompactParams {
 
 hipError_t nwk_launch_gen(hipStream_t st, uint64_t seed, long long row0, long long rows, int d, float* out);
 hipError_t nwk_launch_prep(hipStream_t st, const float* raw, long long rows, int d, long long rows_pad, int dp, float* prepared, float* norms);
-hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool dense);
+hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool dense, int variant);
 hipError_t nwk_launch_compact(hipStream_t st, const NwkCompactParams& p, long long n_queries);
 hipError_t nwk_launch_finalize(hipStream_t st, const unsigned long long* buf, const unsigned int* cnt, int cap, int k, long long nq,
                                long long index_offset, float* out_d, long long* out_i);

@@ -25,6 +25,8 @@ def oracle():
 @pytest.fixture(scope="session")
 def engine():
     """One HIP engine for the whole GPU session (tests call through the C ABI via this wrapper)."""
+    import torch
+    torch.cuda.init()                     # torch's HIP context first, then ours, in one shared runtime (see _lib.py)
     from neighborhoodwatch_amd import KnnEngine
     eng = KnnEngine(0)
     yield eng
