@@ -81,7 +81,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_variant = 0, opt_dbg_ptr = 0, opt_stagger = 0;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -208,14 +208,13 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
         h->opt_max_chunk = value;
     } else if (!strcmp(name, "profile")) {
         h->opt_profile = value ? 1 : 0;
-    } else if (!strcmp(name, "stagger")) {
-        if (value < 0 || value > 10000000) return fail(NWKNN_EINVAL, "stagger out of range");
-        h->opt_stagger = value;
+    } else if (!strcmp(name, "tile_rows")) {
+        if (value != 0 && value != 128 && value != 256) return fail(NWKNN_EINVAL, "tile_rows must be 0 (auto), 128 or 256");
+        h->opt_tile_rows = value;
+    } else if (!strcmp(name, "diag")) {
+        h->opt_diag = value;             // dev: timing ablations of the tile kernel (results are wrong when != 0)
     } else if (!strcmp(name, "dbg_ptr")) {
         h->opt_dbg_ptr = value;          // dev: device buffer of >= grid*64 bytes receiving per-workgroup cycle stamps
-    } else if (!strcmp(name, "variant")) {
-        if (value < 0 || value > 20) return fail(NWKNN_EINVAL, "variant out of range");
-        h->opt_variant = value;
     } else {
         return fail(NWKNN_EINVAL, "unknown option '%s'", name);
     }
@@ -290,9 +289,9 @@ extern "C" int nwknn_set_base(nwknn_handle h, const void* base, int64_t rows, in
 }
 
 // ---- search -----------------------------------------------------------------------------------------
-struct SearchPlan { int cap; long long first, max_chunk, safe; };
+struct SearchPlan { int cap; long long first, max_chunk, safe; int tile_rows; };
 
-static int make_plan(nwknn_ctx* h, int k, SearchPlan* pl)
+static int make_plan(nwknn_ctx* h, int k, long long nq, SearchPlan* pl)
 {
     long long cap = h->opt_capacity;
     if (cap == 0) { cap = 1024; while (cap < 4ll * k) cap <<= 1; }
@@ -305,6 +304,9 @@ static int make_plan(nwknn_ctx* h, int k, SearchPlan* pl)
     pl->first = first;
     pl->max_chunk = h->opt_max_chunk;
     pl->safe = (cap - k) / NWK_TILE_ROWS * NWK_TILE_ROWS;      // a range this small cannot overflow a compacted list
+    // query tile height: 256 rows (fewer DMA instructions and tile turnarounds per MFMA) once there are enough queries
+    // to fill the chip with such tiles, else 128 (less padding waste)
+    pl->tile_rows = h->opt_tile_rows ? (int)h->opt_tile_rows : (nq >= 2048 ? 256 : 128);
     return NWKNN_OK;
 }
 
@@ -316,9 +318,8 @@ static NwkTileParams tile_params(nwknn_ctx* h, const SearchPlan& pl, long long n
     p.tau = h->tau.as<u64>(); p.cnt = h->cnt.as<u32>(); p.buf = h->buf.as<u64>();
     p.qtile_list = nullptr;
     p.nb_valid = h->nb;
-    p.n_qtiles = (int)(nq_pad / NWK_TILE_ROWS);
+    p.n_qtiles = (int)(nq_pad / pl.tile_rows);
     p.dp = h->dp; p.cap = pl.cap;
-    p.stagger = (int)h->opt_stagger;
     p.dbg = h->opt_dbg_ptr ? (unsigned long long*)(uintptr_t)h->opt_dbg_ptr : nullptr;
     return p;
 }
@@ -329,7 +330,7 @@ static NwkCompactParams compact_params(nwknn_ctx* h, const SearchPlan& pl, int k
     memset(&c, 0, sizeof c);
     c.buf = h->buf.as<u64>(); c.cnt = h->cnt.as<u32>(); c.tau = h->tau.as<u64>();
     c.ovf = h->ovf.as<u32>(); c.ovf_any = h->ovf_any.as<u32>();
-    c.cap = pl.cap; c.k = k;
+    c.cap = pl.cap; c.k = k; c.qtile_rows = pl.tile_rows;
     return c;
 }
 
@@ -342,17 +343,21 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
     tp.dense_col0 = lo;
     if (qtile_list) { tp.qtile_list = qtile_list; tp.n_qtiles = n_list_tiles; }
     EvPair* e = ev_begin(h, 0);
-    HIPCHK(nwk_launch_tile(h->stream, tp, metric, dense, (int)h->opt_variant));
+    HIPCHK(nwk_launch_tile(h->stream, tp, metric, dense, pl.tile_rows, (int)h->opt_diag));
     ev_end(h, e);
     h->stats.tile_launches += 1;
     if (rescan) h->stats.rescan_launches += 1;
-    h->stats.tile_flops += 2.0 * (double)tp.n_qtiles * NWK_TILE_ROWS * (double)rows * (double)h->d;
+    {   // algorithmic FLOPs of this launch: real (unpadded) query rows x real base rows x 2d
+        const long long real_rows = std::max<long long>(0, std::min<long long>(lo + rows, h->nb) - lo);
+        const double q_rows = qtile_list ? (double)n_list_tiles * pl.tile_rows : (double)h->stats.nq;
+        h->stats.tile_flops += 2.0 * q_rows * (double)real_rows * (double)h->d;
+    }
 
     NwkCompactParams cp = compact_params(h, pl, k);
     cp.dense_count = dense ? (int)rows : 0;
     cp.dedupe = dedupe ? 1 : 0;
     cp.qtile_list = qtile_list;
-    const long long nqc = qtile_list ? (long long)n_list_tiles * NWK_TILE_ROWS : nq_pad;
+    const long long nqc = qtile_list ? (long long)n_list_tiles * pl.tile_rows : nq_pad;
     e = ev_begin(h, 1);
     HIPCHK(nwk_launch_compact(h->stream, cp, nqc));
     ev_end(h, e);
@@ -365,14 +370,15 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
 // cannot overflow: the recursion terminates.
 static int repair(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long long nq_pad)
 {
-    const long long n_tiles_all = nq_pad / NWK_TILE_ROWS;
+    const int TR = pl.tile_rows;
+    const long long n_tiles_all = nq_pad / TR;
     std::vector<u32> flags((size_t)nq_pad);
     HIPCHK(hipMemcpy(flags.data(), h->ovf.p, (size_t)nq_pad * 4, hipMemcpyDeviceToHost));
     std::vector<int> tiles;
     int nflag = 0;
     for (long long t = 0; t < n_tiles_all; ++t) {
         bool any = false;
-        for (int j = 0; j < NWK_TILE_ROWS; ++j) if (flags[(size_t)t * NWK_TILE_ROWS + j]) { any = true; ++nflag; }
+        for (int j = 0; j < TR; ++j) if (flags[(size_t)t * TR + j]) { any = true; ++nflag; }
         if (any) tiles.push_back((int)t);
     }
     h->stats.overflowed_queries += nflag;
@@ -402,7 +408,7 @@ static int repair(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long lo
         std::vector<int> again;
         for (int t : w.tiles) {
             bool a = false;
-            for (int j = 0; j < NWK_TILE_ROWS; ++j) a |= flags[(size_t)t * NWK_TILE_ROWS + j] != 0;
+            for (int j = 0; j < TR; ++j) a |= flags[(size_t)t * TR + j] != 0;
             if (a) again.push_back(t);
         }
         const long long mid = w.lo + round_up((w.hi - w.lo) / 2, NWK_TILE_ROWS);
@@ -425,9 +431,9 @@ extern "C" int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int
         return fail(NWKNN_EINVAL, "nwknn_search: bad location");
     RCCHK(use_device(h));
     SearchPlan pl;
-    RCCHK(make_plan(h, k, &pl));
+    RCCHK(make_plan(h, k, nq, &pl));
 
-    const long long nq_pad = round_up(nq, NWK_TILE_ROWS);
+    const long long nq_pad = round_up(nq, NWK_QPAD_ROWS);
     RCCHK(h->qp.ensure((size_t)nq_pad * h->dp * 4));
     RCCHK(h->qn.ensure((size_t)nq_pad * 4));
     RCCHK(h->tau.ensure((size_t)nq_pad * 8));

@@ -7,7 +7,8 @@
 #define NWKNN_METRIC_ONE_MINUS_DOT 1
 #define NWKNN_METRIC_COSINE 2
 
-#define NWK_TILE_ROWS 128          // query rows / base rows per workgroup tile
+#define NWK_TILE_ROWS 128          // base rows per workgroup tile; granule of chunk sizes
+#define NWK_QPAD_ROWS 256          // query-side arrays are padded to this (the larger query tile)
 #define NWK_K_ALIGN 32             // prepared rows are zero padded to a multiple of this many floats
 
 struct NwkTileParams {
@@ -25,11 +26,8 @@ struct NwkTileParams {
     int bt0;                       // first base tile of this launch
     int n_btiles;
     int n_super_b;                 // filled in by the launcher
-    int n_super_q;                 // "  (persistent kernel)
-    int sb_shift;                  // "  super-tile = (64 >> sb_shift) query tiles x (1 << sb_shift) base tiles
     int dp;
     int cap;
-    int stagger;                   // cycles the second-round workgroups (blocks 256..511) wait before their first tile
     unsigned long long* dbg;       // dev builds only: per-workgroup stamps {t_start, t_loop, t_loop_end, t_end, rt_start, rt_end, xcc, 0}
 };
 
@@ -42,13 +40,14 @@ struct NwkCompactParams {
     const int* qtile_list;         // optional: compact only the queries of these tiles (grid = n_tiles*128)
     int cap;
     int k;
+    int qtile_rows;                // rows per entry of qtile_list (128 or 256)
     int dense_count;               // > 0: every list holds exactly this many entries (first chunk)
     int dedupe;
 };
 
 hipError_t nwk_launch_gen(hipStream_t st, uint64_t seed, long long row0, long long rows, int d, float* out);
 hipError_t nwk_launch_prep(hipStream_t st, const float* raw, long long rows, int d, long long rows_pad, int dp, float* prepared, float* norms);
-hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool dense, int variant);
+hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool dense, int tile_rows, int diag);
 hipError_t nwk_launch_compact(hipStream_t st, const NwkCompactParams& p, long long n_queries);
 hipError_t nwk_launch_finalize(hipStream_t st, const unsigned long long* buf, const unsigned int* cnt, int cap, int k, long long nq,
                                long long index_offset, float* out_d, long long* out_i);

@@ -110,16 +110,18 @@ def test_list_overflow_is_repaired_exactly(oracle, order):
     if order == "random":
         base = base[rng.permutation(B)]
     queries = (centre[None, :] + 0.01 * rng.standard_normal((Q, d))).astype(np.float32)
-    with KnnEngine(0) as eng:
-        eng.set_option("capacity", 256)
-        eng.set_option("first_chunk", 128)
-        eng.set_base(base)
-        dist, idx = eng.search(queries, k)
-        st = eng.stats()
     rd, ri = oracle.knn_canonical(base, queries, k)
-    assert np.array_equal(idx, ri) and _same_bits(dist, rd)
-    if order == "approaching":
-        assert st["overflowed_queries"] > 0 and st["rescan_launches"] > 0, "the test did not reach the repair path"
+    for tile_rows in (128, 256):
+        with KnnEngine(0) as eng:
+            eng.set_option("capacity", 256)
+            eng.set_option("first_chunk", 128)
+            eng.set_option("tile_rows", tile_rows)
+            eng.set_base(base)
+            dist, idx = eng.search(queries, k)
+            st = eng.stats()
+        assert np.array_equal(idx, ri) and _same_bits(dist, rd)
+        if order == "approaching":
+            assert st["overflowed_queries"] > 0 and st["rescan_launches"] > 0, "the test did not reach the repair path"
 
 
 def test_small_chunks_do_not_change_the_result(oracle):
