@@ -39,6 +39,17 @@ SEED_BASE, SEED_QUERY = 0x6E770001, 0x6E770002
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
 
 
+def recorded_traffic(workload):
+    """HBM/fabric bytes per launch of the tile kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
+    gfx950 correction + WRITE_SIZE, separate passes; profiles/traffic_<workload>.json).  PMC cannot be sampled from inside
+    this process, so the figure is the recorded one for this workload, or None."""
+    f = ROOT / "profiles" / f"traffic_{workload}.json"
+    try:
+        return float(json.loads(f.read_text())["hbm_fabric_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(eng, base_dev, queries_dev, k, metric, full_b):
     """numpy/BLAS brute force on a bounded sample of the same workload, timed on this box's host cores."""
     import numpy as np
@@ -73,6 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="compare the merged result with a single-engine search of the whole base (small workloads)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option (nwknn_set_option), dev use")
     args = ap.parse_args()
 
@@ -88,15 +100,23 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # NWKNN_DIST_BACKEND=gloo rehearses the N-rank path on a box with fewer GPUs than ranks (ranks share devices, the
+    # all-gather goes through the host); production is nccl == RCCL, one rank per GPU.
+    backend = os.environ.get("NWKNN_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            td.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     Q, B, d, k, metric, desc = WORKLOADS[args.workload]
     lo, hi = shard_bounds(B, world, rank)
-    eng = KnnEngine(local_rank, profile=True)
+    eng = KnnEngine(dev_index, profile=True)
     for kvs in args.opt:
         for kv in kvs.split(","):
             name, value = kv.split("=")
@@ -134,15 +154,16 @@ def main():
         step(False)
     fence()
     t0 = time.perf_counter()
+    last = None
     for _ in range(args.steps):
-        step(True)
+        last = step(True)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
-        fl = torch.tensor([agg["tile_flops"], agg["tile_ms"]], dtype=torch.float64, device="cuda")
+        fl = torch.tensor([agg["tile_flops"], agg["tile_ms"]], dtype=torch.float64, device=red_dev)
         td.all_reduce(fl, op=td.ReduceOp.SUM)
         sum_flops, sum_ms = float(fl[0]), float(fl[1])
     else:
@@ -161,7 +182,8 @@ def main():
             "config": {"workload": desc, "queries": Q, "base_rows": B, "dim": d, "k": k, "metric": metric,
                        "parallelism": f"base rows sharded x{world}" + (" + RCCL all-gather of [Q,k] partials + merge" if world > 1 else "")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": recorded_traffic(args.workload),
+                         "traffic_note": "bytes per launch, rocprofv3 PMC passes recorded in profiles/ (not sampled live)",
                          "kernel": "nwk_tile_kernel", "launches": agg["tile_launches"],
                          "avg_launch_ms": agg["tile_ms"] / max(agg["tile_launches"], 1),
                          "flops_per_launch": agg["tile_flops"] / max(agg["tile_launches"], 1)},
@@ -172,6 +194,15 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(eng, base_raw, queries, k, metric, B)
         print(json.dumps(out), flush=True)
+    if args.verify and rank == 0:
+        full = eng.generate(SEED_BASE, 0, B, d)
+        eng.set_base(full)
+        rd, ri = eng.search(queries, k, metric)
+        dist, idx = last
+        same = bool(torch.equal(ri, idx)) and bool(torch.equal(rd, dist))
+        print(json.dumps({"verify": "merged N-rank result == single-engine result", "ok": same}), flush=True)
+        if not same:
+            raise SystemExit(3)
     if world > 1:
         td.barrier()
         td.destroy_process_group()

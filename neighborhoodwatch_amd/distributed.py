@@ -34,10 +34,14 @@ def allgather_partials(dist, idx, group=None):
     if td.get_backend(group) == "nccl":              # RCCL: one ncclAllGather per array straight into the stacked buffer
         td.all_gather_into_tensor(gd, dist.contiguous(), group=group)
         td.all_gather_into_tensor(gi, idx.contiguous(), group=group)
-    else:                                            # gloo (CPU tests): list form over views of the same buffer
-        td.all_gather(list(gd.unbind(0)), dist.contiguous(), group=group)
-        td.all_gather(list(gi.unbind(0)), idx.contiguous(), group=group)
-    return gd, gi
+        return gd, gi
+    # gloo (CPU tests, and single-GPU rehearsals of the N-rank path): list form; device tensors are staged through the host
+    hd, hi = dist.contiguous().cpu(), idx.contiguous().cpu()
+    cd = torch.empty((world,) + tuple(hd.shape), dtype=hd.dtype)
+    ci = torch.empty((world,) + tuple(hi.shape), dtype=hi.dtype)
+    td.all_gather(list(cd.unbind(0)), hd, group=group)
+    td.all_gather(list(ci.unbind(0)), hi, group=group)
+    return cd.to(dist.device), ci.to(idx.device)
 
 
 def sharded_search(search_shard: Callable, merge: Callable, queries, k: int, shard_lo: int, group=None):
