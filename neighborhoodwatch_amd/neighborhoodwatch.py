@@ -5,7 +5,9 @@ Positional arguments, every flag and the five-stage order are the reference's.  
     paid services; here they write seeded synthetic embeddings with the same parquet schema and file names
     (``--synthetic-seed``), or are skipped when the source parquet files already exist (as the reference does,
     generate_dataset.py:266-268,298-300).  ``check_dataset_exists_remote`` (neighborhoodwatch.py:65) is not called.
-  * stage 5 (fvec/ivec/hdf5 writers, parquet_to_format.py) is outside this round's hot-path scope.
+  * stage 5 writes .fvec/.ivec with a vectorised writer (byte-identical to the reference's); hdf5 needs h5py and is
+    skipped with a message where it is not installed.  ``--post-validation`` runs validate_files_v0 without the
+    interactive prompt of neighborhoodwatch.py:184-186.
 """
 from __future__ import annotations
 
@@ -18,9 +20,10 @@ from . import synth
 from .cu_knn import compute_knn
 from .cu_knn_ds import compute_knn_ds
 from .merge import merge_indices_and_distances
+from .parquet_to_format import generate_output_files, validate_files_v0
 from .nw_utils import (get_effective_embedding_size, get_partial_distances_filename, get_partial_indices_filename,
                        get_source_base_dataset_filename, get_source_query_dataset_filename, get_valid_model_names_string,
-                       is_valid_model_name, setup_model_output_folder)
+                       get_model_prefix, is_valid_model_name, setup_model_output_folder)
 
 
 def cleanup_partial_parquet(data_dir):
@@ -57,9 +60,9 @@ Some example commands:\n
     parser.add_argument('--use-dataset-api', action=argparse.BooleanOptionalAction, default=False,
                         help="Use 'pyarrow.dataset' API to read the dataset. Recommended for large datasets.")
     parser.add_argument('--gen-hdf5', action=argparse.BooleanOptionalAction, default=True,
-                        help='Generate hdf5 files (accepted; stage 5 is out of scope in this build)')
+                        help='Generate hdf5 files (default: True; needs h5py)')
     parser.add_argument('--post-validation', action=argparse.BooleanOptionalAction, default=False,
-                        help='Validate the generated files (accepted; stage 5 is out of scope in this build)')
+                        help='Validate the generated files (default: False)')
     parser.add_argument('--enable-memory-tuning', action='store_true', help='Enable memory tuning')
     parser.add_argument('--disable-memory-tuning', action='store_false',
                         help='Disable memory tuning (useful for very small datasets)')
@@ -117,8 +120,16 @@ def main(argv=None):
     section = time.time()
     merge_indices_and_distances(data_dir, k=args.k, device=args.device)
     print(f"(Duration: {time.time() - section:.2f} seconds out of {time.time() - start_time:.2f} seconds)")
-    print(f"final tables: {get_partial_indices_filename(data_dir, -1)}, {get_partial_distances_filename(data_dir, -1)}")
-    print("ivec/fvec/hdf5 generation (stage 5) is not part of this build")
+    print("Generating ivec's and fvec's ......")
+    section = time.time()
+    files = generate_output_files(data_dir, get_model_prefix(args.model_name), output_dimension, base_filename, query_filename,
+                                  args.base_count, args.query_count, get_partial_indices_filename(data_dir, -1),
+                                  get_partial_distances_filename(data_dir, -1), args.k, args.gen_hdf5, column_names=None,
+                                  output_dtype=output_dtype)                               # neighborhoodwatch.py:167-179
+    print(f"(Duration: {time.time() - section:.2f} seconds out of {time.time() - start_time:.2f} seconds)")
+    if args.post_validation:
+        print("Validating ivec's and fvec's ......")
+        validate_files_v0(data_dir, *files)
     return 0
 
 

@@ -126,8 +126,36 @@ def make_knn_case(name, base, queries, k, metric, keep_rows=None, torch_literal=
           f"idx==fp64 {frac:.5f} (all mismatches are fp32 near-ties), max|d-d64|={err:.3e}, rank slack {slack:.2e}")
 
 
+def make_ifvec_case():
+    """fvec/ivec bytes written by the reference's own write_ivec_fvec_from_dataframe (parquet_to_format.py:71-89).
+    parquet_to_format.py imports cupy / h5py / cuvs at module level for its hdf5 writer and GPU validators only; the
+    writer itself is pure pandas/numpy, so those three are satisfied with inert mocks."""
+    for m in ["cupy", "h5py", "cuvs", "cuvs.distance", "cuvs.neighbors"]:
+        sys.modules.setdefault(m, MagicMock())
+    import neighborhoodwatch.parquet_to_format as ref_ptf  # type: ignore
+    rng = np.random.default_rng(21)
+    vec = rng.standard_normal((23, 7)).astype(np.float32)
+    ids = rng.integers(0, 2 ** 31 - 1, size=(23, 5)).astype(np.int64)
+    tmp = Path(tempfile.mkdtemp(prefix="nwgold_"))
+    try:
+        ref_ptf.write_ivec_fvec_from_dataframe(str(tmp), "m", "v.fvec", pd.DataFrame(vec), "f", 7)
+        ref_ptf.write_ivec_fvec_from_dataframe(str(tmp), "m", "i.ivec", pd.DataFrame(ids), "i", 5)
+        idr = pd.DataFrame(ids); idr["RowNum"] = np.arange(23)                     # trailing RowNum column is dropped (:77-78)
+        ref_ptf.write_ivec_fvec_from_dataframe(str(tmp), "m", "r.ivec", idr, "i", 5)
+        np.savez_compressed(OUT / "ifvec_reference_writer.npz", vec=vec, ids=ids,
+                            fvec_bytes=np.frombuffer((tmp / "v.fvec").read_bytes(), dtype=np.uint8),
+                            ivec_bytes=np.frombuffer((tmp / "i.ivec").read_bytes(), dtype=np.uint8),
+                            ivec_rownum_bytes=np.frombuffer((tmp / "r.ivec").read_bytes(), dtype=np.uint8),
+                            count=ref_ptf.count_vectors(str(tmp), "v.fvec"), third=np.array(ref_ptf.get_nth_vector(str(tmp), "v.fvec", 3)),
+                            third_ids=np.array(ref_ptf.get_nth_vector(str(tmp), "i.ivec", 3)))
+        print(f"ifvec_reference_writer: fvec {(tmp / 'v.fvec').stat().st_size} B, ivec {(tmp / 'i.ivec').stat().st_size} B")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ref_merge = _import_reference_merge()
+    make_ifvec_case()
     make_merge_case(ref_merge, "basic", 11, q=50, k=10, n_lists=3)
     make_merge_case(ref_merge, "ties", 12, q=40, k=8, n_lists=4, ties=True)
     make_merge_case(ref_merge, "single", 13, q=17, k=5, n_lists=1)

@@ -1,0 +1,82 @@
+"""CPU: fvec/ivec writers and readers.  Golden bytes come from the reference's own writer
+(tests/golden/make_golden.py runs parquet_to_format.write_ivec_fvec_from_dataframe from /root/reference)."""
+import struct
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import GOLDEN
+from neighborhoodwatch_amd import nw_utils, parquet_to_format as ptf, synth
+
+
+@pytest.fixture()
+def gold():
+    return np.load(GOLDEN / "ifvec_reference_writer.npz")
+
+
+def test_writer_is_byte_identical_to_the_reference_writer(tmp_path, gold):
+    ptf.write_ivec_fvec_from_dataframe(str(tmp_path), "m", "v.fvec", pd.DataFrame(gold["vec"]), "f", 7)
+    ptf.write_ivec_fvec_from_dataframe(str(tmp_path), "m", "i.ivec", pd.DataFrame(gold["ids"]), "i", 5)
+    withrow = pd.DataFrame(gold["ids"]); withrow["RowNum"] = np.arange(len(withrow))
+    ptf.write_ivec_fvec_from_dataframe(str(tmp_path), "m", "r.ivec", withrow, "i", 5)
+    assert (tmp_path / "v.fvec").read_bytes() == gold["fvec_bytes"].tobytes()
+    assert (tmp_path / "i.ivec").read_bytes() == gold["ivec_bytes"].tobytes()
+    assert (tmp_path / "r.ivec").read_bytes() == gold["ivec_rownum_bytes"].tobytes()          # trailing RowNum dropped
+    assert ptf.count_vectors(str(tmp_path), "v.fvec") == int(gold["count"]) == 23
+    assert np.array_equal(np.array(ptf.get_nth_vector(str(tmp_path), "v.fvec", 3), dtype=np.float32), gold["third"].astype(np.float32))
+    assert list(ptf.get_nth_vector(str(tmp_path), "i.ivec", 3)) == gold["third_ids"].tolist()
+    with pytest.raises(AssertionError, match="Expected 5 values, got 7"):
+        ptf.write_ivec_fvec_from_dataframe(str(tmp_path), "m", "x.fvec", pd.DataFrame(gold["vec"]), "f", 5)   # parquet_to_format.py:79-81
+
+
+def test_record_layout_and_vectorised_reader(tmp_path, gold):
+    """int32 LE dim + dim x 4 B per record (parquet_to_format.py:86-88); element-exact round trip
+    (the intent of the reference's tests/test_04_gen_ifvec_hdf5.py:166-174)."""
+    ptf.write_ivec_fvec_from_dataframe(str(tmp_path), "m", "v.fvec", gold["vec"], "f", 7)
+    raw = (tmp_path / "v.fvec").read_bytes()
+    assert len(raw) == 23 * 4 * 8
+    for r in (0, 11, 22):
+        rec = raw[r * 32:(r + 1) * 32]
+        assert struct.unpack("<i", rec[:4])[0] == 7
+        assert np.array_equal(np.frombuffer(rec[4:], dtype="<f4"), gold["vec"][r])
+    assert np.array_equal(ptf.read_vectors(str(tmp_path), "v.fvec"), gold["vec"])
+    ptf.write_ivec_fvec_from_dataframe(str(tmp_path), "m", "i.ivec", gold["ids"], "i", 5)
+    assert np.array_equal(ptf.read_vectors(str(tmp_path), "i.ivec"), gold["ids"].astype(np.int32))     # ids narrowed to int32 (:84)
+    (tmp_path / "e.fvec").write_bytes(b"")
+    assert ptf.count_vectors(str(tmp_path), "e.fvec") == 0 and ptf.is_empty_file(str(tmp_path / "e.fvec"))
+
+
+def test_output_file_names():
+    q, b, i, d = ptf.get_ivec_fvec_filenames("/x", "intfloat/e5-small-v2", 384, 10000, 1000, 100)      # nw_utils.py:110-142
+    assert q == "/x/intfloat_e5-small-v2_384_query_vectors_1000.fvec"
+    assert b == "/x/intfloat_e5-small-v2_384_base_vectors_10000.fvec"
+    assert i == "/x/intfloat_e5-small-v2_384_indices_b10000_q1000_k100.ivec"
+    assert d == "/x/intfloat_e5-small-v2_384_distances_b10000_q1000_k100.fvec"
+    assert ptf.get_hdf5_filename("/x", "voyage-3-large", 1024, 5, 7, 3, "int8") == "/x/voyage-3-large_1024_int8_base_5_query_7_k3.hdf5"
+
+
+def test_generate_output_files_and_validator(tmp_path, oracle):
+    """Stage 5 end to end on CPU inputs: source parquet + final tables (here from the oracle) -> four files;
+    validate_files_v0 (parquet_to_format.py:351-383) accepts them and catches a corrupted distance."""
+    from neighborhoodwatch_amd import cu_knn
+    data_dir = nw_utils.setup_model_output_folder(str(tmp_path), "intfloat/e5-small-v2", 40, 300, 10)
+    qf = nw_utils.get_source_query_dataset_filename(data_dir, "intfloat/e5-small-v2", 40, 384)
+    bf = nw_utils.get_source_base_dataset_filename(data_dir, "intfloat/e5-small-v2", 300, 384)
+    synth.write_source_parquet(qf, 3, 40, 384, normalize=True); synth.write_source_parquet(bf, 4, 300, 384, normalize=True)
+    base, queries = synth.gen_unit_rows(4, 0, 300, 384), synth.gen_unit_rows(3, 0, 40, 384)
+    d, i = oracle.knn_canonical(base, queries, 10)
+    cu_knn.stream_cudf_to_parquet(nw_utils.get_partial_distances_filename(data_dir, -1), d, 100000)
+    cu_knn.stream_cudf_to_parquet(nw_utils.get_partial_indices_filename(data_dir, -1), i, 100000)
+    files = ptf.generate_output_files(data_dir, "intfloat_e5-small-v2", 384, bf, qf, 300, 40,
+                                      nw_utils.get_partial_indices_filename(data_dir, -1), nw_utils.get_partial_distances_filename(data_dir, -1),
+                                      10, output_hdf5=False)
+    qv, bv, iv, dv = files
+    assert ptf.count_vectors(data_dir, qv) == 40 and ptf.count_vectors(data_dir, bv) == 300
+    assert ptf.count_vectors(data_dir, iv) == 40 and len(ptf.get_first_vector(data_dir, iv)) == 10
+    assert np.array_equal(ptf.read_vectors(data_dir, bv), base) and np.array_equal(ptf.read_vectors(data_dir, iv), i.astype(np.int32))
+    assert np.array_equal(ptf.read_vectors(data_dir, dv), d)
+    assert ptf.validate_files_v0(data_dir, qv, bv, iv, dv) == 0
+    bad = ptf.read_vectors(data_dir, dv).copy(); bad[5, 2] += 0.01
+    ptf.write_ivec_fvec_from_dataframe(data_dir, "m", dv, bad, "f", 10)
+    assert ptf.validate_files_v0(data_dir, qv, bv, iv, dv) == 1

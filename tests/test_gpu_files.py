@@ -119,3 +119,8 @@ def test_cli_end_to_end(tmp_path, oracle):
     base = synth.gen_rows(synth.SEED_BASE, 0, 3000, 384); queries = synth.gen_rows(synth.SEED_QUERY, 0, 200, 384)
     rd, ri = oracle.knn_canonical(base, queries, 20)
     assert np.array_equal(_arr(fi, np.int64), ri) and np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
+    # stage 5: the four fvec/ivec files of neighborhoodwatch.py:167-179
+    from neighborhoodwatch_amd import parquet_to_format as ptf
+    qv, bv, iv, dv = ptf.get_ivec_fvec_filenames(data_dir, "intfloat_e5-small-v2", 384, 3000, 200, 20)
+    assert ptf.count_vectors(data_dir, qv) == 200 and ptf.count_vectors(data_dir, bv) == 3000
+    assert np.array_equal(ptf.read_vectors(data_dir, iv), ri.astype(np.int32)) and np.array_equal(ptf.read_vectors(data_dir, dv), rd)
