@@ -30,13 +30,17 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 WORKLOADS = {
-    # name: (Q, B, d, k, metric, description)
-    "c3": (100_000, 10_000_000, 1024, 100, "sqeuclidean", "C3: 100k queries x 10M base, d=1024 (e5-large-v2 shape), k=100, fp32 sqeuclidean"),
-    "c2": (10_000, 1_000_000, 768, 100, "sqeuclidean", "C2: 10k queries x 1M base, d=768, k=100, fp32 sqeuclidean"),
-    "dev": (4_096, 262_144, 256, 100, "sqeuclidean", "dev: 4k x 256k, d=256, k=100 (not a headline number)"),
+    # name: (Q, B, d, k, metric, dtype, description)
+    "c3": (100_000, 10_000_000, 1024, 100, "sqeuclidean", "f32", "C3: 100k queries x 10M base, d=1024 (e5-large-v2 shape), k=100, fp32 sqeuclidean"),
+    "c2": (10_000, 1_000_000, 768, 100, "sqeuclidean", "f32", "C2: 10k queries x 1M base, d=768, k=100, fp32 sqeuclidean"),
+    "dev": (4_096, 262_144, 256, 100, "sqeuclidean", "f32", "dev: 4k x 256k, d=256, k=100 (not a headline number)"),
+    # BASELINE config 4 (fp16 MFMA + L2, 8 GPUs) and the piece of it one GPU sees (its 12.5M-row shard, a tenth of the queries)
+    "c4": (1_000_000, 100_000_000, 1536, 100, "sqeuclidean", "f16", "C4: 1M queries x 100M base, d=1536 (ada-002 shape), k=100, fp16 MFMA sqeuclidean"),
+    "c4gpu": (100_000, 12_500_000, 1536, 100, "sqeuclidean", "f16", "C4 per-GPU slice: 100k queries x 12.5M base rows (one of 8 shards), d=1536, k=100, fp16"),
+    "dev16": (8_192, 524_288, 512, 100, "sqeuclidean", "f16", "dev16: 8k x 512k, d=512, k=100, fp16 (not a headline number)"),
 }
 SEED_BASE, SEED_QUERY = 0x6E770001, 0x6E770002
-F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0}      # MI355X_MICROARCH.md: dense f32 / f16 MFMA peaks
 
 
 def recorded_traffic(workload):
@@ -61,10 +65,10 @@ def cpu_baseline(eng, base_dev, queries_dev, k, metric, full_b):
     except Exception:
         blas_threads = cores
     d = base_dev.shape[1]
-    bs = min(base_dev.shape[0], max(10_000, int(2.5e11 / (512 * d))))      # ~0.25 TFLOP per 512 queries
-    qs = min(queries_dev.shape[0], 512)
-    base = base_dev[:bs].cpu().numpy()
-    qry = queries_dev[:qs].cpu().numpy()
+    qs = min(queries_dev.shape[0], 2048)
+    bs = min(base_dev.shape[0], max(10_000, int(1.0e13 / (2.0 * qs * d))))     # ~10 TFLOP of sgemm: 10-30 s on a 16..64-core host
+    base = base_dev[:bs].float().cpu().numpy()
+    qry = queries_dev[:qs].float().cpu().numpy()
     cpu_oracle.knn_blas_fp32(base[: min(bs, 20000)], qry[:64], min(k, 100), metric)      # warm-up
     t0 = time.perf_counter()
     cpu_oracle.knn_blas_fp32(base, qry, k, metric)
@@ -114,15 +118,16 @@ def main():
             td.init_process_group(backend, rank=rank, world_size=world)
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
-    Q, B, d, k, metric, desc = WORKLOADS[args.workload]
+    Q, B, d, k, metric, dtype, desc = WORKLOADS[args.workload]
+    peak = MFMA_PEAK_TFLOPS[dtype]
     lo, hi = shard_bounds(B, world, rank)
     eng = KnnEngine(dev_index, profile=True)
     for kvs in args.opt:
         for kv in kvs.split(","):
             name, value = kv.split("=")
             eng.set_option(name, int(value))
-    base_raw = eng.generate(SEED_BASE, lo, hi - lo, d)            # this rank's shard, raw row-major f32 in HBM
-    queries = eng.generate(SEED_QUERY, 0, Q, d)                   # replicated
+    base_raw = eng.generate(SEED_BASE, lo, hi - lo, d, dtype)     # this rank's shard, raw row-major in HBM (an fp16 base selects the fp16 path)
+    queries = eng.generate(SEED_QUERY, 0, Q, d, dtype)            # replicated
     host_d = torch.empty((Q, k), dtype=torch.float32).pin_memory() if rank == 0 else None
     host_i = torch.empty((Q, k), dtype=torch.int64).pin_memory() if rank == 0 else None
 
@@ -177,12 +182,12 @@ def main():
             "metric": "queries/sec + pairwise-dist TFLOP/s, 100k x 10M d=1024 k=100" if args.workload == "c3" else f"queries/sec ({args.workload})",
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (seeded counter-based embeddings in [-1,1), generated on device)",
+            "dtype": dtype, "data": "synthetic (seeded counter-based embeddings in [-1,1), generated on device)",
             "pairwise_tflops": 2.0 * Q * B * d * args.steps / elapsed / 1e12,
             "config": {"workload": desc, "queries": Q, "base_rows": B, "dim": d, "k": k, "metric": metric,
                        "parallelism": f"base rows sharded x{world}" + (" + RCCL all-gather of [Q,k] partials + merge" if world > 1 else "")},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": recorded_traffic(args.workload),
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": recorded_traffic(args.workload),
                          "traffic_note": "bytes per launch, rocprofv3 PMC passes recorded in profiles/ (not sampled live)",
                          "kernel": "nwk_tile_kernel", "launches": agg["tile_launches"],
                          "avg_launch_ms": agg["tile_ms"] / max(agg["tile_launches"], 1),

@@ -43,6 +43,7 @@ extern "C" {
 #define NWKNN_METRIC_COSINE 2        /* engine='cuvs'  : brute_force metric="cosine", cu_knn.py:247-248         */
 
 #define NWKNN_DTYPE_F32 0
+#define NWKNN_DTYPE_F16 1          /* IEEE half: input element type and/or compute path (BASELINE config 4) */
 
 #define NWKNN_HOST 0
 #define NWKNN_DEVICE 1
@@ -81,7 +82,9 @@ int nwknn_destroy(nwknn_handle h);
  * restores the handle's own stream. */
 int nwknn_set_stream(nwknn_handle h, void* hip_stream);
 /* Tunables: "capacity" (candidate slots per query, power of two >= 4k), "first_chunk", "max_chunk"
- * (base rows per launch, multiples of 128), "profile" (0/1: per-kernel HIP-event timing into nwknn_stats). */
+ * (base rows per launch, multiples of 128), "profile" (0/1: per-kernel HIP-event timing into nwknn_stats),
+ * "compute_dtype" (NWKNN_DTYPE_F32 | NWKNN_DTYPE_F16: with F16 the next nwknn_set_base rounds fp32 input to fp16 and
+ * distance tiles run on the fp16 MFMA path with fp32 accumulation), "tile_rows" (0 auto | 128 | 256, fp32 path). */
 int nwknn_set_option(nwknn_handle h, const char* name, int64_t value);
 int nwknn_get_stats(nwknn_handle h, nwknn_stats* out);
 /* Wait for everything queued on the handle's stream. */
@@ -92,7 +95,9 @@ int nwknn_synchronize(nwknn_handle h);
 /* Make rows [0, rows) x d of `base` the searchable set of this handle (this GPU's shard).  The library keeps
  * its own MFMA-ready copy plus row norms; the caller's buffer is not referenced after return (for
  * NWKNN_DEVICE the copy is queued on the handle's stream and the buffer may be reused after
- * nwknn_synchronize or any later blocking call). */
+ * nwknn_synchronize or any later blocking call).  dtype = element type of `base`; an fp16 base (or option
+ * "compute_dtype" = NWKNN_DTYPE_F16) selects the fp16 compute path: results then carry fp16 input rounding and are
+ * checked against the float64 truth with a tolerance instead of bit for bit. */
 int nwknn_set_base(nwknn_handle h, const void* base, int64_t rows, int32_t d, int dtype, int location);
 
 /* ---- the operator: distances, indices = knn(dataset, queries, k)  (cu_knn.py:243-245) ------------------- */
@@ -100,7 +105,7 @@ int nwknn_set_base(nwknn_handle h, const void* base, int64_t rows, int32_t d, in
  * lower index first among equal distances.  out_idx = row number in the base set + index_offset
  * (index_offset plays the role of `+ batch_offset`, cu_knn.py:273: pass the shard's first global row).
  * Requires 0 < k <= base rows (cu_knn.py:177-178,237) and k <= 1024. */
-int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int location, int32_t k, int metric,
+int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int dtype, int location, int32_t k, int metric,
                  int64_t index_offset, float* out_dist, int64_t* out_idx, int out_location);
 
 /* ---- merge of partial top-k lists: merge_indices_and_distances(), merge.py:56-101 ----------------------- */
@@ -111,9 +116,10 @@ int nwknn_merge(nwknn_handle h, const float* dists, const int64_t* idx, int32_t 
                 int32_t k_out, float* out_dist, int64_t* out_idx, int location);
 
 /* ---- synthetic inputs (no reference counterpart: generate_dataset.py needs the network) ----------------- */
-/* Fill device buffer out[rows][d] (float32) with value(seed, row0 + r, c) in [-1,1) on a 2^-23 grid; the
- * same integer recipe as oracle/cpu_oracle.gen_numpy, so hosts can regenerate any row for checking. */
-int nwknn_generate(nwknn_handle h, uint64_t seed, int64_t row0, int64_t rows, int32_t d, float* out_device);
+/* Fill device buffer out[rows][d] with value(seed, row0 + r, c) in [-1,1): float32 on a 2^-23 grid, or fp16 on a
+ * 2^-10 grid (the top bits of the same draw); the same integer recipe as oracle/cpu_oracle.gen_numpy /
+ * gen_f16_numpy, so hosts can regenerate any row for checking. */
+int nwknn_generate(nwknn_handle h, uint64_t seed, int64_t row0, int64_t rows, int32_t d, int dtype, void* out_device);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@ LIB_PATH = PKG_DIR / "libnwknn.so"
 
 NWKNN_OK = 0
 HOST, DEVICE = 0, 1
+DTYPE_F32, DTYPE_F16 = 0, 1
 METRIC_IDS = {"sqeuclidean": 0, "one_minus_dot": 1, "cosine": 2}
 # the reference selects the distance through its `engine` argument (cu_knn.py:193-200,243-262)
 ENGINE_TO_METRIC = {"raft": "sqeuclidean", "torch": "one_minus_dot", "cuvs": "cosine", "hip": "sqeuclidean"}
@@ -90,9 +91,9 @@ def load() -> ctypes.CDLL:
     L.nwknn_get_stats.argtypes = [c_void_p, POINTER(NwknnStats)]
     L.nwknn_synchronize.argtypes = [c_void_p]
     L.nwknn_set_base.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int, c_int]
-    L.nwknn_search.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int32, c_int, c_int64, c_void_p, c_void_p, c_int]
+    L.nwknn_search.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_int32, c_int, c_int64, c_void_p, c_void_p, c_int]
     L.nwknn_merge.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int]
-    L.nwknn_generate.argtypes = [c_void_p, c_uint64, c_int64, c_int64, c_int32, c_void_p]
+    L.nwknn_generate.argtypes = [c_void_p, c_uint64, c_int64, c_int64, c_int32, c_int, c_void_p]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("nwknn_last_error",):

@@ -76,12 +76,13 @@ struct nwknn_ctx {
     DevBuf bp, bn, braw;
     long long nb = 0, nb_pad = 0;
     int d = 0, dp = 0;
+    int f16 = 0;                    // 1: the prepared base (and queries) are fp16, distance tiles run on the fp16 MFMA kernel
     // query side
     DevBuf qraw, qp, qn;
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -208,6 +209,9 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
         h->opt_max_chunk = value;
     } else if (!strcmp(name, "profile")) {
         h->opt_profile = value ? 1 : 0;
+    } else if (!strcmp(name, "compute_dtype")) {
+        if (value != NWKNN_DTYPE_F32 && value != NWKNN_DTYPE_F16) return fail(NWKNN_EINVAL, "compute_dtype must be 0 (f32) or 1 (f16)");
+        h->opt_compute_f16 = value;      // takes effect at the next nwknn_set_base
     } else if (!strcmp(name, "tile_rows")) {
         if (value != 0 && value != 128 && value != 256) return fail(NWKNN_EINVAL, "tile_rows must be 0 (auto), 128 or 256");
         h->opt_tile_rows = value;
@@ -238,28 +242,34 @@ extern "C" int nwknn_synchronize(nwknn_handle h)
 
 // ---- dataset side -----------------------------------------------------------------------------------
 // Stages a caller matrix onto the device (if it is on the host) and runs the prep kernel into dst/norms.
-static int stage_and_prep(nwknn_ctx* h, const void* src, int location, long long rows, int d, long long rows_pad, int dp, DevBuf& raw,
-                          float* dst, float* norms)
+// in_f16: element type of the caller's matrix; out_f16: element type of the prepared layout (the compute path).
+static int stage_and_prep(nwknn_ctx* h, const void* src, int location, int in_f16, int out_f16, long long rows, int d, long long rows_pad,
+                          int dp, DevBuf& raw, void* dst, float* norms)
 {
-    const float* dsrc = (const float*)src;
+    const size_t in_es = in_f16 ? 2 : 4, out_es = out_f16 ? 2 : 4;
+    auto launch = [&](const void* dsrc, long long real, long long pad, void* ddst, float* dn) -> hipError_t {
+        if (out_f16) return nwk_launch_prep_f16(h->stream, dsrc, in_f16, real, d, pad, dp, ddst, dn);
+        return nwk_launch_prep(h->stream, (const float*)dsrc, real, d, pad, dp, (float*)ddst, dn);
+    };
+    if (in_f16 && !out_f16) return fail(NWKNN_EINVAL, "fp16 input needs the fp16 compute path (set option compute_dtype=1 or pass an fp16 base)");
     if (location == NWKNN_HOST) {
         // slab-wise so the raw staging copy stays small next to a 288 GB shard
-        const long long slab_rows = std::max<long long>(NWK_TILE_ROWS, ((256ll << 20) / ((long long)d * 4)) / NWK_TILE_ROWS * NWK_TILE_ROWS);
-        RCCHK(raw.ensure((size_t)std::min(slab_rows, std::max<long long>(rows, 1)) * d * 4));
+        const long long slab_rows = std::max<long long>(256, ((256ll << 20) / ((long long)d * (long long)in_es)) / 256 * 256);
+        RCCHK(raw.ensure((size_t)std::min(slab_rows, std::max<long long>(rows, 1)) * d * in_es));
         for (long long r0 = 0; r0 < rows_pad; r0 += slab_rows) {
             const long long pad_here = std::min(slab_rows, rows_pad - r0);
             const long long real_here = std::max<long long>(0, std::min(slab_rows, rows - r0));
             if (real_here > 0)
-                HIPCHK(hipMemcpyAsync(raw.p, (const char*)src + (size_t)r0 * d * 4, (size_t)real_here * d * 4, hipMemcpyHostToDevice, h->stream));
+                HIPCHK(hipMemcpyAsync(raw.p, (const char*)src + (size_t)r0 * d * in_es, (size_t)real_here * d * in_es, hipMemcpyHostToDevice, h->stream));
             EvPair* e = ev_begin(h, 2);
-            HIPCHK(nwk_launch_prep(h->stream, raw.as<float>(), real_here, d, pad_here, dp, dst + r0 * dp, norms + r0));
+            HIPCHK(launch(raw.p, real_here, pad_here, (char*)dst + (size_t)r0 * dp * out_es, norms + r0));
             ev_end(h, e);
             HIPCHK(hipStreamSynchronize(h->stream));    // the slab is reused by the next copy
         }
         return NWKNN_OK;
     }
     EvPair* e = ev_begin(h, 2);
-    HIPCHK(nwk_launch_prep(h->stream, dsrc, rows, d, rows_pad, dp, dst, norms));
+    HIPCHK(launch(src, rows, rows_pad, dst, norms));
     ev_end(h, e);
     return NWKNN_OK;
 }
@@ -267,18 +277,19 @@ static int stage_and_prep(nwknn_ctx* h, const void* src, int location, long long
 extern "C" int nwknn_set_base(nwknn_handle h, const void* base, int64_t rows, int32_t d, int dtype, int location)
 {
     if (!h || !base) return fail(NWKNN_EINVAL, "nwknn_set_base: null handle or base pointer");
-    if (dtype != NWKNN_DTYPE_F32) return fail(NWKNN_EINVAL, "nwknn_set_base: unsupported dtype %d (only float32)", dtype);
+    if (dtype != NWKNN_DTYPE_F32 && dtype != NWKNN_DTYPE_F16) return fail(NWKNN_EINVAL, "nwknn_set_base: unsupported dtype %d", dtype);
     if (rows <= 0 || d <= 0) return fail(NWKNN_EINVAL, "nwknn_set_base: rows=%lld d=%d must be positive", (long long)rows, d);
-    if (rows >= (1ll << 32) - NWK_TILE_ROWS) return fail(NWKNN_EINVAL, "nwknn_set_base: a shard holds at most 2^32-129 rows");
+    if (rows >= (1ll << 32) - 512) return fail(NWKNN_EINVAL, "nwknn_set_base: a shard holds at most 2^32-513 rows");
     if (location != NWKNN_HOST && location != NWKNN_DEVICE) return fail(NWKNN_EINVAL, "bad location %d", location);
     RCCHK(use_device(h));
-    const long long rows_pad = round_up(rows, NWK_TILE_ROWS);
-    const int dp = (int)round_up(d, NWK_K_ALIGN);
-    RCCHK(h->bp.ensure((size_t)rows_pad * dp * 4));
+    const int f16 = (dtype == NWKNN_DTYPE_F16 || h->opt_compute_f16) ? 1 : 0;
+    const long long rows_pad = round_up(rows, f16 ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS);
+    const int dp = (int)round_up(d, f16 ? NWK_K_ALIGN_F16 : NWK_K_ALIGN);
+    RCCHK(h->bp.ensure((size_t)rows_pad * dp * (f16 ? 2 : 4)));
     RCCHK(h->bn.ensure((size_t)rows_pad * 4));
     h->ev_used = 0;
-    RCCHK(stage_and_prep(h, base, location, rows, d, rows_pad, dp, h->braw, h->bp.as<float>(), h->bn.as<float>()));
-    h->nb = rows; h->nb_pad = rows_pad; h->d = d; h->dp = dp;
+    RCCHK(stage_and_prep(h, base, location, dtype == NWKNN_DTYPE_F16, f16, rows, d, rows_pad, dp, h->braw, h->bp.p, h->bn.as<float>()));
+    h->nb = rows; h->nb_pad = rows_pad; h->d = d; h->dp = dp; h->f16 = f16;
     if (h->opt_profile) {
         HIPCHK(hipStreamSynchronize(h->stream));
         double t, c, p;
@@ -289,7 +300,7 @@ extern "C" int nwknn_set_base(nwknn_handle h, const void* base, int64_t rows, in
 }
 
 // ---- search -----------------------------------------------------------------------------------------
-struct SearchPlan { int cap; long long first, max_chunk, safe; int tile_rows; };
+struct SearchPlan { int cap; long long first, max_chunk, safe; int tile_rows; int granule; };
 
 static int make_plan(nwknn_ctx* h, int k, long long nq, SearchPlan* pl)
 {
@@ -297,16 +308,19 @@ static int make_plan(nwknn_ctx* h, int k, long long nq, SearchPlan* pl)
     if (cap == 0) { cap = 1024; while (cap < 4ll * k) cap <<= 1; }
     if (cap < 2ll * k + NWK_TILE_ROWS) return fail(NWKNN_EINVAL, "capacity %lld too small for k=%d (need >= 2k+%d)", cap, k, NWK_TILE_ROWS);
     if (cap > 4096) return fail(NWKNN_EINVAL, "k=%d needs capacity %lld > 4096", k, cap);
-    long long first = h->opt_first_chunk ? h->opt_first_chunk : cap / 2;
-    first = std::max<long long>(first, round_up(k, NWK_TILE_ROWS));
-    first = std::min<long long>(first, cap / NWK_TILE_ROWS * NWK_TILE_ROWS);
+    const long long G = h->f16 ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS;          // base rows per tile = granule of every chunk
+    long long first = h->opt_first_chunk ? round_up(h->opt_first_chunk, G) : cap / 2;
+    first = std::max<long long>(first, round_up(k, G));
+    first = std::min<long long>(first, cap / G * G);
     pl->cap = (int)cap;
     pl->first = first;
-    pl->max_chunk = h->opt_max_chunk;
-    pl->safe = (cap - k) / NWK_TILE_ROWS * NWK_TILE_ROWS;      // a range this small cannot overflow a compacted list
+    pl->max_chunk = std::max<long long>(G, h->opt_max_chunk / G * G);
+    pl->safe = (cap - k) / G * G;                              // a range this small cannot overflow a compacted list
+    pl->granule = (int)G;
+    if (pl->safe < G || first < k) return fail(NWKNN_EINVAL, "capacity %lld too small for k=%d on this compute path", cap, k);
     // query tile height: 256 rows (fewer DMA instructions and tile turnarounds per MFMA) once there are enough queries
     // to fill the chip with such tiles, else 128 (less padding waste)
-    pl->tile_rows = h->opt_tile_rows ? (int)h->opt_tile_rows : (nq >= 2048 ? 256 : 128);
+    pl->tile_rows = h->f16 ? NWK_F16_TILE_ROWS : (h->opt_tile_rows ? (int)h->opt_tile_rows : (nq >= 2048 ? 256 : 128));
     return NWKNN_OK;
 }
 
@@ -314,7 +328,8 @@ static NwkTileParams tile_params(nwknn_ctx* h, const SearchPlan& pl, long long n
 {
     NwkTileParams p;
     memset(&p, 0, sizeof p);
-    p.qp = h->qp.as<float>(); p.bp = h->bp.as<float>(); p.qn = h->qn.as<float>(); p.bn = h->bn.as<float>();
+    p.qp = h->qp.as<float>(); p.bp = h->bp.as<float>();          // halves on the fp16 path (the kernel casts)
+    p.qn = h->qn.as<float>(); p.bn = h->bn.as<float>();
     p.tau = h->tau.as<u64>(); p.cnt = h->cnt.as<u32>(); p.buf = h->buf.as<u64>();
     p.qtile_list = nullptr;
     p.nb_valid = h->nb;
@@ -338,12 +353,13 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
                      const int* qtile_list, int n_list_tiles, bool dedupe, bool rescan)
 {
     NwkTileParams tp = tile_params(h, pl, nq_pad);
-    tp.bt0 = (int)(lo / NWK_TILE_ROWS);
-    tp.n_btiles = (int)(rows / NWK_TILE_ROWS);
+    tp.bt0 = (int)(lo / pl.granule);
+    tp.n_btiles = (int)(rows / pl.granule);
     tp.dense_col0 = lo;
     if (qtile_list) { tp.qtile_list = qtile_list; tp.n_qtiles = n_list_tiles; }
     EvPair* e = ev_begin(h, 0);
-    HIPCHK(nwk_launch_tile(h->stream, tp, metric, dense, pl.tile_rows, (int)h->opt_diag));
+    if (h->f16) HIPCHK(nwk_launch_tile_f16(h->stream, tp, metric, dense));
+    else HIPCHK(nwk_launch_tile(h->stream, tp, metric, dense, pl.tile_rows, (int)h->opt_diag));
     ev_end(h, e);
     h->stats.tile_launches += 1;
     if (rescan) h->stats.rescan_launches += 1;
@@ -411,14 +427,14 @@ static int repair(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long lo
             for (int j = 0; j < TR; ++j) a |= flags[(size_t)t * TR + j] != 0;
             if (a) again.push_back(t);
         }
-        const long long mid = w.lo + round_up((w.hi - w.lo) / 2, NWK_TILE_ROWS);
+        const long long mid = w.lo + round_up((w.hi - w.lo) / 2, pl.granule);
         stack.push_back({mid, w.hi, again});
         stack.push_back({w.lo, mid, again});
     }
     return NWKNN_OK;
 }
 
-extern "C" int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int location, int32_t k, int metric, int64_t index_offset,
+extern "C" int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int dtype, int location, int32_t k, int metric, int64_t index_offset,
                             float* out_dist, int64_t* out_idx, int out_location)
 {
     if (!h || !queries || !out_dist || !out_idx) return fail(NWKNN_EINVAL, "nwknn_search: null argument");
@@ -427,6 +443,7 @@ extern "C" int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int
     if (k <= 0 || k > h->nb) return fail(NWKNN_EINVAL, "nwknn_search: k=%d must satisfy 0 < k <= %lld base rows", k, h->nb);   // cu_knn.py:237
     if (k > 1024) return fail(NWKNN_EINVAL, "nwknn_search: k=%d exceeds the supported maximum 1024", k);
     if (metric < 0 || metric > 2) return fail(NWKNN_EINVAL, "nwknn_search: unknown metric %d", metric);
+    if (dtype != NWKNN_DTYPE_F32 && dtype != NWKNN_DTYPE_F16) return fail(NWKNN_EINVAL, "nwknn_search: unsupported query dtype %d", dtype);
     if ((location != NWKNN_HOST && location != NWKNN_DEVICE) || (out_location != NWKNN_HOST && out_location != NWKNN_DEVICE))
         return fail(NWKNN_EINVAL, "nwknn_search: bad location");
     RCCHK(use_device(h));
@@ -434,7 +451,7 @@ extern "C" int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int
     RCCHK(make_plan(h, k, nq, &pl));
 
     const long long nq_pad = round_up(nq, NWK_QPAD_ROWS);
-    RCCHK(h->qp.ensure((size_t)nq_pad * h->dp * 4));
+    RCCHK(h->qp.ensure((size_t)nq_pad * h->dp * (h->f16 ? 2 : 4)));
     RCCHK(h->qn.ensure((size_t)nq_pad * 4));
     RCCHK(h->tau.ensure((size_t)nq_pad * 8));
     RCCHK(h->cnt.ensure((size_t)nq_pad * 4));
@@ -447,7 +464,7 @@ extern "C" int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int
     h->ev_used = 0;
     if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_begin, h->stream));
 
-    RCCHK(stage_and_prep(h, queries, location, nq, h->d, nq_pad, h->dp, h->qraw, h->qp.as<float>(), h->qn.as<float>()));
+    RCCHK(stage_and_prep(h, queries, location, dtype == NWKNN_DTYPE_F16, h->f16, nq, h->d, nq_pad, h->dp, h->qraw, h->qp.p, h->qn.as<float>()));
     HIPCHK(hipMemsetAsync(h->tau.p, 0xFF, (size_t)nq_pad * 8, h->stream));
     HIPCHK(hipMemsetAsync(h->cnt.p, 0, (size_t)nq_pad * 4, h->stream));
     HIPCHK(hipMemsetAsync(h->ovf.p, 0, (size_t)nq_pad * 4, h->stream));
@@ -521,11 +538,13 @@ extern "C" int nwknn_merge(nwknn_handle h, const float* dists, const int64_t* id
 }
 
 // ---- synthetic inputs -------------------------------------------------------------------------------
-extern "C" int nwknn_generate(nwknn_handle h, uint64_t seed, int64_t row0, int64_t rows, int32_t d, float* out_device)
+extern "C" int nwknn_generate(nwknn_handle h, uint64_t seed, int64_t row0, int64_t rows, int32_t d, int dtype, void* out_device)
 {
     if (!h || !out_device) return fail(NWKNN_EINVAL, "nwknn_generate: null argument");
     if (rows <= 0 || d <= 0 || row0 < 0) return fail(NWKNN_EINVAL, "nwknn_generate: bad shape");
+    if (dtype != NWKNN_DTYPE_F32 && dtype != NWKNN_DTYPE_F16) return fail(NWKNN_EINVAL, "nwknn_generate: unsupported dtype %d", dtype);
     RCCHK(use_device(h));
-    HIPCHK(nwk_launch_gen(h->stream, seed, row0, rows, d, out_device));
+    if (dtype == NWKNN_DTYPE_F16) HIPCHK(nwk_launch_gen_f16(h->stream, seed, row0, rows, d, out_device));
+    else HIPCHK(nwk_launch_gen(h->stream, seed, row0, rows, d, (float*)out_device));
     return NWKNN_OK;
 }

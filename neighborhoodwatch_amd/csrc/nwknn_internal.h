@@ -9,7 +9,9 @@
 
 #define NWK_TILE_ROWS 128          // base rows per workgroup tile; granule of chunk sizes
 #define NWK_QPAD_ROWS 256          // query-side arrays are padded to this (the larger query tile)
-#define NWK_K_ALIGN 32             // prepared rows are zero padded to a multiple of this many floats
+#define NWK_K_ALIGN 32             // prepared fp32 rows are zero padded to a multiple of this many floats
+#define NWK_K_ALIGN_F16 64         // prepared fp16 rows: multiple of this many halves
+#define NWK_F16_TILE_ROWS 256      // fp16 path: query and base tiles are 256 rows
 
 struct NwkTileParams {
     const float* qp;               // prepared queries [nq_pad][dp]
@@ -46,6 +48,9 @@ struct NwkCompactParams {
 };
 
 hipError_t nwk_launch_gen(hipStream_t st, uint64_t seed, long long row0, long long rows, int d, float* out);
+hipError_t nwk_launch_gen_f16(hipStream_t st, uint64_t seed, long long row0, long long rows, int d, void* out);
+hipError_t nwk_launch_prep_f16(hipStream_t st, const void* raw, int raw_is_f16, long long rows, int d, long long rows_pad, int dp, void* prepared, float* norms);
+hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool dense);
 hipError_t nwk_launch_prep(hipStream_t st, const float* raw, long long rows, int d, long long rows_pad, int dp, float* prepared, float* norms);
 hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool dense, int tile_rows, int diag);
 hipError_t nwk_launch_compact(hipStream_t st, const NwkCompactParams& p, long long n_queries);

@@ -128,6 +128,59 @@ __global__ __launch_bounds__(256) void nwk_prep_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp16 compute path (BASELINE config 4): generator and prep.
+//   * synthetic f16 values: the top 11 bits of the same 64-bit draw, as a signed integer times 2^-10 -- exactly
+//     representable in fp16, in [-1, 1)
+//   * prep: raw row-major (f32 or f16) -> fp16 [rows_pad][dp], dp = d rounded up to 64 halves (one 128-B LDS row per
+//     K slab), natural k order (lane half h of v_mfma_f32_32x32x16_f16 holds k = 8h..8h+7: one ds_read_b128);
+//     f32 input is rounded to nearest-even; the norm is the fp32 fmaf chain over the ROUNDED values, so every term of
+//     |q|^2 + |b|^2 - 2 q.b refers to the same vectors.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void nwk_gen_f16_kernel(u64 seed, long long row0, long long rows, int d, _Float16* __restrict__ out)
+{
+    const long long total = rows * (long long)d;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / d;
+        const int c = (int)(i - r * d);
+        const u64 rk = fmix64(seed + (u64)(row0 + r) * 0x9E3779B97F4A7C15ull);
+        const u64 u = fmix64(rk + (u64)(c + 1) * 0xD1342543DE82EF95ull);
+        const int v = (int)(u >> 53) - (1 << 10);
+        out[i] = (_Float16)((float)v * (1.0f / 1024.0f));
+    }
+}
+
+template <typename TIN>
+__global__ __launch_bounds__(256) void nwk_prep_f16_kernel(const TIN* __restrict__ raw, long long rows, int d, long long rows_pad, int dp,
+                                                            _Float16* __restrict__ prepared, float* __restrict__ norms)
+{
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows_pad) return;
+    _Float16* dst = prepared + r * dp;
+    if (r >= rows) {
+        const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < dp; k += 8) *(f16x8*)(dst + k) = z;
+        norms[r] = 0.0f;
+        return;
+    }
+    const TIN* src = raw + r * (long long)d;
+    float acc = 0.0f;
+    for (int k0 = 0; k0 < dp; k0 += 8) {
+        f16x8 hv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const _Float16 x = (k0 + j < d) ? (_Float16)src[k0 + j] : (_Float16)0;
+            hv[j] = x;
+            const float xf = (float)x;
+            acc = __fmaf_rn(xf, xf, acc);
+        }
+        *(f16x8*)(dst + k0) = hv;
+    }
+    norms[r] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
 // the distance-tile + filter kernel
 // ------------------------------------------------------------------------------------------------
 // One workgroup (4 waves) computes a TM x 128 tile of the distance matrix over the whole d:
@@ -405,6 +458,134 @@ __global__ __launch_bounds__(256, 2) void nwk_tile_kernel(const NwkTileParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp16 distance tile: 256 queries x 256 base rows per workgroup of 8 waves (2 x 4; a wave owns 128 x 64 = 4 x 2
+// accumulators of v_mfma_f32_32x32x16_f16, fp32 accumulate), K in 64-half (128-B) slabs through two 64 KiB LDS stages.
+// fp16 MFMA is 16x the fp32 rate, so the operand stream is the problem: per DMA instruction this shape has
+// 256*256/(256+256) = 128 cycles of MFMA work, the most a 160 KiB LDS allows with 2 stages.  Same LDS image, swizzle,
+// DMA form, epilogue and candidate-list logic as the fp32 kernel.  The accumulation order inside one MFMA (16 k's) is
+// not specified by the ISA, so this path is checked against the float64 oracle with a tolerance, not bit for bit.
+// ------------------------------------------------------------------------------------------------
+#define H_TM 256
+#define H_TN 256
+#define H_BK 64                       // halves per slab = 128-B rows
+#define H_STAGE (2 * 256 * 128)       // A 32 KiB + B 32 KiB
+
+template <int METRIC, bool DENSE>
+__global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16(const NwkTileParams p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[2 * H_STAGE];
+
+    const TileCoord tc = tile_from_block(p);
+    if (!tc.ok) return;
+
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, l = tid & 63;
+    const int wr = w >> 2, wc = w & 3;
+    const int h = l >> 5, c32 = l & 31;
+    const long long q0 = (long long)tc.qt * H_TM;
+    const long long b0 = (long long)tc.bt * H_TN;
+    const int dp = p.dp;                          // halves per prepared row
+    const int nk = dp / H_BK;
+    const _Float16* qp = (const _Float16*)p.qp;
+    const _Float16* bp = (const _Float16*)p.bp;
+
+    // DMA: 32 wave-instructions per operand per slab (8 rows each); wave w issues rows [32w, 32w+32) of both tiles
+    unsigned voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (w * 4 + i) * 8 + (l >> 3);
+        voff[i] = (unsigned)(row * dp * 2 + (((l & 7) ^ ((row >> 1) & 7)) << 4));
+    }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(qp + q0 * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(bp + b0 * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const int lds_w = __builtin_amdgcn_readfirstlane(w * 4096);
+    auto issue_stage = [&](int stage, int kt) {
+        char* base = smem + stage * H_STAGE + lds_w;
+        const int soff = kt * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(base + i * 1024), 16, voff[i], soff, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(base + 32768 + i * 1024), 16, voff[i], soff, 0, 0);
+    };
+
+    int offA[4], offB[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int ra = wr * 128 + m * 32 + c32;
+        offA[m] = ra * 128 + ((h ^ ((ra >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int rb = wc * 64 + n * 32 + c32;
+        offB[n] = 32768 + rb * 128 + ((h ^ ((rb >> 1) & 7)) << 4);
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    float bnv[2];
+    u32 colv[2];
+    bool colok[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const long long col = b0 + wc * 64 + n * 32 + c32;
+        colv[n] = (u32)col;
+        colok[n] = col < p.nb_valid;
+        bnv[n] = p.bn[col];
+    }
+    float my_qn = 0.f;
+    u64 my_tau = ~0ull;
+    if (tid < H_TM) {
+        my_qn = p.qn[q0 + tid];
+        if (!DENSE) my_tau = p.tau[q0 + tid];
+    }
+
+    issue_stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            issue_stage(cur ^ 1, kt + 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const char* sb = smem + cur * H_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {                       // 16 k's per step: chunk 2*ks + h
+            f16x8 a[4], b[2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] = *(const f16x8*)(sb + (offA[m] ^ (ks << 5)));
+#pragma unroll
+            for (int n = 0; n < 2; ++n) b[n] = *(const f16x8*)(sb + (offB[n] ^ (ks << 5)));
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    float* s_qn = (float*)smem;
+    u64* s_tau = (u64*)(smem + H_TM * 4);
+    if (tid < H_TM) {
+        s_qn[tid] = my_qn;
+        if (!DENSE) s_tau[tid] = my_tau;
+    }
+    __syncthreads();
+    tile_epilogue<METRIC, DENSE, 4>(p, acc, s_qn, s_tau, bnv, colv, colok, q0, wr * 128, h, c32);
+}
+
+// ------------------------------------------------------------------------------------------------
 // compaction: sort one query's candidate list, (optionally) drop duplicate keys, keep k, tighten tau
 //   dynamic LDS: [cap] u64 keys | [2][cap] u32 scan buffers | 16 B scratch   (one array: keeps the base 16-B aligned)
 // ------------------------------------------------------------------------------------------------
@@ -568,6 +749,28 @@ hipError_t nwk_launch_gen(hipStream_t st, uint64_t seed, long long row0, long lo
     return hipGetLastError();
 }
 
+hipError_t nwk_launch_gen_f16(hipStream_t st, uint64_t seed, long long row0, long long rows, int d, void* out)
+{
+    const long long total = rows * (long long)d;
+    if (total <= 0) return hipSuccess;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(nwk_gen_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (u64)seed, row0, rows, d, (_Float16*)out);
+    return hipGetLastError();
+}
+
+hipError_t nwk_launch_prep_f16(hipStream_t st, const void* raw, int raw_is_f16, long long rows, int d, long long rows_pad, int dp, void* prepared,
+                               float* norms)
+{
+    if (rows_pad <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((rows_pad + 255) / 256);
+    if (raw_is_f16)
+        hipLaunchKernelGGL((nwk_prep_f16_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, (const _Float16*)raw, rows, d, rows_pad, dp, (_Float16*)prepared, norms);
+    else
+        hipLaunchKernelGGL((nwk_prep_f16_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)raw, rows, d, rows_pad, dp, (_Float16*)prepared, norms);
+    return hipGetLastError();
+}
+
 hipError_t nwk_launch_prep(hipStream_t st, const float* raw, long long rows, int d, long long rows_pad, int dp, float* prepared,
                            float* norms)
 {
@@ -613,6 +816,32 @@ hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool den
     case NWKNN_METRIC_SQEUCLIDEAN: return launch_tile_metric<NWKNN_METRIC_SQEUCLIDEAN>(st, p, dense, (unsigned)grid, tile_rows, diag);
     case NWKNN_METRIC_ONE_MINUS_DOT: return launch_tile_metric<NWKNN_METRIC_ONE_MINUS_DOT>(st, p, dense, (unsigned)grid, tile_rows, diag);
     case NWKNN_METRIC_COSINE: return launch_tile_metric<NWKNN_METRIC_COSINE>(st, p, dense, (unsigned)grid, tile_rows, diag);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int METRIC>
+static hipError_t launch_tile_f16_metric(hipStream_t st, const NwkTileParams& p, bool dense, unsigned grid)
+{
+    if (dense) hipLaunchKernelGGL((nwk_tile_kernel_f16<METRIC, true>), dim3(grid), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((nwk_tile_kernel_f16<METRIC, false>), dim3(grid), dim3(512), 0, st, p);
+    return hipGetLastError();
+}
+
+// fp16 path: p.n_qtiles and p.n_btiles both count 256-row tiles; p.bt0 is in 256-row units; p.qp/p.bp point at halves.
+hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool dense)
+{
+    if (p.n_qtiles <= 0 || p.n_btiles <= 0) return hipSuccess;
+    const long long n_super_q = (p.n_qtiles + 7) / 8;
+    p.n_super_b = (p.n_btiles + 7) / 8;
+    long long supers = n_super_q * p.n_super_b;
+    supers = (supers + 7) / 8 * 8;
+    const long long grid = supers * 64;
+    if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    switch (metric) {
+    case NWKNN_METRIC_SQEUCLIDEAN: return launch_tile_f16_metric<NWKNN_METRIC_SQEUCLIDEAN>(st, p, dense, (unsigned)grid);
+    case NWKNN_METRIC_ONE_MINUS_DOT: return launch_tile_f16_metric<NWKNN_METRIC_ONE_MINUS_DOT>(st, p, dense, (unsigned)grid);
+    case NWKNN_METRIC_COSINE: return launch_tile_f16_metric<NWKNN_METRIC_COSINE>(st, p, dense, (unsigned)grid);
     default: return hipErrorInvalidValue;
     }
 }

@@ -14,7 +14,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import DEVICE, ENGINE_TO_METRIC, HOST, METRIC_IDS, NwknnStats, check
+from ._lib import DEVICE, DTYPE_F16, DTYPE_F32, ENGINE_TO_METRIC, HOST, METRIC_IDS, NwknnStats, check
 
 
 def _is_torch(x) -> bool:
@@ -81,29 +81,36 @@ class KnnEngine:
     # -- data -------------------------------------------------------------------------------------
     @staticmethod
     def _matrix(x, what: str):
-        """-> (pointer, rows, dim, location, keepalive)"""
+        """-> (pointer, rows, dim, dtype id, location, keepalive).  float16 inputs stay float16 (fp16 compute path);
+        everything else is taken as float32 (``dataset.astype(np.float32)``, cu_knn.py:243)."""
         if _is_torch(x):
             import torch
-            if x.dtype != torch.float32:
-                x = x.to(torch.float32)          # dataset.astype(np.float32), cu_knn.py:243
+            if x.dtype not in (torch.float32, torch.float16):
+                x = x.to(torch.float32)
             if x.dim() != 2:
                 raise ValueError(f"{what} must be 2-D, got shape {tuple(x.shape)}")
             x = x.contiguous()
             loc = DEVICE if x.is_cuda else HOST
-            return x.data_ptr(), x.shape[0], x.shape[1], loc, x
-        a = np.ascontiguousarray(x, dtype=np.float32)
+            return x.data_ptr(), x.shape[0], x.shape[1], (DTYPE_F16 if x.dtype == torch.float16 else DTYPE_F32), loc, x
+        a = np.asarray(x)
+        a = np.ascontiguousarray(a, dtype=np.float16 if a.dtype == np.float16 else np.float32)
         if a.ndim != 2:
             raise ValueError(f"{what} must be 2-D, got shape {a.shape}")
-        return a.ctypes.data, a.shape[0], a.shape[1], HOST, a
+        return a.ctypes.data, a.shape[0], a.shape[1], (DTYPE_F16 if a.dtype == np.float16 else DTYPE_F32), HOST, a
+
+    def set_compute_dtype(self, dtype: str) -> None:
+        """'f32' (default, bit-exact canonical arithmetic) or 'f16' (fp16 MFMA, fp32 accumulate; BASELINE config 4).
+        Takes effect at the next set_base."""
+        self.set_option("compute_dtype", {"f32": DTYPE_F32, "fp32": DTYPE_F32, "f16": DTYPE_F16, "fp16": DTYPE_F16}[dtype])
 
     def set_base(self, dataset) -> None:
-        ptr, rows, dim, loc, keep = self._matrix(dataset, "dataset")
+        ptr, rows, dim, dt, loc, keep = self._matrix(dataset, "dataset")
         if rows == 0 or dim == 0:
             raise ValueError("dataset is empty")
         if loc == DEVICE:
             import torch
             torch.cuda.current_stream(keep.device).synchronize()
-        check(self._L.nwknn_set_base(self._h, ctypes.c_void_p(ptr), rows, dim, 0, loc), "nwknn_set_base")
+        check(self._L.nwknn_set_base(self._h, ctypes.c_void_p(ptr), rows, dim, dt, loc), "nwknn_set_base")
         if loc == DEVICE:
             self.synchronize()               # the caller may free/overwrite its tensor right after we return
         self.rows, self.dim = rows, dim
@@ -112,7 +119,7 @@ class KnnEngine:
     def search(self, queries, k: int, metric: str = "sqeuclidean", index_offset: int = 0, out_device: Optional[bool] = None):
         """-> (distances float32 [q,k], indices int64 [q,k]); torch CUDA tensors if the queries were, else numpy."""
         metric = resolve_metric(metric)
-        ptr, nq, dim, loc, keep = self._matrix(queries, "queries")
+        ptr, nq, dim, dt, loc, keep = self._matrix(queries, "queries")
         if self.rows == 0:
             raise _lib.NwknnError("search before set_base")
         if dim != self.dim:
@@ -133,7 +140,7 @@ class KnnEngine:
             od = np.empty((nq, k), dtype=np.float32)
             oi = np.empty((nq, k), dtype=np.int64)
             pd_, pi_, oloc = od.ctypes.data, oi.ctypes.data, HOST
-        check(self._L.nwknn_search(self._h, ctypes.c_void_p(ptr), nq, loc, int(k), METRIC_IDS[metric], int(index_offset),
+        check(self._L.nwknn_search(self._h, ctypes.c_void_p(ptr), nq, dt, loc, int(k), METRIC_IDS[metric], int(index_offset),
                                    ctypes.c_void_p(pd_), ctypes.c_void_p(pi_), oloc), "nwknn_search")
         del keep
         return od, oi
@@ -157,13 +164,14 @@ class KnnEngine:
                                   ctypes.c_void_p(od.ctypes.data), ctypes.c_void_p(oi.ctypes.data), HOST), "nwknn_merge")
         return od, oi
 
-    def generate(self, seed: int, row0: int, rows: int, dim: int):
-        """Seeded synthetic rows straight into HBM (torch CUDA tensor [rows, dim], float32)."""
+    def generate(self, seed: int, row0: int, rows: int, dim: int, dtype: str = "f32"):
+        """Seeded synthetic rows straight into HBM (torch CUDA tensor [rows, dim], float32 or float16)."""
         import torch
-        out = torch.empty((rows, dim), dtype=torch.float32, device=torch.device("cuda", self.device))
+        f16 = dtype in ("f16", "fp16")
+        out = torch.empty((rows, dim), dtype=torch.float16 if f16 else torch.float32, device=torch.device("cuda", self.device))
         torch.cuda.current_stream(out.device).synchronize()
-        check(self._L.nwknn_generate(self._h, ctypes.c_uint64(seed), int(row0), int(rows), int(dim), ctypes.c_void_p(out.data_ptr())),
-              "nwknn_generate")
+        check(self._L.nwknn_generate(self._h, ctypes.c_uint64(seed), int(row0), int(rows), int(dim), DTYPE_F16 if f16 else DTYPE_F32,
+                                     ctypes.c_void_p(out.data_ptr())), "nwknn_generate")
         self.synchronize()
         return out
 

@@ -119,6 +119,16 @@ def gen(seed: int, row0: int, rows: int, d: int) -> np.ndarray:
     return out
 
 
+def gen_f16_numpy(seed: int, row0: int, rows: int, d: int) -> np.ndarray:
+    """fp16 variant of the generator: top 11 bits of the same 64-bit draw, signed, times 2^-10 (exact in fp16)."""
+    with np.errstate(over="ignore"):
+        r = (np.arange(rows, dtype=np.uint64) + np.uint64(row0))[:, None]
+        c = (np.arange(d, dtype=np.uint64) + np.uint64(1))[None, :]
+        u = _fmix64(_fmix64(np.uint64(seed) + r * _G1) + c * _G2)
+    v = (u >> np.uint64(53)).astype(np.int64) - (1 << 10)
+    return (v.astype(np.float32) * np.float32(1.0 / 1024.0)).astype(np.float16)
+
+
 def gen_unit_rows(seed: int, row0: int, rows: int, d: int) -> np.ndarray:
     """Seeded stand-in for the reference's test data (tests/test_02_cu_knn.py:15-28: np.random.rand rows,
     each L2-normalised by nw_utils.normalize_vector, nw_utils.py:56-59): values on a 2^-24 grid in [0,1),

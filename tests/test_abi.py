@@ -49,7 +49,7 @@ def test_argument_errors_do_not_need_a_gpu():
     assert L.nwknn_create(None, 0) == -1                       # NWKNN_EINVAL, message retrievable
     assert b"null" in L.nwknn_last_error()
     assert L.nwknn_set_option(None, b"capacity", 1024) == -1
-    assert L.nwknn_search(None, None, 1, 0, 1, 0, 0, None, None, 0) == -1
+    assert L.nwknn_search(None, None, 1, 0, 0, 1, 0, 0, None, None, 0) == -1
     assert L.nwknn_destroy(None) == 0
 
 

@@ -186,3 +186,67 @@ def test_runs_are_bitwise_reproducible(engine, oracle):
     a = engine.search(queries, 100)
     b = engine.search(queries, 100)
     assert np.array_equal(a[1], b[1]) and _same_bits(a[0], b[0])
+
+
+# ---- fp16 compute path (BASELINE config 4): tolerance parity against the float64 truth ------------------------
+def _f16_reference(oracle, base16, queries16, k, metric):
+    """float64 exact ranking of the fp16-rounded vectors (the MFMA's in-instruction summation order is unspecified,
+    so the fp16 path is not bit-comparable; SURVEY 7, hard part 5)."""
+    b, q = base16.astype(np.float32), queries16.astype(np.float32)
+    return b, q, oracle.knn_exact_fp64(b, q, k, metric)
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean", "one_minus_dot", "cosine"])
+@pytest.mark.parametrize("shape", [(300, 5000, 768, 100), (37, 2000, 100, 16), (513, 4097, 1536, 10), (9, 300, 36, 300)])
+def test_fp16_path_matches_float64_truth_within_tolerance(oracle, shape, metric):
+    from neighborhoodwatch_amd import KnnEngine
+    q, b, d, k = shape
+    base16, queries16 = oracle.gen_f16_numpy(0x71 + d, 0, b, d), oracle.gen_f16_numpy(0x72 + d, 0, q, d)
+    with KnnEngine(0) as eng:
+        eng.set_base(base16)                                  # fp16 input selects the fp16 MFMA path
+        dist, idx = eng.search(queries16, k, metric)
+    bf, qf, (ed, ei) = _f16_reference(oracle, base16, queries16, k, metric)
+    err, slack = oracle.check_against_exact(bf, qf, dist, idx, ed, metric)      # 1e-5 * max(1, |q|^2+|b|^2), near-tie aware
+    assert (idx == ei).mean() > 0.98
+
+
+def test_fp16_compute_on_fp32_input_rounds_to_nearest_even(oracle):
+    from neighborhoodwatch_amd import KnnEngine
+    base, queries = oracle.gen(0x81, 0, 3000, 384), oracle.gen(0x82, 0, 200, 384)
+    with KnnEngine(0) as eng:
+        eng.set_compute_dtype("f16")
+        eng.set_base(base)
+        dist, idx = eng.search(queries, 50)
+        eng.set_compute_dtype("f32")                           # and back: the next set_base is exact fp32 again
+        eng.set_base(base)
+        d32, i32 = eng.search(queries, 50)
+    b16, q16 = base.astype(np.float16), queries.astype(np.float16)
+    bf, qf, (ed, ei) = _f16_reference(oracle, b16, q16, 50, "sqeuclidean")
+    oracle.check_against_exact(bf, qf, dist, idx, ed, "sqeuclidean")
+    rd, ri = oracle.knn_canonical(base, queries, 50)
+    assert np.array_equal(i32, ri) and _same_bits(d32, rd)
+
+
+def test_fp16_device_generator_equals_host_generator(engine, oracle):
+    x = engine.generate(oracle.SEED_BASE, 4321, 200, 130, dtype="f16").cpu().numpy()
+    assert x.dtype == np.float16 and np.array_equal(x, oracle.gen_f16_numpy(oracle.SEED_BASE, 4321, 200, 130))
+
+
+def test_fp16_overflow_repair_and_shards(oracle):
+    from neighborhoodwatch_amd import KnnEngine
+    from neighborhoodwatch_amd.distributed import shard_bounds
+    base16, queries16 = oracle.gen_f16_numpy(0x91, 0, 6000, 128), oracle.gen_f16_numpy(0x92, 0, 300, 128)
+    bf, qf, (ed, ei) = _f16_reference(oracle, base16, queries16, 20, "sqeuclidean")
+    with KnnEngine(0) as eng:
+        eng.set_option("capacity", 1024); eng.set_option("max_chunk", 256)
+        eng.set_base(base16)
+        d1, i1 = eng.search(queries16, 20)
+        oracle.check_against_exact(bf, qf, d1, i1, ed, "sqeuclidean")
+        pd, pi = [], []
+        for r in range(3):
+            lo, hi = shard_bounds(6000, 3, r)
+            eng.set_base(base16[lo:hi])
+            dd, ii = eng.search(queries16, 20, index_offset=lo)
+            pd.append(dd); pi.append(ii)
+        md, mi = eng.merge(np.stack(pd), np.stack(pi), 20)
+    oracle.check_against_exact(bf, qf, md, mi, ed, "sqeuclidean")
