@@ -37,7 +37,7 @@ WORKLOADS = {
     # BASELINE config 4 (fp16 MFMA + L2, 8 GPUs) and the piece of it one GPU sees (its 12.5M-row shard, a tenth of the queries)
     "c4": (1_000_000, 100_000_000, 1536, 100, "sqeuclidean", "f16", "C4: 1M queries x 100M base, d=1536 (ada-002 shape), k=100, fp16 MFMA sqeuclidean"),
     "c4gpu": (100_000, 12_500_000, 1536, 100, "sqeuclidean", "f16", "C4 per-GPU slice: 100k queries x 12.5M base rows (one of 8 shards), d=1536, k=100, fp16"),
-    "dev16": (8_192, 524_288, 512, 100, "sqeuclidean", "f16", "dev16: 8k x 512k, d=512, k=100, fp16 (not a headline number)"),
+    "dev16": (32_768, 1_048_576, 1536, 100, "sqeuclidean", "f16", "dev16: 32k x 1M, d=1536, k=100, fp16 (not a headline number)"),
 }
 SEED_BASE, SEED_QUERY = 0x6E770001, 0x6E770002
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0}      # MI355X_MICROARCH.md: dense f32 / f16 MFMA peaks

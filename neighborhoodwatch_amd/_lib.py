@@ -10,8 +10,11 @@ import ctypes
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 from pathlib import Path
 
+import os
+
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "libnwknn.so"
+# NWKNN_LIB_PATH: developers A/B two builds of the library inside one GPU session (tools/ab_libs.sh); unset in production
+LIB_PATH = Path(os.environ["NWKNN_LIB_PATH"]) if os.environ.get("NWKNN_LIB_PATH") else PKG_DIR / "libnwknn.so"
 
 NWKNN_OK = 0
 HOST, DEVICE = 0, 1

@@ -358,7 +358,7 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
     tp.dense_col0 = lo;
     if (qtile_list) { tp.qtile_list = qtile_list; tp.n_qtiles = n_list_tiles; }
     EvPair* e = ev_begin(h, 0);
-    if (h->f16) HIPCHK(nwk_launch_tile_f16(h->stream, tp, metric, dense));
+    if (h->f16) HIPCHK(nwk_launch_tile_f16(h->stream, tp, metric, dense, (int)h->opt_diag));
     else HIPCHK(nwk_launch_tile(h->stream, tp, metric, dense, pl.tile_rows, (int)h->opt_diag));
     ev_end(h, e);
     h->stats.tile_launches += 1;

@@ -227,67 +227,129 @@ __device__ __forceinline__ TileCoord tile_from_block(const NwkTileParams& p)
 // ------------------------------------------------------------------------------------------------
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
+// Pre-filter.  key < tau requires dist <= tau_d (tau_d = distance part of tau).  For the two additive metrics that is a
+// lower bound on the raw dot product that splits into a row part and a column part:
+//     sqeuclidean   : qn + bn - 2 dot <= tau_d   <=>  dot >= (qn - tau_d)/2 + bn/2
+//     one_minus_dot : 1 - dot <= tau_d           <=>  dot >= 1 - tau_d
+// so the common case costs one add and one compare per accumulator.  The row part is lowered by a margin that covers
+// every rounding of the canonical fp32 evaluation (a few ulps of the operands), which makes the test a strict superset of
+// the exact one; whatever passes it is re-evaluated exactly.  Cosine has no additive split and pre-tests on the distance.
+template <int METRIC>
+__device__ __forceinline__ float prefilter_row(float qn, u64 tau)
+{
+    if (tau == ~0ull) return -__builtin_inff();                      // fewer than k listed: everything may pass
+    const float td = unsortable_f32((u32)(tau >> 32));
+    if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) return 0.5f * (qn - td) - 1.0e-6f * (fabsf(qn) + fabsf(td)) - 1.0e-30f;
+    if (METRIC == NWKNN_METRIC_ONE_MINUS_DOT) return (1.0f - td) - 1.0e-6f * (1.0f + fabsf(td));
+    return td;                                                        // cosine: compared against the distance itself
+}
+template <int METRIC>
+__device__ __forceinline__ float prefilter_col(float bn)
+{
+    if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) return 0.5f * bn - 1.0e-6f * fabsf(bn);
+    return 0.0f;
+}
+
 template <int METRIC, bool DENSE, int MT>
 __device__ __forceinline__ void tile_epilogue(const NwkTileParams& p, const f32x16 (&acc)[MT][2], const float* s_qn, const u64* s_tau,
-                                              const float (&bnv)[2], const u32 (&colv)[2], const bool (&colok)[2], long long q0, int wrow0,
-                                              int h, int c32)
+                                              const float* s_pre, const float (&bnv)[2], const u32 (&colv)[2], const bool (&colok)[2],
+                                              long long q0, int wrow0, int h, int c32)
 {
     const int cap = p.cap;
+    float cpre[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) cpre[n] = colok[n] ? prefilter_col<METRIC>(bnv[n]) : __builtin_inff();   // padding columns never pass
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int rb = wrow0 + m * 32 + 4 * h;
-        f32x4 qn4[4];
-        u64x2 tl[4], th[4];
+        if (DENSE) {
+            f32x4 qn4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            qn4[j] = *(const f32x4*)(s_qn + rb + 8 * j);
-            if (!DENSE) {
+            for (int j = 0; j < 4; ++j) qn4[j] = *(const f32x4*)(s_qn + rb + 8 * j);
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dist = distance_epilogue<METRIC>(acc[m][n][r], qn4[r >> 2][r & 3], bnv[n]);
+                    const int row = rb + (r & 3) + 8 * (r >> 2);
+                    const u32 sd = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? (__float_as_uint(dist) | 0x80000000u) : sortable_u32(dist);
+                    const long long slot = (long long)(colv[n] - (u32)p.dense_col0);
+                    p.buf[(q0 + row) * cap + slot] = colok[n] ? (((u64)sd << 32) | colv[n]) : ~0ull;
+                }
+            continue;
+        }
+        f32x4 pre4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pre4[j] = *(const f32x4*)(s_pre + rb + 8 * j);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            bool maybe = false;
+            if (METRIC == NWKNN_METRIC_COSINE) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rb + (r & 3) + 8 * (r >> 2);
+                    const float dist = distance_epilogue<METRIC>(acc[m][n][r], s_qn[row], bnv[n]);
+                    maybe |= !(dist > pre4[r >> 2][r & 3]);
+                }
+                maybe &= colok[n];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) maybe |= !(acc[m][n][r] < pre4[r >> 2][r & 3] + cpre[n]);   // NaN falls through
+            }
+            if (!__ballot(maybe)) continue;                        // the common case: nothing in this 32x32 block can survive
+            // exact pass over the block: norms and thresholds of its 16 rows per lane come in with 12 ds_read_b128, then
+            // straight-line VALU (distance -> key -> 64-bit compare); only rows with a survivor reach the atomics
+            f32x4 qn4[4];
+            u64x2 tl[4], th[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                qn4[j] = *(const f32x4*)(s_qn + rb + 8 * j);
                 tl[j] = *(const u64x2*)(s_tau + rb + 8 * j);
                 th[j] = *(const u64x2*)(s_tau + rb + 8 * j + 2);
             }
-        }
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
             u64 key[16];
             bool pass[16];
-            bool any = false;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float dist = distance_epilogue<METRIC>(acc[m][n][r], qn4[r >> 2][r & 3], bnv[n]);
                 const u32 sd = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? (__float_as_uint(dist) | 0x80000000u)   // dist >= +0, never NaN
                                                                      : sortable_u32(dist);
                 key[r] = ((u64)sd << 32) | colv[n];
-                if (!DENSE) {
-                    const u64 tau = (r & 2) ? th[r >> 2][r & 1] : tl[r >> 2][r & 1];
-                    pass[r] = (key[r] < tau) & colok[n];
-                    any |= pass[r];
-                }
+                const u64 tau = (r & 2) ? th[r >> 2][r & 1] : tl[r >> 2][r & 1];
+                pass[r] = (key[r] < tau) & colok[n];               // exact (distance, index) order
             }
-            if (DENSE) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 16; ++r) {
+                const u64 mk = __ballot(pass[r]);
+                if (mk) {                                        // wave-uniform
                     const int row = rb + (r & 3) + 8 * (r >> 2);
-                    const long long slot = (long long)(colv[n] - (u32)p.dense_col0);
-                    p.buf[(q0 + row) * cap + slot] = colok[n] ? key[r] : ~0ull;
-                }
-            } else if (__ballot(any)) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const u64 mk = __ballot(pass[r]);
-                    if (mk) {                                        // wave-uniform
-                        const int row = rb + (r & 3) + 8 * (r >> 2);
-                        const u32 mh = h ? (u32)(mk >> 32) : (u32)mk; // this half-wave's survivors: all for ONE query row
-                        const int leader = mh ? (__ffs(mh) - 1) : 0;
-                        u32 base = 0;
-                        if (mh && c32 == leader) base = atomicAdd(p.cnt + q0 + row, (u32)__popc(mh));
-                        base = __shfl(base, leader + (h << 5));
-                        if (pass[r]) {
-                            const u32 pos = base + __popc(mh & ((1u << c32) - 1u));
-                            if (pos < (u32)cap) p.buf[(q0 + row) * cap + pos] = key[r];
-                        }
+                    const u32 mh = h ? (u32)(mk >> 32) : (u32)mk; // this half-wave's survivors: all for ONE query row
+                    const int leader = mh ? (__ffs(mh) - 1) : 0;
+                    u32 base = 0;
+                    if (mh && c32 == leader) base = atomicAdd(p.cnt + q0 + row, (u32)__popc(mh));
+                    base = __shfl(base, leader + (h << 5));
+                    if (pass[r]) {
+                        const u32 pos = base + __popc(mh & ((1u << c32) - 1u));
+                        if (pos < (u32)cap) p.buf[(q0 + row) * cap + pos] = key[r];
                     }
                 }
             }
+        }
+    }
+}
+
+// staging of the tile's query-side epilogue inputs in LDS: norms | 64-bit thresholds | pre-filter row terms
+template <int METRIC, bool DENSE>
+__device__ __forceinline__ void stage_query_side(char* lds, int rows, int tid, float my_qn, u64 my_tau)
+{
+    float* s_qn = (float*)lds;
+    u64* s_tau = (u64*)(lds + rows * 4);
+    float* s_pre = (float*)(lds + rows * 12);
+    if (tid < rows) {
+        s_qn[tid] = my_qn;
+        if (!DENSE) {
+            s_tau[tid] = my_tau;
+            s_pre[tid] = prefilter_row<METRIC>(my_qn, my_tau);
         }
     }
 }
@@ -308,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void nwk_tile_kernel(const NwkTileParams p)
     constexpr int LPS = IA + IB;
     constexpr int NG = BKT / 8;                   // 8-k groups per slab
     static_assert((TM == 128 && BKT == 32) || (TM == 256 && BKT == 16), "built shapes");
-    static_assert(2 * STAGE >= TM * 12, "epilogue staging reuses the operand stages");
+    static_assert(2 * STAGE >= TM * 16, "epilogue staging reuses the operand stages");
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
     unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;
@@ -442,14 +504,10 @@ __global__ __launch_bounds__(256, 2) void nwk_tile_kernel(const NwkTileParams p)
 
     if (p.dbg) st2 = __builtin_amdgcn_s_memtime();
     // ---- epilogue: accumulators -> keys -> filter -> candidate lists (staging reuses the idle operand stages)
-    float* s_qn = (float*)smem;
-    u64* s_tau = (u64*)(smem + TM * 4);
-    if (tid < TM) {
-        s_qn[tid] = my_qn;
-        if (!DENSE) s_tau[tid] = my_tau;
-    }
+    stage_query_side<METRIC, DENSE>(smem, TM, tid, my_qn, my_tau);
     __syncthreads();
-    tile_epilogue<METRIC, DENSE, MT>(p, acc, s_qn, s_tau, bnv, colv, colok, q0, wr * (TM / 2), h, c32);
+    tile_epilogue<METRIC, DENSE, MT>(p, acc, (const float*)smem, (const u64*)(smem + TM * 4), (const float*)(smem + TM * 12), bnv, colv, colok,
+                                     q0, wr * (TM / 2), h, c32);
     if (p.dbg && tid == 0) {
         unsigned long long* o = p.dbg + (size_t)blockIdx.x * 8;
         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memtime(); o[4] = rt0; o[5] = __builtin_amdgcn_s_memrealtime();
@@ -470,10 +528,11 @@ __global__ __launch_bounds__(256, 2) void nwk_tile_kernel(const NwkTileParams p)
 #define H_BK 64                       // halves per slab = 128-B rows
 #define H_STAGE (2 * 256 * 128)       // A 32 KiB + B 32 KiB
 
-template <int METRIC, bool DENSE>
+template <int METRIC, bool DENSE, int DIAG = 0>
 __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16(const NwkTileParams p)
 {
-    __shared__ __attribute__((aligned(16))) char smem[2 * H_STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[2 * H_STAGE + H_TM * 16];
+    char* const epi = smem + 2 * H_STAGE;     // query norms | thresholds | pre-filter terms of this tile, written once up front
 
     const TileCoord tc = tile_from_block(p);
     if (!tc.ok) return;
@@ -540,49 +599,87 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16(const NwkTileParam
         colok[n] = col < p.nb_valid;
         bnv[n] = p.bn[col];
     }
-    float my_qn = 0.f;
-    u64 my_tau = ~0ull;
-    if (tid < H_TM) {
-        my_qn = p.qn[q0 + tid];
-        if (!DENSE) my_tau = p.tau[q0 + tid];
+    {   // query-side epilogue inputs go to their own LDS region now; the first barrier of the K loop publishes them
+        float my_qn = 0.f;
+        u64 my_tau = ~0ull;
+        if (tid < H_TM) {
+            my_qn = p.qn[q0 + tid];
+            if (!DENSE) my_tau = p.tau[q0 + tid];
+        }
+        stage_query_side<METRIC, DENSE>(epi, H_TM, tid, my_qn, my_tau);
     }
+
+    // Software pipeline: fragment registers are double buffered (set S feeds the MFMAs of k-step s while the ds_reads of
+    // k-step s+1 land in set S^1), and there is ONE barrier per slab, placed before the slab's last k-step: by then this
+    // wave has completed every LDS read of slab kt and slab kt+1's DMA (issued a slab earlier) has landed, so the same
+    // barrier publishes slab kt+1 and releases slab kt's buffer; the DMA of slab kt+2 and the first fragment reads of
+    // slab kt+1 go out right behind it, under the 8 MFMAs of the last k-step.
+    f16x8 fa[2][4], fb[2][2];
+    auto read_frags = [&](int set, int stage, int ks) {
+        const char* sb = smem + stage * H_STAGE;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) fa[set][m] = *(const f16x8*)(sb + (offA[m] ^ (ks << 5)));
+#pragma unroll
+        for (int n = 0; n < 2; ++n) fb[set][n] = *(const f16x8*)(sb + (offB[n] ^ (ks << 5)));
+    };
+    auto mma = [&](int set, int m0, int m1) {
+#pragma unroll
+        for (int m = m0; m < m1; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][m], fb[set][n], acc[m][n], 0, 0, 0);
+    };
+#define NWK_HSTEP(SET, NEXT_STAGE, NEXT_KS)              \
+    do {                                                 \
+        __builtin_amdgcn_sched_barrier(0);               \
+        mma(SET, 0, 1);                                  \
+        __builtin_amdgcn_sched_barrier(0);               \
+        if (!(DIAG & 1)) read_frags((SET) ^ 1, NEXT_STAGE, NEXT_KS); \
+        __builtin_amdgcn_sched_barrier(0);               \
+        mma(SET, 1, 4);                                  \
+        __builtin_amdgcn_sched_barrier(0);               \
+    } while (0)
 
     issue_stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            issue_stage(cur ^ 1, kt + 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        const char* sb = smem + cur * H_STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {                       // 16 k's per step: chunk 2*ks + h
-            f16x8 a[4], b[2];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) a[m] = *(const f16x8*)(sb + (offA[m] ^ (ks << 5)));
-#pragma unroll
-            for (int n = 0; n < 2; ++n) b[n] = *(const f16x8*)(sb + (offB[n] ^ (ks << 5)));
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[n], acc[m][n], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+    if (nk > 1) {
+        issue_stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");       // slab 0 landed; my epilogue-input ds_writes are done
+    } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, 0);
+    if (DIAG & 1) read_frags(1, 0, 1);
 
-    float* s_qn = (float*)smem;
-    u64* s_tau = (u64*)(smem + H_TM * 4);
-    if (tid < H_TM) {
-        s_qn[tid] = my_qn;
-        if (!DENSE) s_tau[tid] = my_tau;
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const int cur = kt & 1;
+        NWK_HSTEP(0, cur, 1);
+        NWK_HSTEP(1, cur, 2);
+        NWK_HSTEP(0, cur, 3);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (!(DIAG & 4)) __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk && !(DIAG & 2)) issue_stage(cur, kt + 2);
+        NWK_HSTEP(1, cur ^ 1, 0);
     }
-    __syncthreads();
-    tile_epilogue<METRIC, DENSE, 4>(p, acc, s_qn, s_tau, bnv, colv, colok, q0, wr * 128, h, c32);
+    {
+        const int cur = (nk - 1) & 1;
+        NWK_HSTEP(0, cur, 1);
+        NWK_HSTEP(1, cur, 2);
+        NWK_HSTEP(0, cur, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, 0, 4);
+    }
+#undef NWK_HSTEP
+
+    if (!(DIAG & 16))
+        tile_epilogue<METRIC, DENSE, 4>(p, acc, (const float*)epi, (const u64*)(epi + H_TM * 4), (const float*)(epi + H_TM * 12), bnv, colv,
+                                        colok, q0, wr * 128, h, c32);
+    else {                                                   // DIAG 16: no epilogue (keep the accumulators alive)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) asm volatile("" :: "v"(acc[m][n]));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -821,15 +918,23 @@ hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool den
 }
 
 template <int METRIC>
-static hipError_t launch_tile_f16_metric(hipStream_t st, const NwkTileParams& p, bool dense, unsigned grid)
+static hipError_t launch_tile_f16_metric(hipStream_t st, const NwkTileParams& p, bool dense, unsigned grid, int diag)
 {
-    if (dense) hipLaunchKernelGGL((nwk_tile_kernel_f16<METRIC, true>), dim3(grid), dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((nwk_tile_kernel_f16<METRIC, false>), dim3(grid), dim3(512), 0, st, p);
+    if (dense) { hipLaunchKernelGGL((nwk_tile_kernel_f16<METRIC, true, 0>), dim3(grid), dim3(512), 0, st, p); return hipGetLastError(); }
+    switch (diag) {              // dev-only timing ablations (wrong results by construction)
+    case 1: hipLaunchKernelGGL((nwk_tile_kernel_f16<METRIC, false, 1>), dim3(grid), dim3(512), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((nwk_tile_kernel_f16<METRIC, false, 2>), dim3(grid), dim3(512), 0, st, p); break;
+    case 4: hipLaunchKernelGGL((nwk_tile_kernel_f16<METRIC, false, 4>), dim3(grid), dim3(512), 0, st, p); break;
+    case 7: hipLaunchKernelGGL((nwk_tile_kernel_f16<METRIC, false, 7>), dim3(grid), dim3(512), 0, st, p); break;
+    case 16: hipLaunchKernelGGL((nwk_tile_kernel_f16<METRIC, false, 16>), dim3(grid), dim3(512), 0, st, p); break;
+    case 23: hipLaunchKernelGGL((nwk_tile_kernel_f16<METRIC, false, 23>), dim3(grid), dim3(512), 0, st, p); break;
+    default: hipLaunchKernelGGL((nwk_tile_kernel_f16<METRIC, false, 0>), dim3(grid), dim3(512), 0, st, p); break;
+    }
     return hipGetLastError();
 }
 
 // fp16 path: p.n_qtiles and p.n_btiles both count 256-row tiles; p.bt0 is in 256-row units; p.qp/p.bp point at halves.
-hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool dense)
+hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool dense, int diag)
 {
     if (p.n_qtiles <= 0 || p.n_btiles <= 0) return hipSuccess;
     const long long n_super_q = (p.n_qtiles + 7) / 8;
@@ -839,9 +944,9 @@ hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool
     const long long grid = supers * 64;
     if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
     switch (metric) {
-    case NWKNN_METRIC_SQEUCLIDEAN: return launch_tile_f16_metric<NWKNN_METRIC_SQEUCLIDEAN>(st, p, dense, (unsigned)grid);
-    case NWKNN_METRIC_ONE_MINUS_DOT: return launch_tile_f16_metric<NWKNN_METRIC_ONE_MINUS_DOT>(st, p, dense, (unsigned)grid);
-    case NWKNN_METRIC_COSINE: return launch_tile_f16_metric<NWKNN_METRIC_COSINE>(st, p, dense, (unsigned)grid);
+    case NWKNN_METRIC_SQEUCLIDEAN: return launch_tile_f16_metric<NWKNN_METRIC_SQEUCLIDEAN>(st, p, dense, (unsigned)grid, diag);
+    case NWKNN_METRIC_ONE_MINUS_DOT: return launch_tile_f16_metric<NWKNN_METRIC_ONE_MINUS_DOT>(st, p, dense, (unsigned)grid, diag);
+    case NWKNN_METRIC_COSINE: return launch_tile_f16_metric<NWKNN_METRIC_COSINE>(st, p, dense, (unsigned)grid, diag);
     default: return hipErrorInvalidValue;
     }
 }
