@@ -297,40 +297,39 @@ __device__ __forceinline__ void tile_epilogue(const NwkTileParams& p, const f32x
                 for (int r = 0; r < 16; ++r) maybe |= !(acc[m][n][r] < pre4[r >> 2][r & 3] + cpre[n]);   // NaN falls through
             }
             if (!__ballot(maybe)) continue;                        // the common case: nothing in this 32x32 block can survive
-            // exact pass over the block: norms and thresholds of its 16 rows per lane come in with 12 ds_read_b128, then
-            // straight-line VALU (distance -> key -> 64-bit compare); only rows with a survivor reach the atomics
-            f32x4 qn4[4];
-            u64x2 tl[4], th[4];
+            // exact pass over the block, four rows (one j) at a time to keep the register footprint small: norms and
+            // thresholds by ds_read_b128, straight-line VALU (distance -> key -> 64-bit compare); only rows with a survivor
+            // reach the atomics
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                qn4[j] = *(const f32x4*)(s_qn + rb + 8 * j);
-                tl[j] = *(const u64x2*)(s_tau + rb + 8 * j);
-                th[j] = *(const u64x2*)(s_tau + rb + 8 * j + 2);
-            }
-            u64 key[16];
-            bool pass[16];
+                const f32x4 qn4 = *(const f32x4*)(s_qn + rb + 8 * j);
+                const u64x2 tl = *(const u64x2*)(s_tau + rb + 8 * j);
+                const u64x2 th = *(const u64x2*)(s_tau + rb + 8 * j + 2);
+                u64 key[4];
+                bool pass[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float dist = distance_epilogue<METRIC>(acc[m][n][r], qn4[r >> 2][r & 3], bnv[n]);
-                const u32 sd = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? (__float_as_uint(dist) | 0x80000000u)   // dist >= +0, never NaN
-                                                                     : sortable_u32(dist);
-                key[r] = ((u64)sd << 32) | colv[n];
-                const u64 tau = (r & 2) ? th[r >> 2][r & 1] : tl[r >> 2][r & 1];
-                pass[r] = (key[r] < tau) & colok[n];               // exact (distance, index) order
-            }
+                for (int i = 0; i < 4; ++i) {
+                    const float dist = distance_epilogue<METRIC>(acc[m][n][4 * j + i], qn4[i], bnv[n]);
+                    const u32 sd = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? (__float_as_uint(dist) | 0x80000000u)   // dist >= +0, never NaN
+                                                                         : sortable_u32(dist);
+                    key[i] = ((u64)sd << 32) | colv[n];
+                    const u64 tau = (i & 2) ? th[i & 1] : tl[i & 1];
+                    pass[i] = (key[i] < tau) & colok[n];           // exact (distance, index) order
+                }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const u64 mk = __ballot(pass[r]);
-                if (mk) {                                        // wave-uniform
-                    const int row = rb + (r & 3) + 8 * (r >> 2);
-                    const u32 mh = h ? (u32)(mk >> 32) : (u32)mk; // this half-wave's survivors: all for ONE query row
-                    const int leader = mh ? (__ffs(mh) - 1) : 0;
-                    u32 base = 0;
-                    if (mh && c32 == leader) base = atomicAdd(p.cnt + q0 + row, (u32)__popc(mh));
-                    base = __shfl(base, leader + (h << 5));
-                    if (pass[r]) {
-                        const u32 pos = base + __popc(mh & ((1u << c32) - 1u));
-                        if (pos < (u32)cap) p.buf[(q0 + row) * cap + pos] = key[r];
+                for (int i = 0; i < 4; ++i) {
+                    const u64 mk = __ballot(pass[i]);
+                    if (mk) {                                    // wave-uniform
+                        const int row = rb + i + 8 * j;
+                        const u32 mh = h ? (u32)(mk >> 32) : (u32)mk; // this half-wave's survivors: all for ONE query row
+                        const int leader = mh ? (__ffs(mh) - 1) : 0;
+                        u32 base = 0;
+                        if (mh && c32 == leader) base = atomicAdd(p.cnt + q0 + row, (u32)__popc(mh));
+                        base = __shfl(base, leader + (h << 5));
+                        if (pass[i]) {
+                            const u32 pos = base + __popc(mh & ((1u << c32) - 1u));
+                            if (pos < (u32)cap) p.buf[(q0 + row) * cap + pos] = key[i];
+                        }
                     }
                 }
             }
@@ -920,6 +919,7 @@ hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool den
 template <int METRIC>
 static hipError_t launch_tile_f16_metric(hipStream_t st, const NwkTileParams& p, bool dense, unsigned grid, int diag)
 {
+
     if (dense) { hipLaunchKernelGGL((nwk_tile_kernel_f16<METRIC, true, 0>), dim3(grid), dim3(512), 0, st, p); return hipGetLastError(); }
     switch (diag) {              // dev-only timing ablations (wrong results by construction)
     case 1: hipLaunchKernelGGL((nwk_tile_kernel_f16<METRIC, false, 1>), dim3(grid), dim3(512), 0, st, p); break;
