@@ -38,3 +38,35 @@ def test_c2_full_size_properties_and_sampled_parity(oracle):
     assert np.array_equal(di[rows].view(np.uint32), rd.view(np.uint32))
     # regenerated on the host, the inputs are what the device generator wrote
     assert np.array_equal(hb[777_000:777_004], oracle.gen_numpy(oracle.SEED_BASE, 777_000, 4, d))
+
+
+@pytest.mark.timeout(1500)
+def test_c3_headline_size_properties_and_sampled_parity(oracle):
+    """BASELINE.json's headline config on one GPU: 100k queries x 10M base rows, d=1024, k=100 (41 GB of base in HBM).
+    Size-independent properties for all rows + 32 sampled queries recomputed on the CPU against the ENTIRE base."""
+    import torch
+    from neighborhoodwatch_amd import KnnEngine
+    Q, B, d, k = 100_000, 10_000_000, 1024, 100
+    with KnnEngine(0) as eng:
+        base = eng.generate(oracle.SEED_BASE, 0, B, d)
+        queries = eng.generate(oracle.SEED_QUERY, 0, Q, d)
+        eng.set_base(base)
+        dist, idx = eng.search(queries, k)
+        st = eng.stats()
+        probe = base[9_876_543:9_876_543 + 16].clone()            # base rows as queries: each must find itself at distance 0
+        pd_, pi_ = eng.search(probe, 2)
+    assert st["overflowed_queries"] == 0 and st["tile_launches"] == 21
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all())                                    # ascending (merge.py:104)
+    assert int(idx.min()) >= 0 and int(idx.max()) < B
+    srt = torch.sort(idx, dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())                                       # no duplicate neighbours
+    assert (pi_[:, 0].cpu().numpy() == np.arange(9_876_543, 9_876_543 + 16)).all() and (pd_[:, 0].cpu().numpy() == 0).all()
+    rows = np.linspace(0, Q - 1, 32).astype(np.int64)
+    hq = queries[torch.from_numpy(rows).cuda()].cpu().numpy()
+    di, ii = dist[torch.from_numpy(rows).cuda()].cpu().numpy(), idx[torch.from_numpy(rows).cuda()].cpu().numpy()
+    del dist, idx, queries
+    hb = base.cpu().numpy()                                                               # 41 GB D2H
+    del base
+    rd, ri = oracle.knn_canonical(hb, hq, k)
+    assert np.array_equal(ii, ri)
+    assert np.array_equal(di.view(np.uint32), rd.view(np.uint32))
