@@ -82,7 +82,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = 3;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -212,6 +212,9 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
     } else if (!strcmp(name, "compute_dtype")) {
         if (value != NWKNN_DTYPE_F32 && value != NWKNN_DTYPE_F16) return fail(NWKNN_EINVAL, "compute_dtype must be 0 (f32) or 1 (f16)");
         h->opt_compute_f16 = value;      // takes effect at the next nwknn_set_base
+    } else if (!strcmp(name, "super_q_shift")) {
+        if (value < 0 || value > 6) return fail(NWKNN_EINVAL, "super_q_shift must be 0..6");
+        h->opt_sq_shift = value;         // super-tile of an XCD = 2^v query tiles x 2^(6-v) base tiles
     } else if (!strcmp(name, "tile_rows")) {
         if (value != 0 && value != 128 && value != 256) return fail(NWKNN_EINVAL, "tile_rows must be 0 (auto), 128 or 256");
         h->opt_tile_rows = value;
@@ -335,6 +338,7 @@ static NwkTileParams tile_params(nwknn_ctx* h, const SearchPlan& pl, long long n
     p.nb_valid = h->nb;
     p.n_qtiles = (int)(nq_pad / pl.tile_rows);
     p.dp = h->dp; p.cap = pl.cap;
+    p.sq_shift = (int)h->opt_sq_shift;
     p.dbg = h->opt_dbg_ptr ? (unsigned long long*)(uintptr_t)h->opt_dbg_ptr : nullptr;
     return p;
 }

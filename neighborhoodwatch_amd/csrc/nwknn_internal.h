@@ -28,6 +28,7 @@ struct NwkTileParams {
     int bt0;                       // first base tile of this launch
     int n_btiles;
     int n_super_b;                 // filled in by the launcher
+    int sq_shift;                  // super-tile = (1 << sq_shift) query tiles x (64 >> sq_shift) base tiles
     int dp;
     int cap;
     unsigned long long* dbg;       // dev builds only: per-workgroup stamps {t_start, t_loop, t_loop_end, t_end, rt_start, rt_end, xcc, 0}

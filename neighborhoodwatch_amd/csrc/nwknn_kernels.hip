@@ -203,14 +203,15 @@ struct TileCoord { int qt, bt, ok; };
 
 __device__ __forceinline__ TileCoord tile_from_block(const NwkTileParams& p)
 {
-    // XCD-aware mapping: blocks b and b+8 share an XCD (and its L2); give each XCD 8x8 super-tiles so that the
-    // 64 co-resident workgroups of an XCD share 8 query tiles and 8 base tiles.
+    // XCD-aware mapping: blocks b and b+8 share an XCD (and its L2); each XCD works through super-tiles of 64 tiles
+    // (SQ query tiles x SB base tiles, SQ*SB = 64, SQ = 1 << p.sq_shift) so that its co-resident workgroups share operands.
     const int bid = blockIdx.x;
     const int xcd = bid & 7, local = bid >> 3;
     const long long super = (long long)(local >> 6) * 8 + xcd;
     const int within = local & 63;
+    const int sb_shift = 6 - p.sq_shift;
     const int sq = (int)(super / p.n_super_b), sb = (int)(super % p.n_super_b);
-    const int qi = sq * 8 + (within >> 3), bi = sb * 8 + (within & 7);
+    const int qi = (sq << p.sq_shift) + (within >> sb_shift), bi = (sb << sb_shift) + (within & ((1 << sb_shift) - 1));
     TileCoord t;
     t.ok = (qi < p.n_qtiles) && (bi < p.n_btiles);
     t.qt = t.ok ? (p.qtile_list ? p.qtile_list[qi] : qi) : 0;
@@ -902,8 +903,10 @@ hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool den
 {
     if (p.n_qtiles <= 0 || p.n_btiles <= 0) return hipSuccess;
     if (tile_rows != 128 && tile_rows != 256) return hipErrorInvalidValue;
-    const long long n_super_q = (p.n_qtiles + 7) / 8;
-    p.n_super_b = (p.n_btiles + 7) / 8;
+    if (p.sq_shift < 0 || p.sq_shift > 6) return hipErrorInvalidValue;
+    const int SQ = 1 << p.sq_shift, SB = 64 >> p.sq_shift;
+    const long long n_super_q = (p.n_qtiles + SQ - 1) / SQ;
+    p.n_super_b = (p.n_btiles + SB - 1) / SB;
     long long supers = n_super_q * p.n_super_b;
     supers = (supers + 7) / 8 * 8;
     const long long grid = supers * 64;
@@ -937,8 +940,10 @@ static hipError_t launch_tile_f16_metric(hipStream_t st, const NwkTileParams& p,
 hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool dense, int diag)
 {
     if (p.n_qtiles <= 0 || p.n_btiles <= 0) return hipSuccess;
-    const long long n_super_q = (p.n_qtiles + 7) / 8;
-    p.n_super_b = (p.n_btiles + 7) / 8;
+    if (p.sq_shift < 0 || p.sq_shift > 6) return hipErrorInvalidValue;
+    const int SQ = 1 << p.sq_shift, SB = 64 >> p.sq_shift;
+    const long long n_super_q = (p.n_qtiles + SQ - 1) / SQ;
+    p.n_super_b = (p.n_btiles + SB - 1) / SB;
     long long supers = n_super_q * p.n_super_b;
     supers = (supers + 7) / 8 * 8;
     const long long grid = supers * 64;

@@ -16,12 +16,19 @@ splitting (cu_knn.py:216-225) unnecessary -- ``split`` is accepted and does not 
 
 The reference's ``engine`` argument ('raft' | 'cuvs' | 'torch') selects the distance exactly as there:
 sqeuclidean, cosine, 1 - dot (cu_knn.py:243-262).
+
+Keyword-only additions (defaults keep the reference behaviour): ``metric`` (overrides ``engine``), ``dtype``
+('fp32' bit-exact | 'fp16' MFMA path), ``device`` / ``devices`` (base tiles are dealt round-robin to the listed GPUs,
+one engine and one host thread per GPU -- the reference is pinned to GPU 0, cu_knn.py:65), ``resume`` (skip base tiles
+whose partial pair already exists; the reference always recomputes).
 """
 from __future__ import annotations
 
 import gc
 import math
-from typing import Optional
+import os
+from concurrent.futures import ThreadPoolExecutor
+from typing import Optional, Sequence
 
 import numpy as np
 import pyarrow as pa
@@ -156,7 +163,10 @@ def compute_knn(data_dir,
                 *,
                 engine='raft',
                 metric: Optional[str] = None,
-                device: int = 0):
+                dtype: str = 'fp32',
+                device: int = 0,
+                devices: Optional[Sequence[int]] = None,
+                resume: bool = False):
     batch_size = initial_batch_size
     print("-- prepare query source table for brute-force KNN computation.")
     query_table = prep_table(data_dir, model_name, query_filename, query_count, dimensions)
@@ -170,7 +180,17 @@ def compute_knn(data_dir,
     assert (len(base_table) % batch_size == 0) or k <= (len(base_table) % batch_size), \
         f"Cannot generate k of {k} with only {len(base_table)} rows and batch_size of {batch_size}."      # cu_knn.py:177-178
 
-    process_batches(data_dir, base_table, query_table, batch_count, batch_size, k, split, engine, metric=metric, device=device)
+    process_batches(data_dir, base_table, query_table, batch_count, batch_size, k, split, engine, metric=metric, dtype=dtype,
+                    device=device, devices=devices, resume=resume)
+
+
+def _partial_pair_exists(data_dir, i, rows) -> bool:
+    fi, fd = get_partial_indices_filename(data_dir, i), get_partial_distances_filename(data_dir, i)
+    try:
+        return (os.path.getsize(fi) > 0 and os.path.getsize(fd) > 0 and pq.ParquetFile(fi).metadata.num_rows == rows
+                and pq.ParquetFile(fd).metadata.num_rows == rows)
+    except (OSError, pa.ArrowInvalid):
+        return False
 
 
 def process_batches(data_dir,
@@ -183,21 +203,44 @@ def process_batches(data_dir,
                     engine='raft',
                     *,
                     metric: Optional[str] = None,
-                    device: int = 0):
+                    dtype: str = 'fp32',
+                    device: int = 0,
+                    devices: Optional[Sequence[int]] = None,
+                    resume: bool = False):
     """One partial (distances, indices) parquet pair per base tile (cu_knn.py:193-287)."""
     metric = resolve_metric(metric, engine)
-    eng: KnnEngine = default_engine(device)
+    devices = list(devices) if devices else [device]
     queries = table_to_matrix(query_table)                      # uploaded once per tile call, not once per split
-    for start in range(0, batch_count):
-        batch_offset = start * batch_size
-        batch_length = batch_size if start != batch_count - 1 else len(base_table) - batch_offset
-        dataset = table_to_matrix(base_table.slice(batch_offset, batch_length))
-        assert (k <= len(dataset))                              # cu_knn.py:237
-        print(f"Dataset shape: {dataset.shape}, Query shape: {queries.shape}")
-        eng.set_base(dataset)
-        distances, indices = eng.search(queries, k, metric, index_offset=batch_offset)     # + batch_offset, cu_knn.py:273
-        assert (len(distances) == len(query_table))             # cu_knn.py:281-282
-        assert (len(indices) == len(query_table))
-        stream_cudf_to_parquet(get_partial_distances_filename(data_dir, start), distances, PARQUET_ROW_GROUP)
-        stream_cudf_to_parquet(get_partial_indices_filename(data_dir, start), indices, PARQUET_ROW_GROUP)
-        cleanup(dataset, distances, indices)
+
+    def run_tiles(slot: int):
+        # tiles slot, slot+n, slot+2n, ... on GPU devices[slot]; engines are per (device, slot) so that two slots may share a device
+        eng: KnnEngine = default_engine(devices[slot]) if len(devices) == 1 else KnnEngine(devices[slot])
+        eng.set_compute_dtype(dtype)
+        try:
+            for start in range(slot, batch_count, len(devices)):
+                batch_offset = start * batch_size
+                batch_length = batch_size if start != batch_count - 1 else len(base_table) - batch_offset
+                if resume and _partial_pair_exists(data_dir, start, len(query_table)):
+                    print(f"-- base tile {start}: partial files present, skipped")
+                    continue
+                dataset = table_to_matrix(base_table.slice(batch_offset, batch_length))
+                assert (k <= len(dataset))                              # cu_knn.py:237
+                print(f"Dataset shape: {dataset.shape}, Query shape: {queries.shape}")
+                eng.set_base(dataset)
+                distances, indices = eng.search(queries, k, metric, index_offset=batch_offset)     # + batch_offset, cu_knn.py:273
+                assert (len(distances) == len(query_table))             # cu_knn.py:281-282
+                assert (len(indices) == len(query_table))
+                stream_cudf_to_parquet(get_partial_distances_filename(data_dir, start), distances, PARQUET_ROW_GROUP)
+                stream_cudf_to_parquet(get_partial_indices_filename(data_dir, start), indices, PARQUET_ROW_GROUP)
+                cleanup(dataset, distances, indices)
+        finally:
+            eng.set_compute_dtype('fp32')
+            if len(devices) > 1:
+                eng.close()
+
+    if len(devices) == 1:
+        run_tiles(0)
+    else:
+        with ThreadPoolExecutor(max_workers=len(devices)) as pool:      # ctypes releases the GIL during the GPU calls
+            for f in [pool.submit(run_tiles, s) for s in range(len(devices))]:
+                f.result()

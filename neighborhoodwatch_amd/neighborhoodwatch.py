@@ -73,6 +73,10 @@ Some example commands:\n
     parser.add_argument('--engine', choices=['raft', 'cuvs', 'torch'], default='raft',
                         help="distance of the reference engine of that name: sqeuclidean | cosine | 1-dot")
     parser.add_argument('--device', type=int, default=0)
+    parser.add_argument('--devices', type=lambda s: [int(x) for x in s.split(',')], default=None,
+                        help='comma separated GPU ids: base tiles are dealt round-robin to them')
+    parser.add_argument('--dtype', choices=['fp32', 'fp16'], default='fp32', help='compute path (fp32 is bit-exact; fp16 uses the fp16 MFMA kernel)')
+    parser.add_argument('--resume', action='store_true', help='keep existing partial files and skip their base tiles')
     return parser
 
 
@@ -104,7 +108,8 @@ def main(argv=None):
         synth.write_source_parquet(base_filename, seed, args.base_count, output_dimension, args.normalize)
     print(f"(Base source file: {base_filename}) ({time.time() - section:.2f} s)")
 
-    cleanup_partial_parquet(f"{data_dir}/partial")
+    if not args.resume:
+        cleanup_partial_parquet(f"{data_dir}/partial")                                  # neighborhoodwatch.py:130
 
     print("Computing knn ......")
     section = time.time()
@@ -113,7 +118,8 @@ def main(argv=None):
                        args.enable_memory_tuning, args.k, engine=args.engine, device=args.device)
     else:
         compute_knn(data_dir, args.model_name, output_dimension, query_filename, args.query_count, base_filename,
-                    args.base_count, args.enable_memory_tuning, args.k, engine=args.engine, device=args.device)
+                    args.base_count, args.enable_memory_tuning, args.k, engine=args.engine, device=args.device,
+                    devices=args.devices, dtype=args.dtype, resume=args.resume)
     print(f"(Duration: {time.time() - section:.2f} seconds out of {time.time() - start_time:.2f} seconds)")
 
     print("Merging indices and distances ......")

@@ -124,3 +124,49 @@ def test_cli_end_to_end(tmp_path, oracle):
     qv, bv, iv, dv = ptf.get_ivec_fvec_filenames(data_dir, "intfloat_e5-small-v2", 384, 3000, 200, 20)
     assert ptf.count_vectors(data_dir, qv) == 200 and ptf.count_vectors(data_dir, bv) == 3000
     assert np.array_equal(ptf.read_vectors(data_dir, iv), ri.astype(np.int32)) and np.array_equal(ptf.read_vectors(data_dir, dv), rd)
+
+
+def test_ck_token_level_knn(tmp_path, oracle):
+    """colbert_knn.process_knn_computation: token_embedding_<i> columns, d=128, 1 - dot, 9000-row base tiles, split=False."""
+    from neighborhoodwatch_amd.colbert_knn import process_knn_computation
+    (tmp_path / "partial").mkdir()
+    synth.write_source_parquet(str(tmp_path / "q_src.parquet"), 0x31, 150, 128, normalize=True, column_prefix="token_embedding_")
+    synth.write_source_parquet(str(tmp_path / "b_src.parquet"), 0x32, 20000, 128, normalize=True, column_prefix="token_embedding_")
+    # only the vector columns reach the engine (the reference selects float columns, cu_knn.py:208)
+    process_knn_computation(str(tmp_path), str(tmp_path / "b_src.parquet"), 20000, str(tmp_path / "q_src.parquet"), 150, k=10)
+    assert merge.get_file_count(f"{tmp_path}/partial") == 3                     # ceil(20000 / 9000), colbert_knn.py:95-98
+    merge.merge_indices_and_distances(str(tmp_path), k=10)
+    fd, fi = _final(str(tmp_path))
+    base = synth.gen_unit_rows(0x32, 0, 20000, 128); queries = synth.gen_unit_rows(0x31, 0, 150, 128)
+    rd, ri = oracle.knn_canonical(base, queries, 10, "one_minus_dot")
+    assert np.array_equal(_arr(fi, np.int64), ri) and np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
+
+
+def test_resume_skips_finished_tiles_and_two_engines_share_the_work(dataset, oracle, capsys):
+    data_dir, qf, bf = dataset
+    # two host threads / two engines (here both on GPU 0) deal the 3 base tiles round-robin
+    cu_knn.compute_knn(data_dir, "intfloat/e5-small-v2", 384, qf, 300, bf, 2600, False, 10, 1000, devices=[0, 0])
+    assert merge.get_file_count(f"{data_dir}/partial") == 3
+    import os
+    os.remove(nw_utils.get_partial_indices_filename(data_dir, 1))              # tile 1 is "unfinished"
+    capsys.readouterr()
+    cu_knn.compute_knn(data_dir, "intfloat/e5-small-v2", 384, qf, 300, bf, 2600, False, 10, 1000, resume=True)
+    out = capsys.readouterr().out
+    assert "base tile 0: partial files present, skipped" in out and "base tile 2: partial files present, skipped" in out
+    assert "base tile 1: partial" not in out
+    merge.merge_indices_and_distances(data_dir, k=10)
+    fd, fi = _final(data_dir)
+    base = synth.gen_unit_rows(0x72, 0, 2600, 384); queries = synth.gen_unit_rows(0x71, 0, 300, 384)
+    rd, ri = oracle.knn_canonical(base, queries, 10)
+    assert np.array_equal(_arr(fi, np.int64), ri) and np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
+
+
+def test_fp16_file_path(dataset, oracle):
+    data_dir, qf, bf = dataset
+    cu_knn.compute_knn(data_dir, "intfloat/e5-small-v2", 384, qf, 300, bf, 2600, False, 10, 100000, dtype="fp16")
+    merge.merge_indices_and_distances(data_dir, k=10)
+    fd, fi = _final(data_dir)
+    b16 = synth.gen_unit_rows(0x72, 0, 2600, 384).astype(np.float16).astype(np.float32)
+    q16 = synth.gen_unit_rows(0x71, 0, 300, 384).astype(np.float16).astype(np.float32)
+    ed, ei = oracle.knn_exact_fp64(b16, q16, 10)
+    oracle.check_against_exact(b16, q16, _arr(fd, np.float32), _arr(fi, np.int64), ed)
