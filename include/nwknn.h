@@ -44,6 +44,7 @@ extern "C" {
 
 #define NWKNN_DTYPE_F32 0
 #define NWKNN_DTYPE_F16 1          /* IEEE half: input element type and/or compute path (BASELINE config 4) */
+#define NWKNN_DTYPE_F64 2          /* double: accepted for COLUMN input only (float64 parquet columns, cast once: cu_knn.py:208,243) */
 
 #define NWKNN_HOST 0
 #define NWKNN_DEVICE 1
@@ -99,6 +100,11 @@ int nwknn_synchronize(nwknn_handle h);
  * "compute_dtype" = NWKNN_DTYPE_F16) selects the fp16 compute path: results then carry fp16 input rounding and are
  * checked against the float64 truth with a tolerance instead of bit for bit. */
 int nwknn_set_base(nwknn_handle h, const void* base, int64_t rows, int32_t d, int dtype, int location);
+/* Same, from COLUMN-major host data: columns[j] points at `rows` contiguous values of dimension j -- the layout parquet /
+ * arrow / cuDF hold (one column per dimension, generate_dataset.py:219-262).  Replaces the device transpose
+ * `cp.from_dlpack(df.to_dlpack()).copy(order='C')` of cu_knn.py:211: no host or device transpose pass is made, the layout
+ * kernel reads the columns directly.  dtype: NWKNN_DTYPE_F32 | NWKNN_DTYPE_F64 | NWKNN_DTYPE_F16. */
+int nwknn_set_base_columns(nwknn_handle h, const void* const* columns, int64_t rows, int32_t d, int dtype);
 
 /* ---- the operator: distances, indices = knn(dataset, queries, k)  (cu_knn.py:243-245) ------------------- */
 /* For each of the nq query rows: the k nearest rows of the base set, ascending by (distance, index),
@@ -107,6 +113,9 @@ int nwknn_set_base(nwknn_handle h, const void* base, int64_t rows, int32_t d, in
  * Requires 0 < k <= base rows (cu_knn.py:177-178,237) and k <= 1024. */
 int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int dtype, int location, int32_t k, int metric,
                  int64_t index_offset, float* out_dist, int64_t* out_idx, int out_location);
+/* Same with COLUMN-major host queries (cu_knn.py:229-235 converts the query tile the same way as the base tile). */
+int nwknn_search_columns(nwknn_handle h, const void* const* columns, int64_t nq, int dtype, int32_t k, int metric,
+                         int64_t index_offset, float* out_dist, int64_t* out_idx, int out_location);
 
 /* ---- merge of partial top-k lists: merge_indices_and_distances(), merge.py:56-101 ----------------------- */
 /* dists/idx: [n_lists][nq][k_in] (partial list l of query q at ((l*nq)+q)*k_in); idx < 0 marks an empty

@@ -18,7 +18,7 @@ LIB_PATH = Path(os.environ["NWKNN_LIB_PATH"]) if os.environ.get("NWKNN_LIB_PATH"
 
 NWKNN_OK = 0
 HOST, DEVICE = 0, 1
-DTYPE_F32, DTYPE_F16 = 0, 1
+DTYPE_F32, DTYPE_F16, DTYPE_F64 = 0, 1, 2
 METRIC_IDS = {"sqeuclidean": 0, "one_minus_dot": 1, "cosine": 2}
 # the reference selects the distance through its `engine` argument (cu_knn.py:193-200,243-262)
 ENGINE_TO_METRIC = {"raft": "sqeuclidean", "torch": "one_minus_dot", "cuvs": "cosine", "hip": "sqeuclidean"}
@@ -26,7 +26,7 @@ ENGINE_TO_METRIC = {"raft": "sqeuclidean", "torch": "one_minus_dot", "cuvs": "co
 EXPORTS = [
     "nwknn_version", "nwknn_last_error", "nwknn_device_count", "nwknn_mem_info", "nwknn_create", "nwknn_destroy",
     "nwknn_set_stream", "nwknn_set_option", "nwknn_get_stats", "nwknn_synchronize", "nwknn_set_base", "nwknn_search",
-    "nwknn_merge", "nwknn_generate",
+    "nwknn_merge", "nwknn_generate", "nwknn_set_base_columns", "nwknn_search_columns",
 ]
 
 
@@ -96,6 +96,8 @@ def load() -> ctypes.CDLL:
     L.nwknn_set_base.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int, c_int]
     L.nwknn_search.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_int32, c_int, c_int64, c_void_p, c_void_p, c_int]
     L.nwknn_merge.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int]
+    L.nwknn_set_base_columns.argtypes = [c_void_p, POINTER(c_void_p), c_int64, c_int32, c_int]
+    L.nwknn_search_columns.argtypes = [c_void_p, POINTER(c_void_p), c_int64, c_int, c_int32, c_int, c_int64, c_void_p, c_void_p, c_int]
     L.nwknn_generate.argtypes = [c_void_p, c_uint64, c_int64, c_int64, c_int32, c_int, c_void_p]
     for name in EXPORTS:
         fn = getattr(L, name)

@@ -277,13 +277,43 @@ static int stage_and_prep(nwknn_ctx* h, const void* src, int location, int in_f1
     return NWKNN_OK;
 }
 
-extern "C" int nwknn_set_base(nwknn_handle h, const void* base, int64_t rows, int32_t d, int dtype, int location)
+// Column-major host input (one pointer per dimension, as parquet/arrow hold embeddings): each slab of rows is staged as
+// [d][slab_rows] by d plain copies (no host-side transpose) and the strided prep kernel writes the prepared layout.
+static int stage_and_prep_columns(nwknn_ctx* h, const void* const* columns, int in_dtype, int out_f16, long long rows, int d, long long rows_pad,
+                                  int dp, DevBuf& raw, void* dst, float* norms)
 {
-    if (!h || !base) return fail(NWKNN_EINVAL, "nwknn_set_base: null handle or base pointer");
-    if (dtype != NWKNN_DTYPE_F32 && dtype != NWKNN_DTYPE_F16) return fail(NWKNN_EINVAL, "nwknn_set_base: unsupported dtype %d", dtype);
+    const size_t in_es = in_dtype == NWKNN_DTYPE_F64 ? 8 : (in_dtype == NWKNN_DTYPE_F16 ? 2 : 4), out_es = out_f16 ? 2 : 4;
+    if (in_dtype == NWKNN_DTYPE_F16 && !out_f16) return fail(NWKNN_EINVAL, "fp16 columns need the fp16 compute path");
+    for (int j = 0; j < d; ++j)
+        if (!columns[j]) return fail(NWKNN_EINVAL, "column %d is a null pointer", j);
+    const long long slab_rows = std::max<long long>(256, ((256ll << 20) / ((long long)d * (long long)in_es)) / 256 * 256);
+    const long long stage_rows = std::min(slab_rows, std::max<long long>(rows, 1));
+    RCCHK(raw.ensure((size_t)stage_rows * d * in_es));
+    for (long long r0 = 0; r0 < rows_pad; r0 += slab_rows) {
+        const long long pad_here = std::min(slab_rows, rows_pad - r0);
+        const long long real_here = std::max<long long>(0, std::min(slab_rows, rows - r0));
+        if (real_here > 0)
+            for (int j = 0; j < d; ++j)
+                HIPCHK(hipMemcpyAsync((char*)raw.p + (size_t)j * stage_rows * in_es, (const char*)columns[j] + (size_t)r0 * in_es,
+                                      (size_t)real_here * in_es, hipMemcpyHostToDevice, h->stream));
+        EvPair* e = ev_begin(h, 2);
+        HIPCHK(nwk_launch_prep_strided(h->stream, raw.p, in_dtype, 1, stage_rows, real_here, d, pad_here, dp, out_f16,
+                                       (char*)dst + (size_t)r0 * dp * out_es, norms + r0));
+        ev_end(h, e);
+        HIPCHK(hipStreamSynchronize(h->stream));    // the staging slab is reused by the next copies
+    }
+    return NWKNN_OK;
+}
+
+static int set_base_common(nwknn_ctx* h, const void* base, const void* const* columns, int64_t rows, int32_t d, int dtype, int location)
+{
+    if (!h || (!base && !columns)) return fail(NWKNN_EINVAL, "nwknn_set_base: null handle or base pointer");
+    const bool cols = columns != nullptr;
+    if (dtype != NWKNN_DTYPE_F32 && dtype != NWKNN_DTYPE_F16 && !(cols && dtype == NWKNN_DTYPE_F64))
+        return fail(NWKNN_EINVAL, "nwknn_set_base: unsupported dtype %d", dtype);
     if (rows <= 0 || d <= 0) return fail(NWKNN_EINVAL, "nwknn_set_base: rows=%lld d=%d must be positive", (long long)rows, d);
     if (rows >= (1ll << 32) - 512) return fail(NWKNN_EINVAL, "nwknn_set_base: a shard holds at most 2^32-513 rows");
-    if (location != NWKNN_HOST && location != NWKNN_DEVICE) return fail(NWKNN_EINVAL, "bad location %d", location);
+    if (!cols && location != NWKNN_HOST && location != NWKNN_DEVICE) return fail(NWKNN_EINVAL, "bad location %d", location);
     RCCHK(use_device(h));
     const int f16 = (dtype == NWKNN_DTYPE_F16 || h->opt_compute_f16) ? 1 : 0;
     const long long rows_pad = round_up(rows, f16 ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS);
@@ -291,7 +321,8 @@ extern "C" int nwknn_set_base(nwknn_handle h, const void* base, int64_t rows, in
     RCCHK(h->bp.ensure((size_t)rows_pad * dp * (f16 ? 2 : 4)));
     RCCHK(h->bn.ensure((size_t)rows_pad * 4));
     h->ev_used = 0;
-    RCCHK(stage_and_prep(h, base, location, dtype == NWKNN_DTYPE_F16, f16, rows, d, rows_pad, dp, h->braw, h->bp.p, h->bn.as<float>()));
+    if (cols) RCCHK(stage_and_prep_columns(h, columns, dtype, f16, rows, d, rows_pad, dp, h->braw, h->bp.p, h->bn.as<float>()));
+    else RCCHK(stage_and_prep(h, base, location, dtype == NWKNN_DTYPE_F16, f16, rows, d, rows_pad, dp, h->braw, h->bp.p, h->bn.as<float>()));
     h->nb = rows; h->nb_pad = rows_pad; h->d = d; h->dp = dp; h->f16 = f16;
     if (h->opt_profile) {
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -300,6 +331,18 @@ extern "C" int nwknn_set_base(nwknn_handle h, const void* base, int64_t rows, in
         h->base_prep_ms = p;
     }
     return NWKNN_OK;
+}
+
+extern "C" int nwknn_set_base(nwknn_handle h, const void* base, int64_t rows, int32_t d, int dtype, int location)
+{
+    if (!base) return fail(NWKNN_EINVAL, "nwknn_set_base: null handle or base pointer");
+    return set_base_common(h, base, nullptr, rows, d, dtype, location);
+}
+
+extern "C" int nwknn_set_base_columns(nwknn_handle h, const void* const* columns, int64_t rows, int32_t d, int dtype)
+{
+    if (!columns) return fail(NWKNN_EINVAL, "nwknn_set_base_columns: null column table");
+    return set_base_common(h, nullptr, columns, rows, d, dtype, NWKNN_HOST);
 }
 
 // ---- search -----------------------------------------------------------------------------------------
@@ -438,16 +481,17 @@ static int repair(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long lo
     return NWKNN_OK;
 }
 
-extern "C" int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int dtype, int location, int32_t k, int metric, int64_t index_offset,
-                            float* out_dist, int64_t* out_idx, int out_location)
+static int search_common(nwknn_ctx* h, const void* queries, const void* const* qcolumns, int64_t nq, int dtype, int location, int32_t k, int metric,
+                         int64_t index_offset, float* out_dist, int64_t* out_idx, int out_location)
 {
-    if (!h || !queries || !out_dist || !out_idx) return fail(NWKNN_EINVAL, "nwknn_search: null argument");
+    if (!h || (!queries && !qcolumns) || !out_dist || !out_idx) return fail(NWKNN_EINVAL, "nwknn_search: null argument");
     if (!h->bp.p || h->nb <= 0) return fail(NWKNN_ESTATE, "nwknn_search: call nwknn_set_base first");
     if (nq <= 0) return fail(NWKNN_EINVAL, "nwknn_search: nq=%lld must be positive", (long long)nq);
     if (k <= 0 || k > h->nb) return fail(NWKNN_EINVAL, "nwknn_search: k=%d must satisfy 0 < k <= %lld base rows", k, h->nb);   // cu_knn.py:237
     if (k > 1024) return fail(NWKNN_EINVAL, "nwknn_search: k=%d exceeds the supported maximum 1024", k);
     if (metric < 0 || metric > 2) return fail(NWKNN_EINVAL, "nwknn_search: unknown metric %d", metric);
-    if (dtype != NWKNN_DTYPE_F32 && dtype != NWKNN_DTYPE_F16) return fail(NWKNN_EINVAL, "nwknn_search: unsupported query dtype %d", dtype);
+    if (dtype != NWKNN_DTYPE_F32 && dtype != NWKNN_DTYPE_F16 && !(qcolumns && dtype == NWKNN_DTYPE_F64))
+        return fail(NWKNN_EINVAL, "nwknn_search: unsupported query dtype %d", dtype);
     if ((location != NWKNN_HOST && location != NWKNN_DEVICE) || (out_location != NWKNN_HOST && out_location != NWKNN_DEVICE))
         return fail(NWKNN_EINVAL, "nwknn_search: bad location");
     RCCHK(use_device(h));
@@ -468,7 +512,8 @@ extern "C" int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int
     h->ev_used = 0;
     if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_begin, h->stream));
 
-    RCCHK(stage_and_prep(h, queries, location, dtype == NWKNN_DTYPE_F16, h->f16, nq, h->d, nq_pad, h->dp, h->qraw, h->qp.p, h->qn.as<float>()));
+    if (qcolumns) RCCHK(stage_and_prep_columns(h, qcolumns, dtype, h->f16, nq, h->d, nq_pad, h->dp, h->qraw, h->qp.p, h->qn.as<float>()));
+    else RCCHK(stage_and_prep(h, queries, location, dtype == NWKNN_DTYPE_F16, h->f16, nq, h->d, nq_pad, h->dp, h->qraw, h->qp.p, h->qn.as<float>()));
     HIPCHK(hipMemsetAsync(h->tau.p, 0xFF, (size_t)nq_pad * 8, h->stream));
     HIPCHK(hipMemsetAsync(h->cnt.p, 0, (size_t)nq_pad * 4, h->stream));
     HIPCHK(hipMemsetAsync(h->ovf.p, 0, (size_t)nq_pad * 4, h->stream));
@@ -511,6 +556,20 @@ extern "C" int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int
         h->base_prep_ms = 0.0;
     }
     return NWKNN_OK;
+}
+
+extern "C" int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int dtype, int location, int32_t k, int metric, int64_t index_offset,
+                            float* out_dist, int64_t* out_idx, int out_location)
+{
+    if (!queries) return fail(NWKNN_EINVAL, "nwknn_search: null argument");
+    return search_common(h, queries, nullptr, nq, dtype, location, k, metric, index_offset, out_dist, out_idx, out_location);
+}
+
+extern "C" int nwknn_search_columns(nwknn_handle h, const void* const* columns, int64_t nq, int dtype, int32_t k, int metric, int64_t index_offset,
+                                    float* out_dist, int64_t* out_idx, int out_location)
+{
+    if (!columns) return fail(NWKNN_EINVAL, "nwknn_search_columns: null column table");
+    return search_common(h, nullptr, columns, nq, dtype, NWKNN_HOST, k, metric, index_offset, out_dist, out_idx, out_location);
 }
 
 // ---- merge ------------------------------------------------------------------------------------------

@@ -52,6 +52,8 @@ hipError_t nwk_launch_gen(hipStream_t st, uint64_t seed, long long row0, long lo
 hipError_t nwk_launch_gen_f16(hipStream_t st, uint64_t seed, long long row0, long long rows, int d, void* out);
 hipError_t nwk_launch_prep_f16(hipStream_t st, const void* raw, int raw_is_f16, long long rows, int d, long long rows_pad, int dp, void* prepared, float* norms);
 hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool dense, int diag);
+hipError_t nwk_launch_prep_strided(hipStream_t st, const void* raw, int in_dtype, long long rs, long long ks, long long rows, int d,
+                                   long long rows_pad, int dp, int out_f16, void* prepared, float* norms);
 hipError_t nwk_launch_prep(hipStream_t st, const float* raw, long long rows, int d, long long rows_pad, int dp, float* prepared, float* norms);
 hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool dense, int tile_rows, int diag);
 hipError_t nwk_launch_compact(hipStream_t st, const NwkCompactParams& p, long long n_queries);

@@ -26,6 +26,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
@@ -128,6 +129,47 @@ __global__ __launch_bounds__(256) void nwk_prep_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// prep from an arbitrary strided source: element (r, k) at raw[r*rs + k*ks].  Used for COLUMN-major input (rs = 1,
+// ks = rows of the staged slab): parquet stores one column per dimension (generate_dataset.py:219-262) and the reference
+// pays a device transpose per tile for it (cu_knn.py:211,235).  One lane owns one row, so for every k a wave reads 64
+// consecutive elements of column k -- the columnar layout is the coalesced one for this kernel -- and the norm chain and
+// the prepared row come out of the same pass.  TIN = float / double / _Float16 (values are converted with one rounding,
+// as ``.astype(np.float32)`` does at cu_knn.py:243); OUT16 selects the fp16 layout of the fp16 compute path.
+// ------------------------------------------------------------------------------------------------
+template <typename TIN, bool OUT16>
+__global__ __launch_bounds__(256) void nwk_prep_strided_kernel(const TIN* __restrict__ raw, long long rs, long long ks, long long rows, int d,
+                                                                long long rows_pad, int dp, void* __restrict__ prepared, float* __restrict__ norms)
+{
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows_pad) return;
+    const bool live = r < rows;
+    const TIN* src = raw + r * rs;
+    float acc = 0.0f;
+    for (int k0 = 0; k0 < dp; k0 += 8) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (live && k0 + j < d) ? (float)src[(long long)(k0 + j) * ks] : 0.0f;
+        if (OUT16) {
+            f16x8 hv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                hv[j] = (_Float16)x[j];
+                const float xf = (float)hv[j];
+                acc = __fmaf_rn(xf, xf, acc);
+            }
+            *(f16x8*)((_Float16*)prepared + r * dp + k0) = hv;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = __fmaf_rn(x[j], x[j], acc);
+            float* dst = (float*)prepared + r * dp + k0;
+            *(f32x4*)(dst) = (f32x4){x[0], x[2], x[4], x[6]};
+            *(f32x4*)(dst + 4) = (f32x4){x[1], x[3], x[5], x[7]};
+        }
+    }
+    norms[r] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
 // fp16 compute path (BASELINE config 4): generator and prep.
 //   * synthetic f16 values: the top 11 bits of the same 64-bit draw, as a signed integer times 2^-10 -- exactly
 //     representable in fp16, in [-1, 1)
@@ -136,7 +178,6 @@ __global__ __launch_bounds__(256) void nwk_prep_kernel(const float* __restrict__
 //     f32 input is rounded to nearest-even; the norm is the fp32 fmaf chain over the ROUNDED values, so every term of
 //     |q|^2 + |b|^2 - 2 q.b refers to the same vectors.
 // ------------------------------------------------------------------------------------------------
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256) void nwk_gen_f16_kernel(u64 seed, long long row0, long long rows, int d, _Float16* __restrict__ out)
 {
@@ -865,6 +906,21 @@ hipError_t nwk_launch_prep_f16(hipStream_t st, const void* raw, int raw_is_f16, 
         hipLaunchKernelGGL((nwk_prep_f16_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, (const _Float16*)raw, rows, d, rows_pad, dp, (_Float16*)prepared, norms);
     else
         hipLaunchKernelGGL((nwk_prep_f16_kernel<float>), dim3(blocks), dim3(256), 0, st, (const float*)raw, rows, d, rows_pad, dp, (_Float16*)prepared, norms);
+    return hipGetLastError();
+}
+
+// in_dtype: 0 f32, 1 f16, 2 f64 (NWKNN_DTYPE_*)
+hipError_t nwk_launch_prep_strided(hipStream_t st, const void* raw, int in_dtype, long long rs, long long ks, long long rows, int d,
+                                   long long rows_pad, int dp, int out_f16, void* prepared, float* norms)
+{
+    if (rows_pad <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((rows_pad + 255) / 256);
+#define NWK_PS(T, O) hipLaunchKernelGGL((nwk_prep_strided_kernel<T, O>), dim3(blocks), dim3(256), 0, st, (const T*)raw, rs, ks, rows, d, rows_pad, dp, prepared, norms)
+    if (in_dtype == 0) { if (out_f16) NWK_PS(float, true); else NWK_PS(float, false); }
+    else if (in_dtype == 1) { if (out_f16) NWK_PS(_Float16, true); else return hipErrorInvalidValue; }
+    else if (in_dtype == 2) { if (out_f16) NWK_PS(double, true); else NWK_PS(double, false); }
+    else return hipErrorInvalidValue;
+#undef NWK_PS
     return hipGetLastError();
 }
 

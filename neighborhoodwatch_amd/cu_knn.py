@@ -106,6 +106,21 @@ def table_to_matrix(table) -> np.ndarray:
     return out
 
 
+def table_columns(table):
+    """The float columns of an arrow table as a list of 1-D numpy arrays, zero-copy where arrow allows it (a sliced,
+    single-chunk column).  This is all the host does to a tile: the column -> row-major conversion the reference performs
+    on the GPU per tile (cu_knn.py:205-211,229-235) happens inside the engine's layout kernel, which reads the columns."""
+    fields = [f for f in table.schema if pa.types.is_float32(f.type) or pa.types.is_float64(f.type) or pa.types.is_float16(f.type)]
+    kinds = {str(f.type) for f in fields}
+    cols = []
+    for f in fields:
+        col = table.column(f.name)
+        arr = col.chunk(0) if col.num_chunks == 1 else col.combine_chunks()
+        a = arr.to_numpy(zero_copy_only=False)
+        cols.append(a if len(kinds) == 1 else a.astype(np.float32))
+    return cols
+
+
 # ---- memory tuning -------------------------------------------------------------------------------------
 def tune_memory(table, batch_size, max_memory_threshold, rmm=None, device: int = 0):
     """Base-tile rows from the GPU's memory size -- the arithmetic of cu_knn.py:54-109 without the probing
@@ -210,7 +225,7 @@ def process_batches(data_dir,
     """One partial (distances, indices) parquet pair per base tile (cu_knn.py:193-287)."""
     metric = resolve_metric(metric, engine)
     devices = list(devices) if devices else [device]
-    queries = table_to_matrix(query_table)                      # uploaded once per tile call, not once per split
+    queries = table_columns(query_table)                        # zero-copy views of the arrow columns
 
     def run_tiles(slot: int):
         # tiles slot, slot+n, slot+2n, ... on GPU devices[slot]; engines are per (device, slot) so that two slots may share a device
@@ -223,11 +238,11 @@ def process_batches(data_dir,
                 if resume and _partial_pair_exists(data_dir, start, len(query_table)):
                     print(f"-- base tile {start}: partial files present, skipped")
                     continue
-                dataset = table_to_matrix(base_table.slice(batch_offset, batch_length))
-                assert (k <= len(dataset))                              # cu_knn.py:237
-                print(f"Dataset shape: {dataset.shape}, Query shape: {queries.shape}")
-                eng.set_base(dataset)
-                distances, indices = eng.search(queries, k, metric, index_offset=batch_offset)     # + batch_offset, cu_knn.py:273
+                dataset = table_columns(base_table.slice(batch_offset, batch_length))
+                assert (k <= batch_length)                              # cu_knn.py:237
+                print(f"Dataset shape: ({batch_length}, {len(dataset)}), Query shape: ({len(query_table)}, {len(queries)})")
+                eng.set_base_columns(dataset)
+                distances, indices = eng.search_columns(queries, k, metric, index_offset=batch_offset)   # + batch_offset, cu_knn.py:273
                 assert (len(distances) == len(query_table))             # cu_knn.py:281-282
                 assert (len(indices) == len(query_table))
                 stream_cudf_to_parquet(get_partial_distances_filename(data_dir, start), distances, PARQUET_ROW_GROUP)

@@ -17,7 +17,7 @@ import numpy as np
 import pyarrow as pa
 import pyarrow.dataset as ds
 
-from .cu_knn import PARQUET_ROW_GROUP, cleanup, stream_cudf_to_parquet, table_to_matrix
+from .cu_knn import PARQUET_ROW_GROUP, cleanup, stream_cudf_to_parquet, table_columns
 from .engine import default_engine, mem_info, resolve_metric
 from .nw_utils import get_full_filename, get_partial_distances_filename, get_partial_indices_filename
 
@@ -110,23 +110,25 @@ def process_dataset_batches(data_dir,
                             device: int = 0):
     metric = resolve_metric(metric, engine)
     eng = default_engine(device)
-    queries = table_to_matrix(query_dataset.to_table(columns=query_column_names))
-    assert len(queries) == query_count                                            # cu_knn_ds.py:229-230
+    query_table = query_dataset.to_table(columns=query_column_names)
+    queries = table_columns(query_table)
+    assert len(query_table) == query_count                                        # cu_knn_ds.py:229-230
     run_d = run_i = None
     batch_offset = 0
     pending, pending_rows = [], 0
 
     def flush():
         nonlocal run_d, run_i, batch_offset, pending, pending_rows
-        base = table_to_matrix(pa.Table.from_batches(pending))
-        assert (k <= len(base))                                                   # cu_knn_ds.py:203
-        eng.set_base(base)
-        d, i = eng.search(queries, k, metric, index_offset=batch_offset)          # + batch_offset, cu_knn_ds.py:216
+        base_table = pa.Table.from_batches(pending)
+        base = table_columns(base_table)
+        assert (k <= len(base_table))                                             # cu_knn_ds.py:203
+        eng.set_base_columns(base)
+        d, i = eng.search_columns(queries, k, metric, index_offset=batch_offset)  # + batch_offset, cu_knn_ds.py:216
         if run_d is None:
             run_d, run_i = d, i
         else:
             run_d, run_i = eng.merge(np.stack([run_d, d]), np.stack([run_i, i]), k)
-        batch_offset += len(base)
+        batch_offset += len(base_table)
         pending, pending_rows = [], 0
         cleanup(base)
 

@@ -14,7 +14,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import DEVICE, DTYPE_F16, DTYPE_F32, ENGINE_TO_METRIC, HOST, METRIC_IDS, NwknnStats, check
+from ._lib import DEVICE, DTYPE_F16, DTYPE_F32, DTYPE_F64, ENGINE_TO_METRIC, HOST, METRIC_IDS, NwknnStats, check
 
 
 def _is_torch(x) -> bool:
@@ -115,6 +115,56 @@ class KnnEngine:
             self.synchronize()               # the caller may free/overwrite its tensor right after we return
         self.rows, self.dim = rows, dim
         del keep
+
+    # -- column-major input (what parquet / arrow hold: one array per dimension) ------------------------------
+    @staticmethod
+    def _columns(columns, what: str):
+        """-> (ctypes pointer table, rows, dim, dtype id, keepalive list).  Every column: 1-D, contiguous, same length and
+        dtype (float32 | float64 | float16)."""
+        cols = [np.asarray(c) for c in columns]
+        if not cols:
+            raise ValueError(f"{what}: no columns")
+        dt = cols[0].dtype
+        if dt not in (np.float32, np.float64, np.float16):
+            cols = [c.astype(np.float32) for c in cols]
+            dt = np.dtype(np.float32)
+        rows = cols[0].shape[0]
+        keep = []
+        for j, c in enumerate(cols):
+            if c.ndim != 1 or c.shape[0] != rows or c.dtype != dt:
+                raise ValueError(f"{what}: column {j} has shape {c.shape} / dtype {c.dtype}, expected ({rows},) / {dt}")
+            keep.append(np.ascontiguousarray(c))
+        table = (ctypes.c_void_p * len(keep))(*[c.ctypes.data for c in keep])
+        ident = {np.dtype(np.float32): DTYPE_F32, np.dtype(np.float64): DTYPE_F64, np.dtype(np.float16): DTYPE_F16}[np.dtype(dt)]
+        return table, rows, len(keep), ident, keep
+
+    def set_base_columns(self, columns) -> None:
+        """Base shard from per-dimension host arrays: no row-major copy is made on the host or the device
+        (the job of ``cp.from_dlpack(df.to_dlpack()).copy(order='C')``, cu_knn.py:211)."""
+        table, rows, dim, dt, keep = self._columns(columns, "dataset")
+        if rows == 0:
+            raise ValueError("dataset is empty")
+        check(self._L.nwknn_set_base_columns(self._h, table, rows, dim, dt), "nwknn_set_base_columns")
+        self.rows, self.dim = rows, dim
+        del keep
+
+    def search_columns(self, columns, k: int, metric: str = "sqeuclidean", index_offset: int = 0):
+        metric = resolve_metric(metric)
+        table, nq, dim, dt, keep = self._columns(columns, "queries")
+        if self.rows == 0:
+            raise _lib.NwknnError("search before set_base")
+        if dim != self.dim:
+            raise ValueError(f"queries have dimension {dim}, dataset has {self.dim}")
+        if not (0 < int(k) <= self.rows):
+            raise ValueError(f"k={k} must satisfy 0 < k <= {self.rows} dataset rows")      # cu_knn.py:237
+        if nq == 0:
+            raise ValueError("queries are empty")
+        od = np.empty((nq, k), dtype=np.float32)
+        oi = np.empty((nq, k), dtype=np.int64)
+        check(self._L.nwknn_search_columns(self._h, table, nq, dt, int(k), METRIC_IDS[metric], int(index_offset),
+                                           ctypes.c_void_p(od.ctypes.data), ctypes.c_void_p(oi.ctypes.data), HOST), "nwknn_search_columns")
+        del keep
+        return od, oi
 
     def search(self, queries, k: int, metric: str = "sqeuclidean", index_offset: int = 0, out_device: Optional[bool] = None):
         """-> (distances float32 [q,k], indices int64 [q,k]); torch CUDA tensors if the queries were, else numpy."""

@@ -250,3 +250,20 @@ def test_fp16_overflow_repair_and_shards(oracle):
             pd.append(dd); pi.append(ii)
         md, mi = eng.merge(np.stack(pd), np.stack(pi), 20)
     oracle.check_against_exact(bf, qf, md, mi, ed, "sqeuclidean")
+
+
+def test_column_major_input_equals_row_major(engine, oracle):
+    """set_base_columns / search_columns: per-dimension arrays (the parquet layout), float32 and float64."""
+    base, queries = oracle.gen(0xA1, 0, 3001, 100), oracle.gen(0xA2, 0, 77, 100)
+    rd, ri = oracle.knn_canonical(base, queries, 12)
+    engine.set_base_columns([np.ascontiguousarray(base[:, j]) for j in range(100)])
+    d, i = engine.search_columns([np.ascontiguousarray(queries[:, j]) for j in range(100)], 12)
+    assert np.array_equal(i, ri) and _same_bits(d, rd)
+    engine.set_base_columns([base[:, j].astype(np.float64) for j in range(100)])              # float64 columns are cast once (cu_knn.py:243)
+    d, i = engine.search_columns([queries[:, j].astype(np.float64) for j in range(100)], 12, "cosine")
+    rd, ri = oracle.knn_canonical(base, queries, 12, "cosine")
+    assert np.array_equal(i, ri) and _same_bits(d, rd)
+    d, i = engine.search(queries, 12, "cosine")                                                 # row-major queries against a column-loaded base
+    assert np.array_equal(i, ri) and _same_bits(d, rd)
+    with pytest.raises(ValueError):
+        engine.set_base_columns([base[:, 0], base[:10, 1]])
