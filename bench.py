@@ -37,6 +37,10 @@ WORKLOADS = {
     # BASELINE config 4 (fp16 MFMA + L2, 8 GPUs) and the piece of it one GPU sees (its 12.5M-row shard, a tenth of the queries)
     "c4": (1_000_000, 100_000_000, 1536, 100, "sqeuclidean", "f16", "C4: 1M queries x 100M base, d=1536 (ada-002 shape), k=100, fp16 MFMA sqeuclidean"),
     "c4gpu": (100_000, 12_500_000, 1536, 100, "sqeuclidean", "f16", "C4 per-GPU slice: 100k queries x 12.5M base rows (one of 8 shards), d=1536, k=100, fp16"),
+    # BASELINE config 5: MaxSim late interaction (an extension -- the reference's `ck` is flat token kNN): Q = queries of 32 tokens,
+    # B = docs of 64 tokens, d = 128, k = 1000; FLOPs = 2 * (32 Q) * (64 B) * d
+    "c5": (2_048, 1_000_000, 128, 1000, "maxsim", "f32", "C5: MaxSim, 2048 queries x 32 tokens vs 1M docs x 64 tokens, d=128, k=1000, fp32"),
+    "dev5": (256, 100_000, 128, 100, "maxsim", "f32", "dev5: MaxSim 256 queries vs 100k docs (not a headline number)"),
     "dev16": (32_768, 1_048_576, 1536, 100, "sqeuclidean", "f16", "dev16: 32k x 1M, d=1536, k=100, fp16 (not a headline number)"),
 }
 SEED_BASE, SEED_QUERY = 0x6E770001, 0x6E770002
@@ -126,12 +130,21 @@ def main():
         for kv in kvs.split(","):
             name, value = kv.split("=")
             eng.set_option(name, int(value))
-    base_raw = eng.generate(SEED_BASE, lo, hi - lo, d, dtype)     # this rank's shard, raw row-major in HBM (an fp16 base selects the fp16 path)
-    queries = eng.generate(SEED_QUERY, 0, Q, d, dtype)            # replicated
+    maxsim = metric == "maxsim"
+    if maxsim:                                                    # token matrices: docs [B, 64, d], queries [Q, 32, d]
+        base_raw = eng.generate(SEED_BASE, lo * 64, (hi - lo) * 64, d, dtype).view(hi - lo, 64, d)
+        queries = eng.generate(SEED_QUERY, 0, Q * 32, d, dtype).view(Q, 32, d)
+    else:
+        base_raw = eng.generate(SEED_BASE, lo, hi - lo, d, dtype)     # this rank's shard, raw row-major in HBM (an fp16 base selects the fp16 path)
+        queries = eng.generate(SEED_QUERY, 0, Q, d, dtype)            # replicated
     host_d = torch.empty((Q, k), dtype=torch.float32).pin_memory() if rank == 0 else None
     host_i = torch.empty((Q, k), dtype=torch.int64).pin_memory() if rank == 0 else None
 
     def search_shard(qs, kk, offset):
+        if maxsim:
+            eng.maxsim_set_docs(base_raw)
+            score, doc = eng.maxsim_search(qs, kk, doc_offset=offset)
+            return -score, doc                                    # ranked like distances through the shared merge
         eng.set_base(base_raw)                                    # layout + norms are part of every job
         return eng.search(qs, kk, metric, index_offset=offset)
 
@@ -183,7 +196,7 @@ def main():
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic (seeded counter-based embeddings in [-1,1), generated on device)",
-            "pairwise_tflops": 2.0 * Q * B * d * args.steps / elapsed / 1e12,
+            "pairwise_tflops": 2.0 * Q * B * d * (32 * 64 if maxsim else 1) * args.steps / elapsed / 1e12,
             "config": {"workload": desc, "queries": Q, "base_rows": B, "dim": d, "k": k, "metric": metric,
                        "parallelism": f"base rows sharded x{world}" + (" + RCCL all-gather of [Q,k] partials + merge" if world > 1 else "")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
@@ -196,13 +209,18 @@ def main():
                                       "prep": agg["prep_ms"] / args.steps, "rescan_launches": agg["rescan_launches"],
                                       "overflowed_queries": agg["overflowed_queries"]},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not maxsim:
             out["cpu_baseline"] = cpu_baseline(eng, base_raw, queries, k, metric, B)
         print(json.dumps(out), flush=True)
     if args.verify and rank == 0:
-        full = eng.generate(SEED_BASE, 0, B, d)
-        eng.set_base(full)
-        rd, ri = eng.search(queries, k, metric)
+        if maxsim:
+            eng.maxsim_set_docs(eng.generate(SEED_BASE, 0, B * 64, d).view(B, 64, d))
+            rs, ri = eng.maxsim_search(queries, k)
+            rd = -rs
+        else:
+            full = eng.generate(SEED_BASE, 0, B, d)
+            eng.set_base(full)
+            rd, ri = eng.search(queries, k, metric)
         dist, idx = last
         same = bool(torch.equal(ri, idx)) and bool(torch.equal(rd, dist))
         print(json.dumps({"verify": "merged N-rank result == single-engine result", "ok": same}), flush=True)

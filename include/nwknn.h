@@ -124,6 +124,18 @@ int nwknn_search_columns(nwknn_handle h, const void* const* columns, int64_t nq,
 int nwknn_merge(nwknn_handle h, const float* dists, const int64_t* idx, int32_t n_lists, int64_t nq, int32_t k_in,
                 int32_t k_out, float* out_dist, int64_t* out_idx, int location);
 
+/* ---- MaxSim late interaction (BASELINE.json config 5).  NOT in the reference: its `ck` program runs flat token-level
+ *      kNN through process_batches (colbert_knn.py:84-126); this is the ColBERT scoring rule itself, provided as an
+ *      extension with its own oracle (oracle nwo_maxsim) and no reference parity claim. ---------------------------- */
+/* doc_tokens: [n_docs][tokens_per_doc][d] float32, tokens_per_doc must be 64 (pad short docs by repeating a token). */
+int nwknn_maxsim_set_docs(nwknn_handle h, const void* doc_tokens, int64_t n_docs, int32_t tokens_per_doc, int32_t d,
+                          int dtype, int location);
+/* query_tokens: [n_queries][tokens_per_query][d] float32, tokens_per_query must be 32.
+ * score(q, doc) = sum_i max_j <q_i, doc_j>; writes the k highest-scoring docs per query, descending by
+ * (score, then lower doc id): out_score float32 [n_queries][k], out_doc int64 [n_queries][k] (+ doc_offset). */
+int nwknn_maxsim_search(nwknn_handle h, const void* query_tokens, int64_t n_queries, int32_t tokens_per_query, int dtype,
+                        int location, int32_t k, int64_t doc_offset, float* out_score, int64_t* out_doc, int out_location);
+
 /* ---- synthetic inputs (no reference counterpart: generate_dataset.py needs the network) ----------------- */
 /* Fill device buffer out[rows][d] with value(seed, row0 + r, c) in [-1,1): float32 on a 2^-23 grid, or fp16 on a
  * 2^-10 grid (the top bits of the same draw); the same integer recipe as oracle/cpu_oracle.gen_numpy /

@@ -76,6 +76,7 @@ struct nwknn_ctx {
     DevBuf bp, bn, braw;
     long long nb = 0, nb_pad = 0;
     int d = 0, dp = 0;
+    long long ms_docs = 0;          // > 0: the base holds ms_docs documents of NWK_MS_TOKENS_PER_DOC token rows each (MaxSim)
     int f16 = 0;                    // 1: the prepared base (and queries) are fp16, distance tiles run on the fp16 MFMA kernel
     // query side
     DevBuf qraw, qp, qn;
@@ -202,8 +203,8 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
         if (value != 0 && (value < 256 || value > 4096 || (value & (value - 1)))) return fail(NWKNN_EINVAL, "capacity must be 0 (auto) or a power of two in [256, 4096]");
         h->opt_capacity = value;
     } else if (!strcmp(name, "first_chunk")) {
-        if (value < 0 || value % NWK_TILE_ROWS) return fail(NWKNN_EINVAL, "first_chunk must be a non-negative multiple of %d", NWK_TILE_ROWS);
-        h->opt_first_chunk = value;
+        if (value < 0) return fail(NWKNN_EINVAL, "first_chunk must be non-negative");
+        h->opt_first_chunk = value;      // base rows (kNN) or docs (MaxSim) of the dense first chunk; rounded up to the tile size
     } else if (!strcmp(name, "max_chunk")) {
         if (value < NWK_TILE_ROWS || value % NWK_TILE_ROWS) return fail(NWKNN_EINVAL, "max_chunk must be a positive multiple of %d", NWK_TILE_ROWS);
         h->opt_max_chunk = value;
@@ -323,7 +324,7 @@ static int set_base_common(nwknn_ctx* h, const void* base, const void* const* co
     h->ev_used = 0;
     if (cols) RCCHK(stage_and_prep_columns(h, columns, dtype, f16, rows, d, rows_pad, dp, h->braw, h->bp.p, h->bn.as<float>()));
     else RCCHK(stage_and_prep(h, base, location, dtype == NWKNN_DTYPE_F16, f16, rows, d, rows_pad, dp, h->braw, h->bp.p, h->bn.as<float>()));
-    h->nb = rows; h->nb_pad = rows_pad; h->d = d; h->dp = dp; h->f16 = f16;
+    h->nb = rows; h->nb_pad = rows_pad; h->d = d; h->dp = dp; h->f16 = f16; h->ms_docs = 0;
     if (h->opt_profile) {
         HIPCHK(hipStreamSynchronize(h->stream));
         double t, c, p;
@@ -486,6 +487,7 @@ static int search_common(nwknn_ctx* h, const void* queries, const void* const* q
 {
     if (!h || (!queries && !qcolumns) || !out_dist || !out_idx) return fail(NWKNN_EINVAL, "nwknn_search: null argument");
     if (!h->bp.p || h->nb <= 0) return fail(NWKNN_ESTATE, "nwknn_search: call nwknn_set_base first");
+    if (h->ms_docs > 0) return fail(NWKNN_ESTATE, "nwknn_search: the handle holds MaxSim documents; call nwknn_set_base for kNN");
     if (nq <= 0) return fail(NWKNN_EINVAL, "nwknn_search: nq=%lld must be positive", (long long)nq);
     if (k <= 0 || k > h->nb) return fail(NWKNN_EINVAL, "nwknn_search: k=%d must satisfy 0 < k <= %lld base rows", k, h->nb);   // cu_knn.py:237
     if (k > 1024) return fail(NWKNN_EINVAL, "nwknn_search: k=%d exceeds the supported maximum 1024", k);
@@ -540,7 +542,7 @@ static int search_common(nwknn_ctx* h, const void* queries, const void* const* q
         RCCHK(h->out_i.ensure((size_t)nq * k * 8));
         od = h->out_d.as<float>(); oi = h->out_i.as<long long>();
     }
-    HIPCHK(nwk_launch_finalize(h->stream, h->buf.as<u64>(), h->cnt.as<u32>(), pl.cap, k, nq, index_offset, od, oi));
+    HIPCHK(nwk_launch_finalize(h->stream, h->buf.as<u64>(), h->cnt.as<u32>(), pl.cap, k, nq, index_offset, od, oi, 0));
     if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_end, h->stream));
     if (out_location == NWKNN_HOST) {
         HIPCHK(hipMemcpyAsync(out_dist, od, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
@@ -570,6 +572,149 @@ extern "C" int nwknn_search_columns(nwknn_handle h, const void* const* columns, 
 {
     if (!columns) return fail(NWKNN_EINVAL, "nwknn_search_columns: null column table");
     return search_common(h, nullptr, columns, nq, dtype, NWKNN_HOST, k, metric, index_offset, out_dist, out_idx, out_location);
+}
+
+// ---- MaxSim late interaction (new: BASELINE config 5; the reference's `ck` is flat token kNN) ----------------
+extern "C" int nwknn_maxsim_set_docs(nwknn_handle h, const void* doc_tokens, int64_t n_docs, int32_t tokens_per_doc, int32_t d, int dtype,
+                                     int location)
+{
+    if (!h || !doc_tokens) return fail(NWKNN_EINVAL, "nwknn_maxsim_set_docs: null argument");
+    if (tokens_per_doc != NWK_MS_TOKENS_PER_DOC) return fail(NWKNN_EINVAL, "nwknn_maxsim_set_docs: tokens_per_doc must be %d", NWK_MS_TOKENS_PER_DOC);
+    if (dtype != NWKNN_DTYPE_F32) return fail(NWKNN_EINVAL, "nwknn_maxsim_set_docs: float32 tokens only");
+    if (n_docs <= 0 || n_docs > (1ll << 25)) return fail(NWKNN_EINVAL, "nwknn_maxsim_set_docs: n_docs out of range");
+    const long long save = h->opt_compute_f16;
+    h->opt_compute_f16 = 0;
+    // 4 docs = 256 token rows per tile: pad the row count to a multiple of 256 by declaring whole (zero) documents
+    const int rc = set_base_common(h, doc_tokens, nullptr, n_docs * tokens_per_doc, d, dtype, location);
+    h->opt_compute_f16 = save;
+    RCCHK(rc);
+    const long long pad = round_up(h->nb, 256);
+    if (pad > h->nb_pad) {      // set_base pads to 128 rows; MaxSim tiles need 256: grow and clear the tail
+        DevBuf nb2, nn2;
+        RCCHK(nb2.ensure((size_t)pad * h->dp * 4)); RCCHK(nn2.ensure((size_t)pad * 4));
+        HIPCHK(hipMemsetAsync(nb2.p, 0, (size_t)pad * h->dp * 4, h->stream));
+        HIPCHK(hipMemcpyAsync(nb2.p, h->bp.p, (size_t)h->nb_pad * h->dp * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemsetAsync(nn2.p, 0, (size_t)pad * 4, h->stream));
+        HIPCHK(hipMemcpyAsync(nn2.p, h->bn.p, (size_t)h->nb_pad * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->bp.release(); h->bn.release();
+        h->bp = nb2; h->bn = nn2;
+        h->nb_pad = pad;
+    }
+    h->ms_docs = n_docs;
+    return NWKNN_OK;
+}
+
+static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq_pad, long long doc_lo, long long docs, bool dense, bool dedupe)
+{
+    NwkTileParams tp;
+    memset(&tp, 0, sizeof tp);
+    tp.qp = h->qp.as<float>(); tp.bp = h->bp.as<float>(); tp.qn = h->qn.as<float>(); tp.bn = h->bn.as<float>();
+    tp.tau = h->tau.as<u64>(); tp.cnt = h->cnt.as<u32>(); tp.buf = h->buf.as<u64>();
+    tp.nb_valid = h->ms_docs; tp.dense_col0 = doc_lo;
+    tp.n_qtiles = (int)(nq_pad / 4); tp.bt0 = (int)(doc_lo / 4); tp.n_btiles = (int)(docs / 4);
+    tp.dp = h->dp; tp.cap = cap; tp.sq_shift = (int)h->opt_sq_shift;
+    EvPair* e = ev_begin(h, 0);
+    HIPCHK(nwk_launch_maxsim(h->stream, tp, dense));
+    ev_end(h, e);
+    h->stats.tile_launches += 1;
+    const long long real_docs = std::max<long long>(0, std::min<long long>(doc_lo + docs, h->ms_docs) - doc_lo);
+    h->stats.tile_flops += 2.0 * (double)nq * NWK_MS_TOKENS_PER_QUERY * (double)real_docs * NWK_MS_TOKENS_PER_DOC * (double)h->d;
+    NwkCompactParams cp;
+    memset(&cp, 0, sizeof cp);
+    cp.buf = h->buf.as<u64>(); cp.cnt = h->cnt.as<u32>(); cp.tau = h->tau.as<u64>(); cp.ovf = h->ovf.as<u32>(); cp.ovf_any = h->ovf_any.as<u32>();
+    cp.cap = cap; cp.k = k; cp.qtile_rows = 4; cp.dense_count = dense ? (int)docs : 0; cp.dedupe = dedupe ? 1 : 0;
+    e = ev_begin(h, 1);
+    HIPCHK(nwk_launch_compact(h->stream, cp, nq_pad));
+    ev_end(h, e);
+    h->stats.compact_launches += 1;
+    return NWKNN_OK;
+}
+
+extern "C" int nwknn_maxsim_search(nwknn_handle h, const void* query_tokens, int64_t n_queries, int32_t tokens_per_query, int dtype, int location,
+                                   int32_t k, int64_t doc_offset, float* out_score, int64_t* out_doc, int out_location)
+{
+    if (!h || !query_tokens || !out_score || !out_doc) return fail(NWKNN_EINVAL, "nwknn_maxsim_search: null argument");
+    if (h->ms_docs <= 0) return fail(NWKNN_ESTATE, "nwknn_maxsim_search: call nwknn_maxsim_set_docs first");
+    if (tokens_per_query != NWK_MS_TOKENS_PER_QUERY) return fail(NWKNN_EINVAL, "nwknn_maxsim_search: tokens_per_query must be %d", NWK_MS_TOKENS_PER_QUERY);
+    if (dtype != NWKNN_DTYPE_F32) return fail(NWKNN_EINVAL, "nwknn_maxsim_search: float32 tokens only");
+    if (n_queries <= 0) return fail(NWKNN_EINVAL, "nwknn_maxsim_search: n_queries must be positive");
+    if (k <= 0 || k > h->ms_docs || k > 1024) return fail(NWKNN_EINVAL, "nwknn_maxsim_search: k=%d must satisfy 0 < k <= min(%lld docs, 1024)", k, h->ms_docs);
+    if ((location != NWKNN_HOST && location != NWKNN_DEVICE) || (out_location != NWKNN_HOST && out_location != NWKNN_DEVICE))
+        return fail(NWKNN_EINVAL, "nwknn_maxsim_search: bad location");
+    RCCHK(use_device(h));
+    long long cap = h->opt_capacity;
+    if (cap == 0) { cap = 1024; while (cap < 4ll * k) cap <<= 1; }
+    if (cap < 2ll * k + 4 || cap > 4096) return fail(NWKNN_EINVAL, "nwknn_maxsim_search: capacity %lld unusable for k=%d", cap, k);
+    const long long nq = n_queries, nq_pad = round_up(nq, 8);               // 8 queries = 256 query-token rows (NWK_QPAD_ROWS)
+    const long long qrows = nq * NWK_MS_TOKENS_PER_QUERY, qrows_pad = nq_pad * NWK_MS_TOKENS_PER_QUERY;
+    RCCHK(h->qp.ensure((size_t)qrows_pad * h->dp * 4));
+    RCCHK(h->qn.ensure((size_t)qrows_pad * 4));
+    RCCHK(h->tau.ensure((size_t)nq_pad * 8)); RCCHK(h->cnt.ensure((size_t)nq_pad * 4)); RCCHK(h->ovf.ensure((size_t)nq_pad * 4));
+    RCCHK(h->ovf_any.ensure(16));
+    RCCHK(h->buf.ensure((size_t)nq_pad * cap * 8));
+    memset(&h->stats, 0, sizeof h->stats);
+    h->stats.nq = nq; h->stats.nb = h->ms_docs; h->stats.d = h->d; h->stats.k = k;
+    h->ev_used = 0;
+    if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_begin, h->stream));
+    RCCHK(stage_and_prep(h, query_tokens, location, 0, 0, qrows, h->d, qrows_pad, h->dp, h->qraw, h->qp.p, h->qn.as<float>()));
+    HIPCHK(hipMemsetAsync(h->tau.p, 0xFF, (size_t)nq_pad * 8, h->stream));
+    HIPCHK(hipMemsetAsync(h->cnt.p, 0, (size_t)nq_pad * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->ovf.p, 0, (size_t)nq_pad * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->ovf_any.p, 0, 4, h->stream));
+
+    const long long docs_pad = h->nb_pad / NWK_MS_TOKENS_PER_DOC;           // multiple of 4
+    const long long max_chunk = std::max<long long>(4, (h->opt_max_chunk / NWK_MS_TOKENS_PER_DOC) / 4 * 4);
+    long long first = h->opt_first_chunk ? round_up(h->opt_first_chunk, 4) : cap / 2;
+    first = std::min<long long>(std::max<long long>(first, round_up(k, 4)), cap / 4 * 4);
+    long long seen = std::min(docs_pad, first);
+    RCCHK(maxsim_chunk(h, (int)cap, k, nq, nq_pad, 0, seen, true, false));
+    while (seen < docs_pad) {
+        const long long m = std::min(std::min(max_chunk, seen), docs_pad - seen);
+        RCCHK(maxsim_chunk(h, (int)cap, k, nq, nq_pad, seen, m, false, false));
+        seen += m;
+    }
+    u32 any = 0;
+    HIPCHK(hipMemcpyAsync(&any, h->ovf_any.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (any) {
+        // some list overflowed: walk all docs again in ranges that cannot overflow a compacted list (<= cap-k new entries),
+        // dropping the duplicates the second walk re-finds
+        const long long safe = (cap - k) / 4 * 4;
+        std::vector<u32> flags((size_t)nq_pad);
+        HIPCHK(hipMemcpy(flags.data(), h->ovf.p, (size_t)nq_pad * 4, hipMemcpyDeviceToHost));
+        for (u32 f : flags) h->stats.overflowed_queries += f ? 1 : 0;
+        HIPCHK(hipMemsetAsync(h->ovf.p, 0, (size_t)nq_pad * 4, h->stream));
+        HIPCHK(hipMemsetAsync(h->ovf_any.p, 0, 4, h->stream));
+        for (long long lo = 0; lo < docs_pad; lo += safe) {
+            RCCHK(maxsim_chunk(h, (int)cap, k, nq, nq_pad, lo, std::min(safe, docs_pad - lo), false, true));
+            h->stats.rescan_launches += 1;
+        }
+        HIPCHK(hipMemcpyAsync(&any, h->ovf_any.p, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (any) return fail(NWKNN_EHIP, "internal: MaxSim list overflow on a safe range");
+    }
+    float* od = out_score;
+    long long* oi = (long long*)out_doc;
+    if (out_location == NWKNN_HOST) {
+        RCCHK(h->out_d.ensure((size_t)nq * k * 4)); RCCHK(h->out_i.ensure((size_t)nq * k * 8));
+        od = h->out_d.as<float>(); oi = h->out_i.as<long long>();
+    }
+    HIPCHK(nwk_launch_finalize(h->stream, h->buf.as<u64>(), h->cnt.as<u32>(), (int)cap, k, nq, doc_offset, od, oi, 1));
+    if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_end, h->stream));
+    if (out_location == NWKNN_HOST) {
+        HIPCHK(hipMemcpyAsync(out_score, od, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(out_doc, oi, (size_t)nq * k * 8, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->opt_profile) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev_begin, h->ev_end));
+        h->stats.total_ms = ms;
+        ev_collect(h, &h->stats.tile_ms, &h->stats.compact_ms, &h->stats.prep_ms);
+        h->stats.prep_ms += h->base_prep_ms; h->base_prep_ms = 0.0;
+    }
+    return NWKNN_OK;
 }
 
 // ---- merge ------------------------------------------------------------------------------------------

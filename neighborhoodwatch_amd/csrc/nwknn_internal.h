@@ -58,6 +58,9 @@ hipError_t nwk_launch_prep(hipStream_t st, const float* raw, long long rows, int
 hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool dense, int tile_rows, int diag);
 hipError_t nwk_launch_compact(hipStream_t st, const NwkCompactParams& p, long long n_queries);
 hipError_t nwk_launch_finalize(hipStream_t st, const unsigned long long* buf, const unsigned int* cnt, int cap, int k, long long nq,
-                               long long index_offset, float* out_d, long long* out_i);
+                               long long index_offset, float* out_d, long long* out_i, int negate);
+hipError_t nwk_launch_maxsim(hipStream_t st, NwkTileParams p, bool dense);
+#define NWK_MS_TOKENS_PER_DOC 64
+#define NWK_MS_TOKENS_PER_QUERY 32
 hipError_t nwk_launch_merge(hipStream_t st, const float* dists, const long long* idx, int n_lists, long long nq, int k_in, int k_out,
                             float* out_d, long long* out_i);

@@ -724,6 +724,151 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16(const NwkTileParam
 }
 
 // ------------------------------------------------------------------------------------------------
+// MaxSim late interaction (BASELINE config 5; NOT in the reference -- its `ck` is flat token-level kNN):
+//     score(query, doc) = sum over the query's TQK tokens of  max over the doc's TDK tokens of  (q_token . d_token)
+// and the k docs with the highest score per query.  One workgroup multiplies 256 doc-token rows (4 docs of 64 tokens)
+// by 128 query-token columns (4 queries of 32 tokens) with the same LDS/DMA/MFMA loop as the kNN tile (d = 128 is
+// 8 slabs of 16).  Orientation matters: doc tokens sit on the accumulator ROWS (registers), query tokens on the lanes,
+// so the max over a doc's 64 tokens is 31 in-lane v_max + one cross-half exchange, and only the final sum over the 32
+// query tokens crosses lanes (5 butterfly steps per (doc, query) pair; the transposed orientation needs 80 per pair).
+// Each wave yields 2 docs x 2 queries = 4 scores per tile.  Scores are ranked through the same 64-bit keys as distances
+// (key = sortable(-score) << 32 | doc), so list filtering, compaction and repair are shared with the kNN path.
+// Canonical arithmetic: dot = ascending-k fmaf chain (fp32 MFMA), max exact, token sum = balanced pairwise tree in
+// natural token order (what the xor-1,2,4,8,16 butterfly computes) -- restated by oracle nwo_maxsim, bit for bit.
+// ------------------------------------------------------------------------------------------------
+#define MS_TDK 64                  // tokens per doc
+#define MS_TQK 32                  // tokens per query
+#define MS_DOCS_PER_TILE 4
+#define MS_QUERIES_PER_TILE 4
+
+template <bool DENSE>
+__global__ __launch_bounds__(256, 2) void nwk_maxsim_kernel(const NwkTileParams p)
+{
+    constexpr int TM = 256, BKT = 16;
+    constexpr int MT = TM / 64, ROWB = BKT * 4, CH = BKT / 4, RSH = 2;
+    constexpr int A_BYTES = TM * ROWB, B_BYTES = TB * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int RPI = 1024 / ROWB, IA = TM / RPI / 4, IB = TB / RPI / 4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const TileCoord tc = tile_from_block(p);         // tc.qt: group of 4 queries, tc.bt: tile of 4 docs
+    if (!tc.ok) return;
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, l = tid & 63;
+    const int wr = w >> 1, wc = w & 1;
+    const int h = l >> 5, c32 = l & 31;
+    const long long drow0 = (long long)tc.bt * TM;   // first doc-token row of the tile   (A operand, from p.bp)
+    const long long qrow0 = (long long)tc.qt * TB;   // first query-token row of the tile (B operand, from p.qp)
+    const int dp = p.dp;
+    const int nk = dp / BKT;
+
+    unsigned voffA[4], voffB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = (w * IA + i) * RPI + (l / CH), rb = (w * IB + i) * RPI + (l / CH);
+        voffA[i] = (unsigned)(ra * dp + (((l % CH) ^ ((ra >> RSH) & (CH - 1))) << 2)) * 4u;
+        voffB[i] = (unsigned)(rb * dp + (((l % CH) ^ ((rb >> RSH) & (CH - 1))) << 2)) * 4u;
+    }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bp + drow0 * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.qp + qrow0 * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const int ldsA = __builtin_amdgcn_readfirstlane(w * IA * 1024);
+    const int ldsB = __builtin_amdgcn_readfirstlane(A_BYTES + w * IB * 1024);
+    auto issue_stage = [&](int stage, int kt) {
+        char* base = smem + stage * STAGE;
+        const int soff = kt * ROWB;
+#pragma unroll
+        for (int i = 0; i < IA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(base + ldsA + i * 1024), 16, voffA[i], soff, 0, 0);
+#pragma unroll
+        for (int i = 0; i < IB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(base + ldsB + i * 1024), 16, voffB[i], soff, 0, 0);
+    };
+
+    int offA[MT], offB[2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int ra = wr * (TM / 2) + m * 32 + c32;
+        offA[m] = ra * ROWB + ((h ^ ((ra >> RSH) & (CH - 1))) << 4);
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int rb = wc * 64 + n * 32 + c32;
+        offB[n] = A_BYTES + rb * ROWB + ((h ^ ((rb >> RSH) & (CH - 1))) << 4);
+    }
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    // thresholds of this wave's two queries (wave-uniform addresses), in flight under the K loop
+    const long long q_first = (long long)tc.qt * MS_QUERIES_PER_TILE + 2 * wc;
+    u64 tauq[2] = {~0ull, ~0ull};
+    if (!DENSE) { tauq[0] = p.tau[q_first]; tauq[1] = p.tau[q_first + 1]; }
+
+    issue_stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            issue_stage(cur ^ 1, kt + 1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const char* sb = smem + cur * STAGE;
+#pragma unroll
+        for (int g = 0; g < BKT / 8; ++g) {
+            f32x4 a[MT], b[2];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[m] = *(const f32x4*)(sb + (offA[m] ^ (g << 5)));
+#pragma unroll
+            for (int n = 0; n < 2; ++n) b[n] = *(const f32x4*)(sb + (offB[n] ^ (g << 5)));
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][t], b[n][t], acc[m][n], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue: 2 docs x 2 queries per wave
+    const int cap = p.cap;
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd) {
+        const long long doc = (long long)tc.bt * MS_DOCS_PER_TILE + 2 * wr + dd;
+        const bool doc_ok = doc < p.nb_valid;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            float v = acc[2 * dd][n][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) v = fmaxf(v, acc[2 * dd][n][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v = fmaxf(v, acc[2 * dd + 1][n][r]);
+            v = fmaxf(v, __shfl_xor(v, 32));                 // the two half-waves hold the other 32 token rows of this doc
+            float sum = v;                                    // lane c32 = query token c32: balanced pairwise tree over tokens
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) sum = __fadd_rn(sum, __shfl_xor(sum, o));
+            const long long q = q_first + n;
+            const u64 key = ((u64)sortable_u32(-sum) << 32) | (u32)doc;
+            if (l == 0) {
+                if (DENSE) {
+                    p.buf[q * cap + (doc - p.dense_col0)] = doc_ok ? key : ~0ull;
+                } else if (doc_ok && key < tauq[n]) {
+                    const u32 pos = atomicAdd(p.cnt + q, 1u);
+                    if (pos < (u32)cap) p.buf[q * cap + pos] = key;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // compaction: sort one query's candidate list, (optionally) drop duplicate keys, keep k, tighten tau
 //   dynamic LDS: [cap] u64 keys | [2][cap] u32 scan buffers | 16 B scratch   (one array: keeps the base 16-B aligned)
 // ------------------------------------------------------------------------------------------------
@@ -811,7 +956,7 @@ __global__ __launch_bounds__(256) void nwk_compact_kernel(const NwkCompactParams
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nwk_finalize_kernel(const u64* __restrict__ buf, const u32* __restrict__ cnt, int cap, int k,
                                                             long long nq, long long index_offset, float* __restrict__ out_d,
-                                                            long long* __restrict__ out_i)
+                                                            long long* __restrict__ out_i, int negate)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= nq * k) return;
@@ -819,10 +964,11 @@ __global__ __launch_bounds__(256) void nwk_finalize_kernel(const u64* __restrict
     const int j = (int)(i - q * k);
     if ((u32)j < cnt[q]) {
         const u64 key = buf[q * cap + j];
-        out_d[i] = unsortable_f32((u32)(key >> 32));
+        const float v = unsortable_f32((u32)(key >> 32));
+        out_d[i] = negate ? -v : v;                          // MaxSim ranks -score
         out_i[i] = (long long)(u32)key + index_offset;
     } else {
-        out_d[i] = __builtin_inff();
+        out_d[i] = negate ? -__builtin_inff() : __builtin_inff();
         out_i[i] = -1;
     }
 }
@@ -1012,6 +1158,23 @@ hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool
     }
 }
 
+// MaxSim: p.n_qtiles counts groups of 4 queries (128 query-token rows), p.n_btiles tiles of 4 docs (256 doc-token rows)
+hipError_t nwk_launch_maxsim(hipStream_t st, NwkTileParams p, bool dense)
+{
+    if (p.n_qtiles <= 0 || p.n_btiles <= 0) return hipSuccess;
+    if (p.sq_shift < 0 || p.sq_shift > 6) return hipErrorInvalidValue;
+    const int SQ = 1 << p.sq_shift, SB = 64 >> p.sq_shift;
+    const long long n_super_q = (p.n_qtiles + SQ - 1) / SQ;
+    p.n_super_b = (p.n_btiles + SB - 1) / SB;
+    long long supers = n_super_q * p.n_super_b;
+    supers = (supers + 7) / 8 * 8;
+    const long long grid = supers * 64;
+    if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    if (dense) hipLaunchKernelGGL((nwk_maxsim_kernel<true>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((nwk_maxsim_kernel<false>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
 hipError_t nwk_launch_compact(hipStream_t st, const NwkCompactParams& p, long long n_queries)
 {
     if (n_queries <= 0) return hipSuccess;
@@ -1021,12 +1184,12 @@ hipError_t nwk_launch_compact(hipStream_t st, const NwkCompactParams& p, long lo
 }
 
 hipError_t nwk_launch_finalize(hipStream_t st, const u64* buf, const u32* cnt, int cap, int k, long long nq, long long index_offset,
-                               float* out_d, long long* out_i)
+                               float* out_d, long long* out_i, int negate)
 {
     const long long total = nq * k;
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(nwk_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, buf, cnt, cap, k, nq, index_offset,
-                       out_d, out_i);
+                       out_d, out_i, negate);
     return hipGetLastError();
 }
 

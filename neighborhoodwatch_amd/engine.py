@@ -214,6 +214,55 @@ class KnnEngine:
                                   ctypes.c_void_p(od.ctypes.data), ctypes.c_void_p(oi.ctypes.data), HOST), "nwknn_merge")
         return od, oi
 
+    # -- MaxSim late interaction (extension; not in the reference) -------------------------------------------
+    def maxsim_set_docs(self, doc_tokens) -> None:
+        """doc_tokens: [n_docs, 64, d] float32 (numpy or torch CUDA)."""
+        if _is_torch(doc_tokens):
+            import torch
+            t = doc_tokens.to(torch.float32).contiguous()
+            if t.dim() != 3:
+                raise ValueError("doc_tokens must be [n_docs, tokens, d]")
+            loc, ptr, shape, keep = (DEVICE if t.is_cuda else HOST), t.data_ptr(), tuple(t.shape), t
+            if t.is_cuda:
+                torch.cuda.current_stream(t.device).synchronize()
+        else:
+            a = np.ascontiguousarray(doc_tokens, dtype=np.float32)
+            if a.ndim != 3:
+                raise ValueError("doc_tokens must be [n_docs, tokens, d]")
+            loc, ptr, shape, keep = HOST, a.ctypes.data, a.shape, a
+        check(self._L.nwknn_maxsim_set_docs(self._h, ctypes.c_void_p(ptr), shape[0], shape[1], shape[2], DTYPE_F32, loc), "nwknn_maxsim_set_docs")
+        if loc == DEVICE:
+            self.synchronize()
+        self.rows, self.dim, self.docs = shape[0] * shape[1], shape[2], shape[0]
+        del keep
+
+    def maxsim_search(self, query_tokens, k: int, doc_offset: int = 0):
+        """query_tokens: [n_queries, 32, d] float32 -> (scores float32 [q,k] descending, doc ids int64 [q,k])."""
+        dev = _is_torch(query_tokens) and query_tokens.is_cuda
+        if _is_torch(query_tokens):
+            import torch
+            t = query_tokens.to(torch.float32).contiguous()
+            shape, ptr, keep, loc = tuple(t.shape), t.data_ptr(), t, (DEVICE if t.is_cuda else HOST)
+        else:
+            a = np.ascontiguousarray(query_tokens, dtype=np.float32)
+            shape, ptr, keep, loc = a.shape, a.ctypes.data, a, HOST
+        if len(shape) != 3 or shape[2] != self.dim:
+            raise ValueError(f"query_tokens must be [n_queries, tokens, {self.dim}]")
+        nq = shape[0]
+        if dev:
+            import torch
+            os_ = torch.empty((nq, k), dtype=torch.float32, device=keep.device)
+            od = torch.empty((nq, k), dtype=torch.int64, device=keep.device)
+            torch.cuda.current_stream(keep.device).synchronize()
+            ps, pd_, oloc = os_.data_ptr(), od.data_ptr(), DEVICE
+        else:
+            os_ = np.empty((nq, k), dtype=np.float32); od = np.empty((nq, k), dtype=np.int64)
+            ps, pd_, oloc = os_.ctypes.data, od.ctypes.data, HOST
+        check(self._L.nwknn_maxsim_search(self._h, ctypes.c_void_p(ptr), nq, shape[1], DTYPE_F32, loc, int(k), int(doc_offset),
+                                          ctypes.c_void_p(ps), ctypes.c_void_p(pd_), oloc), "nwknn_maxsim_search")
+        del keep
+        return os_, od
+
     def generate(self, seed: int, row0: int, rows: int, dim: int, dtype: str = "f32"):
         """Seeded synthetic rows straight into HBM (torch CUDA tensor [rows, dim], float32 or float16)."""
         import torch

@@ -64,6 +64,8 @@ def lib() -> ctypes.CDLL:
         L.nwo_merge.argtypes = [f32p, i64p, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                 f32p, i64p]
         L.nwo_merge.restype = ctypes.c_int
+        L.nwo_maxsim.argtypes = [f32p, ctypes.c_int64, ctypes.c_int32, f32p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, f32p, i64p]
+        L.nwo_maxsim.restype = ctypes.c_int
         L.nwo_distance.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float]
         L.nwo_distance.restype = ctypes.c_float
         L.nwo_sortable_u32.argtypes = [ctypes.c_float]
@@ -231,6 +233,31 @@ def merge_partials(dists, idx, k: int):
     if rc != 0:
         raise RuntimeError(f"oracle merge failed rc={rc}")
     return od, oi
+
+
+def maxsim_canonical(doc_tokens, query_tokens, k: int):
+    """MaxSim under the engine's canonical arithmetic (see nwo_maxsim): (scores f32 [q,k] descending, doc ids i64 [q,k])."""
+    dt = np.ascontiguousarray(doc_tokens, dtype=np.float32); qt = np.ascontiguousarray(query_tokens, dtype=np.float32)
+    nd, td, d = dt.shape; nq, tq, d2 = qt.shape
+    assert d == d2
+    os_ = np.empty((nq, k), dtype=np.float32); od = np.empty((nq, k), dtype=np.int64)
+    rc = lib().nwo_maxsim(_fp(dt), nd, td, _fp(qt), nq, tq, d, k, _fp(os_), _ip(od))
+    if rc != 0:
+        raise RuntimeError(f"oracle maxsim failed rc={rc}")
+    return os_, od
+
+
+def maxsim_exact_fp64(doc_tokens, query_tokens, k: int):
+    """float64 MaxSim, ranked by (-score, doc id): the independent truth."""
+    dt = np.asarray(doc_tokens, dtype=np.float64); qt = np.asarray(query_tokens, dtype=np.float64)
+    nd, td, d = dt.shape
+    scores = np.empty((qt.shape[0], nd))
+    flat = dt.reshape(nd * td, d)
+    for q in range(qt.shape[0]):
+        sim = (qt[q] @ flat.T).reshape(qt.shape[1], nd, td)       # [tq, nd, td]
+        scores[q] = sim.max(axis=2).sum(axis=0)
+    order = np.lexsort((np.broadcast_to(np.arange(nd), scores.shape), -scores), axis=1)[:, :k]
+    return np.take_along_axis(scores, order, axis=1), order.astype(np.int64)
 
 
 def merge_partials_numpy_fold(dists, idx, k: int):

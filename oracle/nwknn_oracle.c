@@ -322,3 +322,49 @@ int nwo_merge(const float* dists, const int64_t* idx, int32_t n_lists, int64_t n
     }
     return 0;
 }
+
+/* ---- MaxSim late interaction (BASELINE config 5).  Not in the reference (its `ck` is flat token kNN, colbert_knn.py:84-126);
+ *      this restates the ENGINE's canonical arithmetic so the HIP kernel can be checked bit for bit:
+ *        dot(q_i, d_j)   = ascending-k fmaf chain
+ *        m_i             = max_j dot(q_i, d_j)
+ *        score           = balanced pairwise tree sum of m_0..m_{tq-1} in natural order (tq a power of two)
+ *      ranked by (-score, doc id).  docs: [nd][td][d], queries: [nq][tq][d]. --------------------------------------- */
+int nwo_maxsim(const float* docs, int64_t nd, int32_t td, const float* queries, int64_t nq, int32_t tq, int32_t d, int32_t k,
+               float* out_score, int64_t* out_doc)
+{
+    if (!docs || !queries || !out_score || !out_doc || k <= 0 || k > nd || tq <= 0 || (tq & (tq - 1)) || tq > 64 || nd >= (1ll << 32)) return -1;
+#pragma omp parallel
+    {
+        uint64_t* keys = (uint64_t*)malloc((size_t)k * sizeof(uint64_t));
+        float m[64];
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t q = 0; q < nq; ++q) {
+            nwo_heap h = { keys, 0, k };
+            for (int64_t doc = 0; doc < nd; ++doc) {
+                for (int32_t i = 0; i < tq; ++i) {
+                    const float* qv = queries + ((size_t)q * tq + i) * d;
+                    float best = -INFINITY;
+                    for (int32_t j = 0; j < td; ++j) {
+                        const float dot = nwo_dot_chain(qv, docs + ((size_t)doc * td + j) * d, d);
+                        best = fmaxf(best, dot);
+                    }
+                    m[i] = best;
+                }
+                for (int32_t step = 1; step < tq; step <<= 1)          /* butterfly: every element ends up holding the tree sum */
+                    for (int32_t i = 0; i < tq; i += 2 * step)
+                        for (int32_t t = 0; t < step; ++t) {
+                            const float a = m[i + t] + m[i + t + step];
+                            m[i + t] = a; m[i + t + step] = a;
+                        }
+                nwo_heap_push(&h, ((uint64_t)nwo_sortable(-m[0]) << 32) | (uint64_t)doc);
+            }
+            qsort(h.key, (size_t)h.n, sizeof(uint64_t), nwo_cmp_u64);
+            for (int32_t j = 0; j < k; ++j) {
+                out_score[q * k + j] = -nwo_unsortable((uint32_t)(h.key[j] >> 32));
+                out_doc[q * k + j] = (int64_t)(uint32_t)h.key[j];
+            }
+        }
+        free(keys);
+    }
+    return 0;
+}

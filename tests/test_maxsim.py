@@ -1,0 +1,57 @@
+"""MaxSim late interaction (BASELINE config 5).  The reference has no MaxSim (its `ck` is flat token kNN), so there is no
+reference parity to claim: the HIP kernel is checked bit for bit against the oracle's restatement of the engine's canonical
+arithmetic, and the oracle against a float64 evaluation of the textbook formula."""
+import numpy as np
+import pytest
+
+
+def _tokens(oracle, seed, n, t, d):
+    return oracle.gen(seed, 0, n * t, d).reshape(n, t, d)
+
+
+def test_oracle_maxsim_matches_float64_formula(oracle):
+    docs, qs = _tokens(oracle, 0xC1, 300, 64, 128), _tokens(oracle, 0xC2, 7, 32, 128)
+    s, i = oracle.maxsim_canonical(docs, qs, 20)
+    es, ei = oracle.maxsim_exact_fp64(docs, qs, 20)
+    assert np.abs(s - es).max() <= 1e-5 * np.abs(es).max()
+    assert (i == ei).mean() > 0.98 and (np.diff(s, axis=1) <= 0).all()
+    for q in range(len(qs)):                                   # every reported doc's fp64 score is within tolerance of the true rank's
+        true = (qs[q].astype(np.float64) @ docs[i[q]].astype(np.float64).reshape(-1, 128).T).reshape(32, 20, 64).max(2).sum(0)
+        assert np.abs(true - es[q]).max() <= 2e-5 * np.abs(es).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(300, 7, 20), (1030, 33, 100), (5000, 9, 1000), (4100, 130, 10)])
+def test_hip_maxsim_matches_oracle_bit_exact(oracle, shape):
+    from neighborhoodwatch_amd import KnnEngine
+    nd, nq, k = shape
+    docs, qs = _tokens(oracle, 0xC3 + nd, nd, 64, 128), _tokens(oracle, 0xC4 + nq, nq, 32, 128)
+    with KnnEngine(0) as eng:
+        eng.maxsim_set_docs(docs)
+        s, i = eng.maxsim_search(qs, k)
+    rs, ri = oracle.maxsim_canonical(docs, qs, k)
+    assert np.array_equal(i, ri)
+    assert np.array_equal(s.view(np.uint32), rs.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_hip_maxsim_overflow_repair_and_offsets(oracle):
+    """Docs arrive in increasing-score order so every doc beats the running threshold: lists overflow and are repaired."""
+    from neighborhoodwatch_amd import KnnEngine
+    rng = np.random.default_rng(3)
+    q = rng.standard_normal((9, 32, 128)).astype(np.float32)
+    base = rng.standard_normal((2500, 64, 128)).astype(np.float32)
+    docs = base * np.linspace(0.05, 3.0, 2500, dtype=np.float32)[:, None, None]     # later docs score higher for every query
+    with KnnEngine(0) as eng:
+        eng.set_option("capacity", 256)
+        eng.set_option("first_chunk", 64)
+        eng.maxsim_set_docs(docs)
+        s, i = eng.maxsim_search(q, 20, doc_offset=7_000_000_000)
+        st = eng.stats()
+        with pytest.raises(ValueError):
+            eng.maxsim_search(q, 2501)
+        with pytest.raises(ValueError):
+            eng.maxsim_search(q[:, :16], 5)                   # 16 tokens per query: unsupported
+    rs, ri = oracle.maxsim_canonical(docs, q, 20)
+    assert np.array_equal(i, ri + 7_000_000_000) and np.array_equal(s.view(np.uint32), rs.view(np.uint32))
+    assert st["overflowed_queries"] > 0 and st["rescan_launches"] > 0
