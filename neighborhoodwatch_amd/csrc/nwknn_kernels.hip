@@ -1124,7 +1124,6 @@ hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool den
 template <int METRIC>
 static hipError_t launch_tile_f16_metric(hipStream_t st, const NwkTileParams& p, bool dense, unsigned grid, int diag)
 {
-
     if (dense) { hipLaunchKernelGGL((nwk_tile_kernel_f16<METRIC, true, 0>), dim3(grid), dim3(512), 0, st, p); return hipGetLastError(); }
     switch (diag) {              // dev-only timing ablations (wrong results by construction)
     case 1: hipLaunchKernelGGL((nwk_tile_kernel_f16<METRIC, false, 1>), dim3(grid), dim3(512), 0, st, p); break;
