@@ -195,20 +195,46 @@ class KnnEngine:
         del keep
         return od, oi
 
+    MERGE_MAX_ENTRIES = 4096        # nwknn_merge sorts at most this many (list, rank) entries per query in LDS
+
     def merge(self, dists, idx, k: int):
-        """dists/idx: [n_lists, Q, k_in] -> top-k by (distance, index), [Q, k] (merge.py:56-101 on the GPU)."""
-        if _is_torch(dists):
+        """dists/idx: [n_lists, Q, k_in] -> top-k by (distance, index), [Q, k] (merge.py:56-101 on the GPU).  More than
+        4096 entries per query (e.g. 8 shards x k=1000) are folded in groups, which gives the same result."""
+        torch_in = _is_torch(dists)
+        if torch_in:
             import torch
             d = dists.contiguous().to(torch.float32); i = idx.contiguous().to(torch.int64)
+        else:
+            d = np.ascontiguousarray(dists, dtype=np.float32); i = np.ascontiguousarray(idx, dtype=np.int64)
+        while True:
             n, q, kin = d.shape
+            group = max(1, self.MERGE_MAX_ENTRIES // kin)
+            if n <= group:
+                return self._merge_once(d, i, int(k))
+            keep = min(kin, int(k))
+            parts = [self._merge_once(d[g0:g0 + group], i[g0:g0 + group], keep) for g0 in range(0, n, group)]
+            if torch_in:
+                import torch
+                d = torch.stack([p[0] for p in parts]); i = torch.stack([p[1] for p in parts])
+            else:
+                d = np.stack([p[0] for p in parts]); i = np.stack([p[1] for p in parts])
+
+    def _merge_once(self, d, i, k: int):
+        n, q, kin = d.shape
+        if n * kin > self.MERGE_MAX_ENTRIES:
+            raise ValueError(f"k_in={kin} alone exceeds the {self.MERGE_MAX_ENTRIES}-entry merge limit")
+        if _is_torch(d):
+            import torch
+            d = d.contiguous(); i = i.contiguous()
             od = torch.empty((q, k), dtype=torch.float32, device=d.device)
             oi = torch.empty((q, k), dtype=torch.int64, device=d.device)
-            torch.cuda.current_stream(d.device).synchronize()
+            loc = DEVICE if d.is_cuda else HOST
+            if d.is_cuda:
+                torch.cuda.current_stream(d.device).synchronize()
             check(self._L.nwknn_merge(self._h, ctypes.c_void_p(d.data_ptr()), ctypes.c_void_p(i.data_ptr()), n, q, kin, int(k),
-                                      ctypes.c_void_p(od.data_ptr()), ctypes.c_void_p(oi.data_ptr()), DEVICE), "nwknn_merge")
+                                      ctypes.c_void_p(od.data_ptr()), ctypes.c_void_p(oi.data_ptr()), loc), "nwknn_merge")
             return od, oi
-        d = np.ascontiguousarray(dists, dtype=np.float32); i = np.ascontiguousarray(idx, dtype=np.int64)
-        n, q, kin = d.shape
+        d = np.ascontiguousarray(d); i = np.ascontiguousarray(i)
         od = np.empty((q, k), dtype=np.float32); oi = np.empty((q, k), dtype=np.int64)
         check(self._L.nwknn_merge(self._h, ctypes.c_void_p(d.ctypes.data), ctypes.c_void_p(i.ctypes.data), n, q, kin, int(k),
                                   ctypes.c_void_p(od.ctypes.data), ctypes.c_void_p(oi.ctypes.data), HOST), "nwknn_merge")

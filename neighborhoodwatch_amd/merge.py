@@ -31,7 +31,6 @@ from .engine import default_engine
 from .nw_utils import get_partial_distances_filename, get_partial_indices_filename
 
 MERGE_QUERY_BATCH = 10_000_000       # merge.py:46
-MAX_LISTS_PER_PASS = 4096            # nwknn_merge sorts n_lists*k_in <= 4096 entries per query
 
 
 def get_file_count(data_dir):
@@ -51,23 +50,10 @@ def _matrix(table, dtype) -> np.ndarray:
 
 
 def merge_partial_arrays(dists, idx, k: int, device: int = 0):
-    """dists f32 [n,Q,k_in], idx i64 [n,Q,k_in] -> ([Q,k], [Q,k]) on the GPU, folding in groups when n*k_in > 4096."""
-    eng = default_engine(device)
-    d = np.ascontiguousarray(dists, dtype=np.float32)
-    i = np.ascontiguousarray(idx, dtype=np.int64)
-    while True:
-        n, q, kin = d.shape
-        group = max(1, MAX_LISTS_PER_PASS // kin)
-        if n <= group:
-            kk = k if n * kin >= k else n * kin
-            od, oi = eng.merge(d, i, kk)
-            return od, oi
-        keep = min(kin, k)
-        parts_d, parts_i = [], []
-        for g0 in range(0, n, group):
-            od, oi = eng.merge(d[g0:g0 + group], i[g0:g0 + group], keep)
-            parts_d.append(od); parts_i.append(oi)
-        d, i = np.stack(parts_d), np.stack(parts_i)
+    """dists f32 [n,Q,k_in], idx i64 [n,Q,k_in] -> ([Q,k], [Q,k]) on the GPU (KnnEngine.merge folds in groups when
+    n*k_in exceeds what one LDS sort holds)."""
+    n, q, kin = np.shape(dists)
+    return default_engine(device).merge(dists, idx, min(k, n * kin))
 
 
 def merge_indices_and_distances(data_dir, k=100, *, device: int = 0):

@@ -267,3 +267,16 @@ def test_column_major_input_equals_row_major(engine, oracle):
     assert np.array_equal(i, ri) and _same_bits(d, rd)
     with pytest.raises(ValueError):
         engine.set_base_columns([base[:, 0], base[:10, 1]])
+
+
+def test_merge_folds_more_than_4096_entries(engine, oracle):
+    """8 shards x k=1000 (BASELINE config 5 on 8 GPUs) exceeds one LDS sort: folded in groups, same result; torch and numpy."""
+    import torch
+    rng = np.random.default_rng(12)
+    d = np.sort(rng.random((8, 37, 1000)).astype(np.float32), axis=2)
+    i = rng.integers(0, 10 ** 9, size=(8, 37, 1000)).astype(np.int64)
+    rd, ri = oracle.merge_partials(d, i, 1000)
+    md, mi = engine.merge(d, i, 1000)
+    assert np.array_equal(mi, ri) and _same_bits(md, rd)
+    td_, ti_ = engine.merge(torch.from_numpy(d).cuda(), torch.from_numpy(i).cuda(), 1000)
+    assert np.array_equal(ti_.cpu().numpy(), ri) and _same_bits(td_.cpu().numpy(), rd)
