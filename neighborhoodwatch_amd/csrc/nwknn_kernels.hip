@@ -129,6 +129,100 @@ __global__ __launch_bounds__(256) void nwk_prep_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// prep, tiled form (the default for row-major input): a lane-per-row kernel touches 64 different rows per load
+// instruction, 16 B from each, i.e. four requests per 64-B granule (2 TB/s on fp32, 0.9 TB/s on fp16).  Here a block owns
+// 256 rows and walks K in 64-byte steps: every global load and store instruction moves whole 64-B row segments (four lanes
+// per row), the row <-> lane transposition goes through LDS (80-B row pitch: conflict-free for ds_read/write_b128), and the
+// lane that owns a row still runs the norm chain in ascending k, so the results are bit-identical to nwk_prep_kernel.
+// TIN = float | _Float16; OUT16 selects the fp16 layout.  Requires a 16-B aligned source and d*sizeof(TIN) % 16 == 0.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename TIN, bool OUT16>
+__global__ __launch_bounds__(256) void nwk_prep_tiled_kernel(const TIN* __restrict__ raw, long long rows, int d, long long rows_pad, int dp,
+                                                              void* __restrict__ prepared, float* __restrict__ norms)
+{
+    constexpr int EIN = 16 / (int)sizeof(TIN);            // elements per 16-B piece of input
+    constexpr int KS = 4 * EIN;                           // elements per step (64 B of input per row)
+    constexpr int OES = OUT16 ? 2 : 4;                    // output element size
+    constexpr int OB = KS * OES;                          // output bytes per row per step: 64 (f32->f32, f16->f16) or 32 (f32->f16)
+    constexpr int OP = OB / 16;                           // 16-B output pieces per row per step
+    constexpr int PITCH = 80;
+    __shared__ __attribute__((aligned(16))) char tile_in[256 * PITCH];
+    __shared__ __attribute__((aligned(16))) char tile_out[256 * PITCH];
+
+    const int tid = threadIdx.x;
+    const long long r0 = (long long)blockIdx.x * 256;
+    const size_t in_row_bytes = (size_t)d * sizeof(TIN);
+    const size_t out_row_bytes = (size_t)dp * OES;
+    float acc = 0.0f;
+
+    for (int k0 = 0; k0 < dp; k0 += KS) {
+        // load: 4 lanes per row, 64 rows per pass
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 64 + (tid >> 2), seg = tid & 3;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (r0 + row < rows && k0 + seg * EIN < d)
+                v = *(const u32x4*)((const char*)raw + (size_t)(r0 + row) * in_row_bytes + (size_t)k0 * sizeof(TIN) + seg * 16);
+            *(u32x4*)(tile_in + row * PITCH + seg * 16) = v;
+        }
+        __syncthreads();
+        // the lane that owns row `tid`: ascending-k norm chain + output layout for this step
+        {
+            float x[KS];
+#pragma unroll
+            for (int piece = 0; piece < 4; ++piece) {
+                const u32x4 v = *(const u32x4*)(tile_in + tid * PITCH + piece * 16);
+                if (sizeof(TIN) == 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[piece * EIN + j] = __uint_as_float(v[j]);
+                } else {
+                    const f16x8 hv = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[piece * EIN + j] = (float)hv[j];
+                }
+            }
+            if (OUT16) {
+                _Float16 hx[KS];
+#pragma unroll
+                for (int j = 0; j < KS; ++j) {
+                    hx[j] = (_Float16)x[j];
+                    const float xf = (float)hx[j];
+                    acc = __fmaf_rn(xf, xf, acc);
+                }
+#pragma unroll
+                for (int piece = 0; piece < OP; ++piece) {
+                    f16x8 hv;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) hv[j] = hx[piece * 8 + j];
+                    *(f16x8*)(tile_out + tid * PITCH + piece * 16) = hv;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < KS; ++j) acc = __fmaf_rn(x[j], x[j], acc);
+#pragma unroll
+                for (int g = 0; g < KS / 8; ++g) {            // [0 2 4 6 | 1 3 5 7] inside every group of 8
+                    *(f32x4*)(tile_out + tid * PITCH + g * 32) = (f32x4){x[8 * g], x[8 * g + 2], x[8 * g + 4], x[8 * g + 6]};
+                    *(f32x4*)(tile_out + tid * PITCH + g * 32 + 16) = (f32x4){x[8 * g + 1], x[8 * g + 3], x[8 * g + 5], x[8 * g + 7]};
+                }
+            }
+        }
+        __syncthreads();
+        // store: OP lanes per row
+#pragma unroll
+        for (int pass = 0; pass < OP; ++pass) {
+            const int idx = pass * 256 + tid;
+            const int row = idx / OP, seg = idx % OP;
+            if (r0 + row < rows_pad)
+                *(u32x4*)((char*)prepared + (size_t)(r0 + row) * out_row_bytes + (size_t)k0 * OES + seg * 16) =
+                    *(const u32x4*)(tile_out + row * PITCH + seg * 16);
+        }
+    }
+    if (r0 + tid < rows_pad) norms[r0 + tid] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
 // prep from an arbitrary strided source: element (r, k) at raw[r*rs + k*ks].  Used for COLUMN-major input (rs = 1,
 // ks = rows of the staged slab): parquet stores one column per dimension (generate_dataset.py:219-262) and the reference
 // pays a device transpose per tile for it (cu_knn.py:211,235).  One lane owns one row, so for every k a wave reads 64
@@ -1048,6 +1142,13 @@ hipError_t nwk_launch_prep_f16(hipStream_t st, const void* raw, int raw_is_f16, 
 {
     if (rows_pad <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((rows_pad + 255) / 256);
+    if ((((uintptr_t)raw) & 15) == 0 && (raw_is_f16 ? (d % 8 == 0) : (d % 4 == 0))) {          // tiled fast path
+        if (raw_is_f16)
+            hipLaunchKernelGGL((nwk_prep_tiled_kernel<_Float16, true>), dim3(blocks), dim3(256), 0, st, (const _Float16*)raw, rows, d, rows_pad, dp, prepared, norms);
+        else
+            hipLaunchKernelGGL((nwk_prep_tiled_kernel<float, true>), dim3(blocks), dim3(256), 0, st, (const float*)raw, rows, d, rows_pad, dp, prepared, norms);
+        return hipGetLastError();
+    }
     if (raw_is_f16)
         hipLaunchKernelGGL((nwk_prep_f16_kernel<_Float16>), dim3(blocks), dim3(256), 0, st, (const _Float16*)raw, rows, d, rows_pad, dp, (_Float16*)prepared, norms);
     else
@@ -1075,6 +1176,10 @@ hipError_t nwk_launch_prep(hipStream_t st, const float* raw, long long rows, int
 {
     if (rows_pad <= 0) return hipSuccess;
     const long long blocks = (rows_pad + 255) / 256;
+    if ((((uintptr_t)raw) & 15) == 0 && d % 4 == 0) {                                           // tiled fast path
+        hipLaunchKernelGGL((nwk_prep_tiled_kernel<float, false>), dim3((unsigned)blocks), dim3(256), 0, st, raw, rows, d, rows_pad, dp, (void*)prepared, norms);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(nwk_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, st, raw, rows, d, rows_pad, dp, prepared, norms);
     return hipGetLastError();
 }
