@@ -669,6 +669,8 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16(const NwkTileParam
     __shared__ __attribute__((aligned(16))) char smem[2 * H_STAGE + H_TM * 16];
     char* const epi = smem + 2 * H_STAGE;     // query norms | thresholds | pre-filter terms of this tile, written once up front
 
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;
+    if (p.dbg) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     const TileCoord tc = tile_from_block(p);
     if (!tc.ok) return;
 
@@ -783,6 +785,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16(const NwkTileParam
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    if (p.dbg) st1 = __builtin_amdgcn_s_memtime();
     read_frags(0, 0, 0);
     if (DIAG & 1) read_frags(1, 0, 1);
 
@@ -806,6 +809,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16(const NwkTileParam
     }
 #undef NWK_HSTEP
 
+    if (p.dbg) st2 = __builtin_amdgcn_s_memtime();
     if (!(DIAG & 16))
         tile_epilogue<METRIC, DENSE, 4>(p, acc, (const float*)epi, (const u64*)(epi + H_TM * 4), (const float*)(epi + H_TM * 12), bnv, colv,
                                         colok, q0, wr * 128, h, c32);
@@ -814,6 +818,11 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16(const NwkTileParam
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n) asm volatile("" :: "v"(acc[m][n]));
+    }
+    if (p.dbg && tid == 0) {
+        unsigned long long* o = p.dbg + (size_t)blockIdx.x * 8;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memtime(); o[4] = rt0; o[5] = __builtin_amdgcn_s_memrealtime();
+        o[6] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); o[7] = 1;
     }
 }
 

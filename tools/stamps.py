@@ -3,14 +3,16 @@ import sys
 sys.path.insert(0, ".")
 import numpy as np, torch
 from neighborhoodwatch_amd import KnnEngine
-variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0  # stamps exist in variant 0 only
-Q, B, d, k = 10_000, 1_000_000, 768, 100
+dtype = sys.argv[1] if len(sys.argv) > 1 else "f32"
+diag = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+Q, B, d, k = (10_000, 1_000_000, 768, 100) if dtype == "f32" else (32_768, 1_048_576, 1536, 100)
+variant = dtype
 eng = KnnEngine(0)
-eng.set_option("variant", variant)
-base = eng.generate(1, 0, B, d); qs = eng.generate(2, 0, Q, d)
+eng.set_option("diag", diag)
+base = eng.generate(1, 0, B, d, dtype); qs = eng.generate(2, 0, Q, d, dtype)
 eng.set_base(base)
 eng.search(qs, k)
-nq_t, nb_t = (Q + 127) // 128, 4096          # biggest launch: 524288 rows
+nq_t, nb_t = (Q + 255) // 256, (4096 if dtype == "f32" else 2048)          # biggest launch: 524288 rows
 grid = ((nq_t + 7) // 8) * ((nb_t + 7) // 8); grid = (grid + 7) // 8 * 8 * 64
 dbg = torch.zeros((grid * 4, 8), dtype=torch.int64, device="cuda")
 eng.set_option("dbg_ptr", dbg.data_ptr())
@@ -27,5 +29,5 @@ clk = cyc_total[ok] / rt[ok] * 100e6 / 1e9
 print(f"variant {variant}: {len(a)} workgroups; clock GHz median {np.median(clk):.3f} (p10 {np.percentile(clk,10):.3f}, p90 {np.percentile(clk,90):.3f})")
 for name, v in (("prologue", pro), ("k-loop", loop), ("epilogue", epi), ("total", cyc_total)):
     print(f"  {name:9s} cycles: median {np.median(v):9.0f}  p10 {np.percentile(v,10):9.0f}  p90 {np.percentile(v,90):9.0f}")
-mfma = (d // 2) * 4 * 64
-print(f"  ideal MFMA cycles per wave per tile: {mfma}; x2 (two workgroups share a SIMD): {2*mfma}")
+mfma = (d // 2) * 8 * 64 if dtype == "f32" else (d // 16) * 8 * 32
+print(f"  ideal MFMA cycles per wave per tile: {mfma}; x2 (two waves share a SIMD): {2*mfma}")
