@@ -38,7 +38,7 @@ typedef unsigned int u32;
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 sortable_u32(float f)
 {
-    u32 u = __float_as_uint(f);
+    u32 u = (f != f) ? 0x7FC00000u : __float_as_uint(f);      // every NaN ranks as +qNaN (last): sign/payload differ between CPUs and GPUs
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __device__ __forceinline__ float unsortable_f32(u32 s)

@@ -30,7 +30,7 @@
  *   one_minus_dot : d = 1.0f - dot
  *   cosine        : d = 1.0f - dot / (sqrtf(qn) * sqrtf(bn))
  *   order         : ascending by (d, index); d compared through the usual sortable-uint32 map
- *                   (so -0.0 < +0.0 and NaN sorts last), lower index wins ties.
+ *                   (so -0.0 < +0.0 and every NaN, canonicalised to +qNaN, sorts last), lower index wins ties.
  */
 #include <immintrin.h>
 #include <math.h>
@@ -77,6 +77,7 @@ void nwo_gen(uint64_t seed, int64_t row0, int64_t rows, int32_t d, float* out)
 static inline uint32_t nwo_sortable(float f)
 {
     uint32_t u; memcpy(&u, &f, 4);
+    if (f != f) u = 0x7FC00000u;                /* every NaN ranks as +qNaN (last): x86 and gfx950 generate different NaN signs */
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 static inline float nwo_unsortable(uint32_t s)

@@ -280,3 +280,28 @@ def test_merge_folds_more_than_4096_entries(engine, oracle):
     assert np.array_equal(mi, ri) and _same_bits(md, rd)
     td_, ti_ = engine.merge(torch.from_numpy(d).cuda(), torch.from_numpy(i).cuda(), 1000)
     assert np.array_equal(ti_.cpu().numpy(), ri) and _same_bits(td_.cpu().numpy(), rd)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (3, 3, 2, 3), (5, 2, 7, 2), (2, 129, 3, 129)])
+def test_degenerate_shapes(engine, oracle, shape):
+    q, b, d, k = shape
+    base, queries = oracle.gen(0xB1 + b, 0, b, d), oracle.gen(0xB2 + q, 0, q, d)
+    engine.set_base(base)
+    for metric in ("sqeuclidean", "one_minus_dot"):
+        dist, idx = engine.search(queries, k, metric)
+        rd, ri = oracle.knn_canonical(base, queries, k, metric)
+        assert np.array_equal(idx, ri) and _same_bits(dist, rd)
+
+
+def test_non_finite_inputs_do_not_break_parity(engine, oracle):
+    """NaN / Inf rows are garbage in, but the engine must neither hang nor diverge from the canonical arithmetic
+    (the pre-filter lets NaNs fall through to the exact test; fmaxf(NaN, 0) = 0 on both sides)."""
+    base, queries = oracle.gen(0xD1, 0, 3000, 40), oracle.gen(0xD2, 0, 70, 40)
+    base[17, 3] = np.nan; base[400, :] = np.inf; base[999, 0] = -np.inf; base[2500, 7] = 3e38
+    queries[5, 1] = np.nan; queries[9, :] = 1e30
+    engine.set_base(base)
+    for metric in ("sqeuclidean", "one_minus_dot"):
+        dist, idx = engine.search(queries, 25, metric)
+        rd, ri = oracle.knn_canonical(base, queries, 25, metric)
+        assert np.array_equal(idx, ri)
+        assert np.array_equal(dist.view(np.uint32), rd.view(np.uint32))
