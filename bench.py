@@ -149,7 +149,7 @@ def main():
         return eng.search(qs, kk, metric, index_offset=offset)
 
     agg = {"tile_ms": 0.0, "tile_flops": 0.0, "tile_launches": 0, "compact_ms": 0.0, "prep_ms": 0.0, "rescan_launches": 0,
-           "overflowed_queries": 0}
+           "overflowed_queries": 0, "rescore_ms": 0.0}
 
     def step(record):
         dist, idx = sharded_search(search_shard, eng.merge, queries, k, lo, None)
@@ -206,7 +206,7 @@ def main():
                          "avg_launch_ms": agg["tile_ms"] / max(agg["tile_launches"], 1),
                          "flops_per_launch": agg["tile_flops"] / max(agg["tile_launches"], 1)},
             "breakdown_ms_per_step": {"tile": agg["tile_ms"] / args.steps, "compact": agg["compact_ms"] / args.steps,
-                                      "prep": agg["prep_ms"] / args.steps, "rescan_launches": agg["rescan_launches"],
+                                      "prep": agg["prep_ms"] / args.steps, "rescore": agg["rescore_ms"] / args.steps, "rescan_launches": agg["rescan_launches"],
                                       "overflowed_queries": agg["overflowed_queries"]},
         }
         if world == 1 and not args.no_cpu_baseline and not maxsim:

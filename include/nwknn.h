@@ -65,6 +65,9 @@ typedef struct nwknn_stats {
     double prep_ms;                /* base + query layout/norm kernels inside the last search/set_base */
     double total_ms;               /* first launch to last launch of the search */
     double tile_flops;             /* 2 * q_rows * b_rows * d summed over the distance-tile launches */
+    double rescore_ms;             /* option "prescreen": sum of the fp32 rescoring kernel durations */
+    int32_t prescreen;             /* 1 when the last search ran the fp16 pre-screen + fp32 rescoring, 0 for the direct kernel */
+    int32_t reserved_;
 } nwknn_stats;
 
 /* ---- library / device ------------------------------------------------------------------------------- */

@@ -37,7 +37,7 @@ class NwknnStats(ctypes.Structure):
         ("tile_launches", c_int32), ("compact_launches", c_int32), ("rescan_launches", c_int32),
         ("overflowed_queries", c_int32),
         ("tile_ms", c_double), ("compact_ms", c_double), ("prep_ms", c_double), ("total_ms", c_double),
-        ("tile_flops", c_double),
+        ("tile_flops", c_double), ("rescore_ms", c_double), ("prescreen", c_int32), ("reserved_", c_int32),
     ]
 
     def as_dict(self) -> dict:

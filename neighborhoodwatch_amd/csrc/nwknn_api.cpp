@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -67,7 +68,7 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
-struct EvPair { hipEvent_t a, b; int kind; };   // kind: 0 tile, 1 compact, 2 prep
+struct EvPair { hipEvent_t a, b; int kind; };   // kind: 0 tile, 1 compact, 2 prep, 3 rescore
 
 struct nwknn_ctx {
     int device = 0;
@@ -80,10 +81,15 @@ struct nwknn_ctx {
     int f16 = 0;                    // 1: the prepared base (and queries) are fp16, distance tiles run on the fp16 MFMA kernel
     // query side
     DevBuf qraw, qp, qn;
+    // fp16 pre-screen of the exact fp32 search (option "prescreen"): scaled fp16 copies of bp / qp
+    DevBuf bp16, qp16, cnt0, scal;
+    int pre_ok = 0;                 // the current base has a usable fp16 copy
+    int dp16 = 0;
+    float b_scale = 1.f, b_maxabs = 0.f;
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = 3;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = 3, opt_prescreen = 0;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -117,14 +123,16 @@ static void ev_end(nwknn_ctx* h, EvPair* e)
 {
     if (e) (void)hipEventRecord(e->b, h->stream);
 }
-static void ev_collect(nwknn_ctx* h, double* tile_ms, double* compact_ms, double* prep_ms)
+static void ev_collect(nwknn_ctx* h, double* tile_ms, double* compact_ms, double* prep_ms, double* rescore_ms = nullptr)
 {
     *tile_ms = *compact_ms = *prep_ms = 0.0;
+    if (rescore_ms) *rescore_ms = 0.0;
     for (size_t i = 0; i < h->ev_used; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b) != hipSuccess) continue;
         if (h->ev_pool[i].kind == 0) *tile_ms += ms;
         else if (h->ev_pool[i].kind == 1) *compact_ms += ms;
+        else if (h->ev_pool[i].kind == 3) { if (rescore_ms) *rescore_ms += ms; }
         else *prep_ms += ms;
     }
     h->ev_used = 0;
@@ -179,7 +187,7 @@ extern "C" int nwknn_destroy(nwknn_handle h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->bp, &h->bn, &h->braw, &h->qraw, &h->qp, &h->qn, &h->tau, &h->cnt, &h->buf, &h->ovf, &h->ovf_any, &h->qtiles,
-                      &h->out_d, &h->out_i, &h->mrg_d, &h->mrg_i})
+                      &h->out_d, &h->out_i, &h->mrg_d, &h->mrg_i, &h->bp16, &h->qp16, &h->cnt0, &h->scal})
         b->release();
     for (EvPair& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
@@ -213,6 +221,8 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
     } else if (!strcmp(name, "compute_dtype")) {
         if (value != NWKNN_DTYPE_F32 && value != NWKNN_DTYPE_F16) return fail(NWKNN_EINVAL, "compute_dtype must be 0 (f32) or 1 (f16)");
         h->opt_compute_f16 = value;      // takes effect at the next nwknn_set_base
+    } else if (!strcmp(name, "prescreen")) {
+        h->opt_prescreen = value ? 1 : 0;   // takes effect at the next nwknn_set_base (it builds the fp16 copy of the base)
     } else if (!strcmp(name, "super_q_shift")) {
         if (value < 0 || value > 6) return fail(NWKNN_EINVAL, "super_q_shift must be 0..6");
         h->opt_sq_shift = value;         // super-tile of an XCD = 2^v query tiles x 2^(6-v) base tiles
@@ -306,6 +316,30 @@ static int stage_and_prep_columns(nwknn_ctx* h, const void* const* columns, int 
     return NWKNN_OK;
 }
 
+// ---- fp16 pre-screen of the exact fp32 search --------------------------------------------------------
+// max |x| of a prepared fp32 matrix; usable = finite and inside [2^-40, 2^40] (keeps every scaled threshold inside fp32)
+static int matrix_maxabs(nwknn_ctx* h, const float* x, long long n, float* maxabs, bool* usable)
+{
+    RCCHK(h->scal.ensure(16));
+    HIPCHK(hipMemsetAsync(h->scal.p, 0, 4, h->stream));
+    HIPCHK(nwk_launch_maxabs(h->stream, x, n, h->scal.as<u32>()));
+    u32 bits = 0;
+    HIPCHK(hipMemcpyAsync(&bits, h->scal.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float v;
+    memcpy(&v, &bits, 4);
+    *maxabs = v;
+    *usable = bits < 0x7F800000u && v >= 0x1p-40f && v <= 0x1p40f;
+    return NWKNN_OK;
+}
+// power of two that puts maxabs in [2^14, 2^15)
+static float prescreen_scale(float maxabs)
+{
+    int e = 0;
+    (void)frexpf(maxabs, &e);            // maxabs = m * 2^e, m in [0.5, 1)
+    return ldexpf(1.0f, 15 - e);
+}
+
 static int set_base_common(nwknn_ctx* h, const void* base, const void* const* columns, int64_t rows, int32_t d, int dtype, int location)
 {
     if (!h || (!base && !columns)) return fail(NWKNN_EINVAL, "nwknn_set_base: null handle or base pointer");
@@ -317,7 +351,8 @@ static int set_base_common(nwknn_ctx* h, const void* base, const void* const* co
     if (!cols && location != NWKNN_HOST && location != NWKNN_DEVICE) return fail(NWKNN_EINVAL, "bad location %d", location);
     RCCHK(use_device(h));
     const int f16 = (dtype == NWKNN_DTYPE_F16 || h->opt_compute_f16) ? 1 : 0;
-    const long long rows_pad = round_up(rows, f16 ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS);
+    const bool pre = h->opt_prescreen && !f16;
+    const long long rows_pad = round_up(rows, (f16 || pre) ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS);
     const int dp = (int)round_up(d, f16 ? NWK_K_ALIGN_F16 : NWK_K_ALIGN);
     RCCHK(h->bp.ensure((size_t)rows_pad * dp * (f16 ? 2 : 4)));
     RCCHK(h->bn.ensure((size_t)rows_pad * 4));
@@ -325,6 +360,20 @@ static int set_base_common(nwknn_ctx* h, const void* base, const void* const* co
     if (cols) RCCHK(stage_and_prep_columns(h, columns, dtype, f16, rows, d, rows_pad, dp, h->braw, h->bp.p, h->bn.as<float>()));
     else RCCHK(stage_and_prep(h, base, location, dtype == NWKNN_DTYPE_F16, f16, rows, d, rows_pad, dp, h->braw, h->bp.p, h->bn.as<float>()));
     h->nb = rows; h->nb_pad = rows_pad; h->d = d; h->dp = dp; h->f16 = f16; h->ms_docs = 0;
+    h->pre_ok = 0;
+    if (pre) {
+        bool usable = false;
+        RCCHK(matrix_maxabs(h, h->bp.as<float>(), rows_pad * (long long)dp, &h->b_maxabs, &usable));
+        if (usable) {       // else (NaN/Inf/extreme magnitudes/all zero): searches on this base run the direct fp32 kernel
+            h->dp16 = (int)round_up(d, NWK_K_ALIGN_F16);
+            h->b_scale = prescreen_scale(h->b_maxabs);
+            RCCHK(h->bp16.ensure((size_t)rows_pad * h->dp16 * 2));
+            EvPair* e = ev_begin(h, 2);
+            HIPCHK(nwk_launch_half_copy(h->stream, h->bp.as<float>(), rows_pad, dp, h->dp16, h->b_scale, h->bp16.p));
+            ev_end(h, e);
+            h->pre_ok = 1;
+        }
+    }
     if (h->opt_profile) {
         HIPCHK(hipStreamSynchronize(h->stream));
         double t, c, p;
@@ -347,15 +396,19 @@ extern "C" int nwknn_set_base_columns(nwknn_handle h, const void* const* columns
 }
 
 // ---- search -----------------------------------------------------------------------------------------
-struct SearchPlan { int cap; long long first, max_chunk, safe; int tile_rows; int granule; };
+struct SearchPlan {
+    int cap; long long first, max_chunk, safe; int tile_rows; int granule;
+    bool pre;                                   // filtered chunks run the fp16 pre-screen + fp32 rescoring
+    float pre_scale, pre_eps_half, pre_aq, pre_ab, pre_cst;
+};
 
-static int make_plan(nwknn_ctx* h, int k, long long nq, SearchPlan* pl)
+static int make_plan(nwknn_ctx* h, int k, long long nq, bool pre, SearchPlan* pl)
 {
     long long cap = h->opt_capacity;
     if (cap == 0) { cap = 1024; while (cap < 4ll * k) cap <<= 1; }
     if (cap < 2ll * k + NWK_TILE_ROWS) return fail(NWKNN_EINVAL, "capacity %lld too small for k=%d (need >= 2k+%d)", cap, k, NWK_TILE_ROWS);
     if (cap > 4096) return fail(NWKNN_EINVAL, "k=%d needs capacity %lld > 4096", k, cap);
-    const long long G = h->f16 ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS;          // base rows per tile = granule of every chunk
+    const long long G = (h->f16 || pre) ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS;  // base rows per tile = granule of every chunk
     long long first = h->opt_first_chunk ? round_up(h->opt_first_chunk, G) : cap / 2;
     first = std::max<long long>(first, round_up(k, G));
     first = std::min<long long>(first, cap / G * G);
@@ -367,7 +420,9 @@ static int make_plan(nwknn_ctx* h, int k, long long nq, SearchPlan* pl)
     if (pl->safe < G || first < k) return fail(NWKNN_EINVAL, "capacity %lld too small for k=%d on this compute path", cap, k);
     // query tile height: 256 rows (fewer DMA instructions and tile turnarounds per MFMA) once there are enough queries
     // to fill the chip with such tiles, else 128 (less padding waste)
-    pl->tile_rows = h->f16 ? NWK_F16_TILE_ROWS : (h->opt_tile_rows ? (int)h->opt_tile_rows : (nq >= 2048 ? 256 : 128));
+    pl->tile_rows = (h->f16 || pre) ? NWK_F16_TILE_ROWS : (h->opt_tile_rows ? (int)h->opt_tile_rows : (nq >= 2048 ? 256 : 128));
+    pl->pre = pre;
+    pl->pre_scale = 1.f; pl->pre_eps_half = pl->pre_aq = pl->pre_ab = pl->pre_cst = 0.f;
     return NWKNN_OK;
 }
 
@@ -393,6 +448,7 @@ static NwkCompactParams compact_params(nwknn_ctx* h, const SearchPlan& pl, int k
     memset(&c, 0, sizeof c);
     c.buf = h->buf.as<u64>(); c.cnt = h->cnt.as<u32>(); c.tau = h->tau.as<u64>();
     c.ovf = h->ovf.as<u32>(); c.ovf_any = h->ovf_any.as<u32>();
+    c.cnt0 = pl.pre ? h->cnt0.as<u32>() : nullptr;
     c.cap = pl.cap; c.k = k; c.qtile_rows = pl.tile_rows;
     return c;
 }
@@ -401,14 +457,29 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
                      const int* qtile_list, int n_list_tiles, bool dedupe, bool rescan)
 {
     NwkTileParams tp = tile_params(h, pl, nq_pad);
-    tp.bt0 = (int)(lo / pl.granule);
-    tp.n_btiles = (int)(rows / pl.granule);
+    const bool prescreen = pl.pre && !dense;               // the dense first chunk of a pre-screened search runs the fp32 kernel
+    const int btile = (h->f16 || prescreen) ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS;
+    tp.bt0 = (int)(lo / btile);
+    tp.n_btiles = (int)(rows / btile);
     tp.dense_col0 = lo;
     if (qtile_list) { tp.qtile_list = qtile_list; tp.n_qtiles = n_list_tiles; }
     EvPair* e = ev_begin(h, 0);
-    if (h->f16) HIPCHK(nwk_launch_tile_f16(h->stream, tp, metric, dense, (int)h->opt_diag));
+    if (prescreen) {
+        tp.qp = h->qp16.as<float>(); tp.bp = h->bp16.as<float>(); tp.dp = h->dp16;
+        tp.pre_scale = pl.pre_scale; tp.pre_eps_half = pl.pre_eps_half; tp.pre_aq = pl.pre_aq; tp.pre_ab = pl.pre_ab; tp.pre_cst = pl.pre_cst;
+        HIPCHK(nwk_launch_tile_prescreen(h->stream, tp, metric));
+    } else if (h->f16) HIPCHK(nwk_launch_tile_f16(h->stream, tp, metric, dense, (int)h->opt_diag));
     else HIPCHK(nwk_launch_tile(h->stream, tp, metric, dense, pl.tile_rows, (int)h->opt_diag));
     ev_end(h, e);
+    if (prescreen) {                                       // listed pairs -> canonical fp32 keys, in place
+        NwkRescoreParams rp;
+        rp.qp = h->qp.as<float>(); rp.bp = h->bp.as<float>(); rp.qn = h->qn.as<float>(); rp.bn = h->bn.as<float>();
+        rp.buf = h->buf.as<u64>(); rp.cnt = h->cnt.as<u32>(); rp.cnt0 = h->cnt0.as<u32>();
+        rp.dp = h->dp; rp.cap = pl.cap;
+        e = ev_begin(h, 3);
+        HIPCHK(nwk_launch_rescore(h->stream, rp, metric, nq_pad));
+        ev_end(h, e);
+    }
     h->stats.tile_launches += 1;
     if (rescan) h->stats.rescan_launches += 1;
     {   // algorithmic FLOPs of this launch: real (unpadded) query rows x real base rows x 2d
@@ -497,8 +568,9 @@ static int search_common(nwknn_ctx* h, const void* queries, const void* const* q
     if ((location != NWKNN_HOST && location != NWKNN_DEVICE) || (out_location != NWKNN_HOST && out_location != NWKNN_DEVICE))
         return fail(NWKNN_EINVAL, "nwknn_search: bad location");
     RCCHK(use_device(h));
+    bool pre = h->pre_ok && !h->f16 && metric != NWKNN_METRIC_COSINE;      // cosine has no additive split: direct fp32 kernel
     SearchPlan pl;
-    RCCHK(make_plan(h, k, nq, &pl));
+    RCCHK(make_plan(h, k, nq, pre, &pl));
 
     const long long nq_pad = round_up(nq, NWK_QPAD_ROWS);
     RCCHK(h->qp.ensure((size_t)nq_pad * h->dp * (h->f16 ? 2 : 4)));
@@ -516,6 +588,35 @@ static int search_common(nwknn_ctx* h, const void* queries, const void* const* q
 
     if (qcolumns) RCCHK(stage_and_prep_columns(h, qcolumns, dtype, h->f16, nq, h->d, nq_pad, h->dp, h->qraw, h->qp.p, h->qn.as<float>()));
     else RCCHK(stage_and_prep(h, queries, location, dtype == NWKNN_DTYPE_F16, h->f16, nq, h->d, nq_pad, h->dp, h->qraw, h->qp.p, h->qn.as<float>()));
+    if (pre) {
+        // scaled fp16 copy of the prepared queries and the constants of the error bound (DESIGN.md "pre-screen bound")
+        float q_maxabs = 0.f;
+        bool usable = false;
+        RCCHK(matrix_maxabs(h, h->qp.as<float>(), nq_pad * (long long)h->dp, &q_maxabs, &usable));
+        if (!usable) {
+            pre = false;
+            RCCHK(make_plan(h, k, nq, false, &pl));                          // same cap; granule/tile shape of the direct path
+        } else {
+            const float q_scale = prescreen_scale(q_maxabs);
+            RCCHK(h->qp16.ensure((size_t)nq_pad * h->dp16 * 2));
+            RCCHK(h->cnt0.ensure((size_t)nq_pad * 4));
+            EvPair* e = ev_begin(h, 2);
+            HIPCHK(nwk_launch_half_copy(h->stream, h->qp.as<float>(), nq_pad, h->dp, h->dp16, q_scale, h->qp16.p));
+            ev_end(h, e);
+            HIPCHK(hipMemsetAsync(h->cnt0.p, 0, (size_t)nq_pad * 4, h->stream));
+            const double u = 0x1p-24, dd = (double)h->dp16;
+            // input rounding (1+2^-11)^2-1, the canonical chain (d u), the fp16 MFMA accumulation (allowed 4 d u), 2 % slack
+            const double eps = 1.02 * (0x1p-10 * (1.0 + 0x1p-11) + 5.5 * dd * u);
+            const double a_q = 0x1p-14 / (double)q_scale, a_b = 0x1p-14 / (double)h->b_scale;   // absolute error per element
+            const double sd = sqrt((double)h->d);
+            pl.pre_scale = q_scale * h->b_scale;
+            pl.pre_eps_half = (float)(0.5 * eps);
+            pl.pre_aq = (float)(1.01 * a_q * sd);       // times sqrt(|b|^2) >= |b|_1 / sqrt(d)
+            pl.pre_ab = (float)(1.01 * a_b * sd);       // times sqrt(|q|^2)
+            pl.pre_cst = (float)(1.01 * (double)h->d * a_q * a_b);
+        }
+    }
+    h->stats.prescreen = pre ? 1 : 0;
     HIPCHK(hipMemsetAsync(h->tau.p, 0xFF, (size_t)nq_pad * 8, h->stream));
     HIPCHK(hipMemsetAsync(h->cnt.p, 0, (size_t)nq_pad * 4, h->stream));
     HIPCHK(hipMemsetAsync(h->ovf.p, 0, (size_t)nq_pad * 4, h->stream));
@@ -553,7 +654,7 @@ static int search_common(nwknn_ctx* h, const void* queries, const void* const* q
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, h->ev_begin, h->ev_end));
         h->stats.total_ms = ms;
-        ev_collect(h, &h->stats.tile_ms, &h->stats.compact_ms, &h->stats.prep_ms);
+        ev_collect(h, &h->stats.tile_ms, &h->stats.compact_ms, &h->stats.prep_ms, &h->stats.rescore_ms);
         h->stats.prep_ms += h->base_prep_ms;      // the base layout/norm pass that preceded this search
         h->base_prep_ms = 0.0;
     }
@@ -582,11 +683,11 @@ extern "C" int nwknn_maxsim_set_docs(nwknn_handle h, const void* doc_tokens, int
     if (tokens_per_doc != NWK_MS_TOKENS_PER_DOC) return fail(NWKNN_EINVAL, "nwknn_maxsim_set_docs: tokens_per_doc must be %d", NWK_MS_TOKENS_PER_DOC);
     if (dtype != NWKNN_DTYPE_F32) return fail(NWKNN_EINVAL, "nwknn_maxsim_set_docs: float32 tokens only");
     if (n_docs <= 0 || n_docs > (1ll << 25)) return fail(NWKNN_EINVAL, "nwknn_maxsim_set_docs: n_docs out of range");
-    const long long save = h->opt_compute_f16;
-    h->opt_compute_f16 = 0;
+    const long long save = h->opt_compute_f16, save_pre = h->opt_prescreen;
+    h->opt_compute_f16 = 0; h->opt_prescreen = 0;
     // 4 docs = 256 token rows per tile: pad the row count to a multiple of 256 by declaring whole (zero) documents
     const int rc = set_base_common(h, doc_tokens, nullptr, n_docs * tokens_per_doc, d, dtype, location);
-    h->opt_compute_f16 = save;
+    h->opt_compute_f16 = save; h->opt_prescreen = save_pre;
     RCCHK(rc);
     const long long pad = round_up(h->nb, 256);
     if (pad > h->nb_pad) {      // set_base pads to 128 rows; MaxSim tiles need 256: grow and clear the tail

@@ -32,12 +32,31 @@ struct NwkTileParams {
     int dp;
     int cap;
     unsigned long long* dbg;       // dev builds only: per-workgroup stamps {t_start, t_loop, t_loop_end, t_end, rt_start, rt_end, xcc, 0}
+    // fp16 pre-screen of the exact fp32 search (nwk_launch_tile_prescreen): qp/bp are the SCALED fp16 copies, qn/bn the canonical
+    // fp32 norms; a pair passes when  acc >= pre_scale * (row(q) + col(b))  with the error bound of DESIGN.md folded into row/col
+    float pre_scale;               // s_q * s_b (power of two): the accumulators hold pre_scale * dot
+    float pre_eps_half;            // eps/2: relative error of the fp16 dot product w.r.t. (|q|^2 + |b|^2)/2
+    float pre_aq, pre_ab;          // absolute terms: pre_aq * sqrt(|b|^2) and pre_ab * sqrt(|q|^2)
+    float pre_cst;
+};
+
+struct NwkRescoreParams {
+    const float* qp;               // prepared fp32 queries / base (canonical layout) and norms
+    const float* bp;
+    const float* qn;
+    const float* bn;
+    unsigned long long* buf;
+    const unsigned int* cnt;       // entries now
+    const unsigned int* cnt0;      // entries after the last compaction: [cnt0, min(cnt, cap)) are pre-screen candidates
+    int dp;
+    int cap;
 };
 
 struct NwkCompactParams {
     unsigned long long* buf;
     unsigned int* cnt;
     unsigned long long* tau;
+    unsigned int* cnt0;            // optional: receives the post-compaction count (start of the next pre-screen candidates)
     unsigned int* ovf;             // per query: set to 1 when its list overflowed in this launch
     unsigned int* ovf_any;         // one word: OR of all overflows
     const int* qtile_list;         // optional: compact only the queries of these tiles (grid = n_tiles*128)
@@ -56,6 +75,10 @@ hipError_t nwk_launch_prep_strided(hipStream_t st, const void* raw, int in_dtype
                                    long long rows_pad, int dp, int out_f16, void* prepared, float* norms);
 hipError_t nwk_launch_prep(hipStream_t st, const float* raw, long long rows, int d, long long rows_pad, int dp, float* prepared, float* norms);
 hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool dense, int tile_rows, int diag);
+hipError_t nwk_launch_tile_prescreen(hipStream_t st, NwkTileParams p, int metric);
+hipError_t nwk_launch_rescore(hipStream_t st, const NwkRescoreParams& p, int metric, long long nq_pad);
+hipError_t nwk_launch_maxabs(hipStream_t st, const float* x, long long n, unsigned int* out_bits);
+hipError_t nwk_launch_half_copy(hipStream_t st, const float* prepared, long long rows_pad, int dp32, int dp16, float scale, void* out16);
 hipError_t nwk_launch_compact(hipStream_t st, const NwkCompactParams& p, long long n_queries);
 hipError_t nwk_launch_finalize(hipStream_t st, const unsigned long long* buf, const unsigned int* cnt, int cap, int k, long long nq,
                                long long index_offset, float* out_d, long long* out_i, int negate);

@@ -386,7 +386,34 @@ __device__ __forceinline__ float prefilter_col(float bn)
     return 0.0f;
 }
 
-template <int METRIC, bool DENSE, int MT>
+// Pre-screen thresholds (fp16 pre-screen of the exact fp32 search).  The accumulator holds  S * dot16  with S = pre_scale and
+// |dot16 - dot32| <= E(q,b) = eps/2 (qn + bn) + aq sqrt(bn) + ab sqrt(qn) + cst   (DESIGN.md "pre-screen bound"), so every pair
+// whose CANONICAL fp32 distance is <= tau_d satisfies  S*dot16 >= S * (row(q) + col(b))  with
+//     sqeuclidean   : row = (qn - tau_d)/2 - eps/2 qn - ab sqrt(qn) - cst,   col = bn/2 - eps/2 bn - aq sqrt(bn)
+//     one_minus_dot : row = (1 - tau_d)    - eps/2 qn - ab sqrt(qn) - cst,   col =        - eps/2 bn - aq sqrt(bn)
+// each lowered by a few ulps of its operands for the fp32 evaluation of these very expressions.
+template <int METRIC>
+__device__ __forceinline__ float prescreen_row(float qn, u64 tau, const NwkTileParams& p)
+{
+    if (tau == ~0ull) return -__builtin_inff();
+    const float td = unsortable_f32((u32)(tau >> 32));
+    const float err = p.pre_eps_half * qn + p.pre_ab * sqrtf(qn) + p.pre_cst;
+    float r;
+    if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) r = 0.5f * (qn - td) - err - 2.0e-6f * (fabsf(qn) + fabsf(td)) - 1.0e-30f;
+    else r = (1.0f - td) - err - 2.0e-6f * (1.0f + fabsf(td) + err);
+    return r * p.pre_scale;
+}
+template <int METRIC>
+__device__ __forceinline__ float prescreen_col(float bn, const NwkTileParams& p)
+{
+    const float err = p.pre_eps_half * bn + p.pre_aq * sqrtf(bn);
+    float c;
+    if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) c = 0.5f * bn - err - 2.0e-6f * fabsf(bn);
+    else c = -err - 2.0e-6f * err;
+    return c * p.pre_scale;
+}
+
+template <int METRIC, bool DENSE, int MT, int PRE = 0>
 __device__ __forceinline__ void tile_epilogue(const NwkTileParams& p, const f32x16 (&acc)[MT][2], const float* s_qn, const u64* s_tau,
                                               const float* s_pre, const float (&bnv)[2], const u32 (&colv)[2], const bool (&colok)[2],
                                               long long q0, int wrow0, int h, int c32)
@@ -394,7 +421,8 @@ __device__ __forceinline__ void tile_epilogue(const NwkTileParams& p, const f32x
     const int cap = p.cap;
     float cpre[2];
 #pragma unroll
-    for (int n = 0; n < 2; ++n) cpre[n] = colok[n] ? prefilter_col<METRIC>(bnv[n]) : __builtin_inff();   // padding columns never pass
+    for (int n = 0; n < 2; ++n)
+        cpre[n] = colok[n] ? (PRE ? prescreen_col<METRIC>(bnv[n], p) : prefilter_col<METRIC>(bnv[n])) : __builtin_inff();   // padding columns never pass
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int rb = wrow0 + m * 32 + 4 * h;
@@ -445,6 +473,11 @@ __device__ __forceinline__ void tile_epilogue(const NwkTileParams& p, const f32x
                 bool pass[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+                    if (PRE) {                                     // pre-screen: the additive test IS the filter; keys are rescored later
+                        key[i] = (u64)colv[n];
+                        pass[i] = !(acc[m][n][4 * j + i] < pre4[j][i] + cpre[n]) & colok[n];
+                        continue;
+                    }
                     const float dist = distance_epilogue<METRIC>(acc[m][n][4 * j + i], qn4[i], bnv[n]);
                     const u32 sd = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? (__float_as_uint(dist) | 0x80000000u)   // dist >= +0, never NaN
                                                                          : sortable_u32(dist);
@@ -474,8 +507,8 @@ __device__ __forceinline__ void tile_epilogue(const NwkTileParams& p, const f32x
 }
 
 // staging of the tile's query-side epilogue inputs in LDS: norms | 64-bit thresholds | pre-filter row terms
-template <int METRIC, bool DENSE>
-__device__ __forceinline__ void stage_query_side(char* lds, int rows, int tid, float my_qn, u64 my_tau)
+template <int METRIC, bool DENSE, int PRE = 0>
+__device__ __forceinline__ void stage_query_side(char* lds, int rows, int tid, float my_qn, u64 my_tau, const NwkTileParams& p)
 {
     float* s_qn = (float*)lds;
     u64* s_tau = (u64*)(lds + rows * 4);
@@ -484,7 +517,7 @@ __device__ __forceinline__ void stage_query_side(char* lds, int rows, int tid, f
         s_qn[tid] = my_qn;
         if (!DENSE) {
             s_tau[tid] = my_tau;
-            s_pre[tid] = prefilter_row<METRIC>(my_qn, my_tau);
+            s_pre[tid] = PRE ? prescreen_row<METRIC>(my_qn, my_tau, p) : prefilter_row<METRIC>(my_qn, my_tau);
         }
     }
 }
@@ -639,7 +672,7 @@ __global__ __launch_bounds__(256, 2) void nwk_tile_kernel(const NwkTileParams p)
 
     if (p.dbg) st2 = __builtin_amdgcn_s_memtime();
     // ---- epilogue: accumulators -> keys -> filter -> candidate lists (staging reuses the idle operand stages)
-    stage_query_side<METRIC, DENSE>(smem, TM, tid, my_qn, my_tau);
+    stage_query_side<METRIC, DENSE>(smem, TM, tid, my_qn, my_tau, p);
     __syncthreads();
     tile_epilogue<METRIC, DENSE, MT>(p, acc, (const float*)smem, (const u64*)(smem + TM * 4), (const float*)(smem + TM * 12), bnv, colv, colok,
                                      q0, wr * (TM / 2), h, c32);
@@ -663,7 +696,7 @@ __global__ __launch_bounds__(256, 2) void nwk_tile_kernel(const NwkTileParams p)
 #define H_BK 64                       // halves per slab = 128-B rows
 #define H_STAGE (2 * 256 * 128)       // A 32 KiB + B 32 KiB
 
-template <int METRIC, bool DENSE, int DIAG = 0>
+template <int METRIC, bool DENSE, int DIAG = 0, int PRE = 0>
 __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16(const NwkTileParams p)
 {
     __shared__ __attribute__((aligned(16))) char smem[2 * H_STAGE + H_TM * 16];
@@ -743,7 +776,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16(const NwkTileParam
             my_qn = p.qn[q0 + tid];
             if (!DENSE) my_tau = p.tau[q0 + tid];
         }
-        stage_query_side<METRIC, DENSE>(epi, H_TM, tid, my_qn, my_tau);
+        stage_query_side<METRIC, DENSE, PRE>(epi, H_TM, tid, my_qn, my_tau, p);
     }
 
     // Software pipeline: fragment registers are double buffered (set S feeds the MFMAs of k-step s while the ds_reads of
@@ -811,7 +844,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16(const NwkTileParam
 
     if (p.dbg) st2 = __builtin_amdgcn_s_memtime();
     if (!(DIAG & 16))
-        tile_epilogue<METRIC, DENSE, 4>(p, acc, (const float*)epi, (const u64*)(epi + H_TM * 4), (const float*)(epi + H_TM * 12), bnv, colv,
+        tile_epilogue<METRIC, DENSE, 4, PRE>(p, acc, (const float*)epi, (const u64*)(epi + H_TM * 4), (const float*)(epi + H_TM * 12), bnv, colv,
                                         colok, q0, wr * 128, h, c32);
     else {                                                   // DIAG 16: no epilogue (keep the accumulators alive)
 #pragma unroll
@@ -972,6 +1005,84 @@ __global__ __launch_bounds__(256, 2) void nwk_maxsim_kernel(const NwkTileParams 
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp16 pre-screen support (exact fp32 search, option "prescreen"): the fp16 MFMA kernel above runs over SCALED fp16 copies
+// of the prepared fp32 operands with the loosened additive filter (PRE = 1) and lists every pair that could be among the
+// k nearest; the rescore kernel then replaces each listed pair by its canonical fp32 key, so compaction, tau and the final
+// result are bit-for-bit those of the direct fp32 path.
+//   * maxabs      : max |x| over a prepared fp32 matrix, as float bits through atomicMax (NaN/Inf show up as >= 0x7F800000)
+//   * half_copy   : prepared fp32 [rows_pad][dp32] (k order [0 2 4 6 | 1 3 5 7] per group of 8) -> fp16 [rows_pad][dp16] in natural
+//                   order, multiplied by a power of two that puts max |x| in [2^14, 2^15): no overflow, and whatever falls below
+//                   the fp16 normal range is < 2^-28 of the largest element (the absolute term of the bound)
+//   * rescore     : one wave per query, one lane per listed pair: ascending-k fmaf chain over the prepared fp32 rows (the same
+//                   chain the fp32 MFMA accumulator performs), canonical epilogue, 64-bit key written back in place
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nwk_maxabs_kernel(const float* __restrict__ x, long long n4, u32* __restrict__ out_bits)
+{
+    u32 m = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const u32x4 v = *(const u32x4*)(x + 4 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const u32 a = v[j] & 0x7FFFFFFFu; m = a > m ? a : m; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const u32 o = (u32)__shfl_xor((int)m, off); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out_bits, m);
+}
+
+__global__ __launch_bounds__(256) void nwk_half_copy_kernel(const float* __restrict__ prepared, long long rows_pad, int dp32, int dp16,
+                                                             float scale, _Float16* __restrict__ out)
+{
+    const int g16 = dp16 >> 3;
+    const long long total = rows_pad * g16;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / g16;
+        const int k0 = (int)(i - r * g16) << 3;
+        f16x8 hv = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (k0 < dp32) {
+            const f32x4 ev = *(const f32x4*)(prepared + r * dp32 + k0), od = *(const f32x4*)(prepared + r * dp32 + k0 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hv[2 * j] = (_Float16)(ev[j] * scale);
+                hv[2 * j + 1] = (_Float16)(od[j] * scale);
+            }
+        }
+        *(f16x8*)(out + r * dp16 + k0) = hv;
+    }
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const long long q = (long long)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const u32 start = p.cnt0[q];
+    u32 end = p.cnt[q];
+    if (end > (u32)p.cap) end = (u32)p.cap;
+    if (start >= end) return;
+    const float* __restrict__ qrow = p.qp + q * p.dp;
+    const float qn = p.qn[q];
+    u64* list = p.buf + q * p.cap;
+    for (u32 e0 = start; e0 < end; e0 += 64) {
+        const u32 e = e0 + lane;
+        const bool live = e < end;
+        const u32 col = live ? (u32)list[e] : 0u;
+        const float* __restrict__ brow = p.bp + (long long)col * p.dp;
+        float acc = 0.0f;
+        for (int k0 = 0; k0 < p.dp; k0 += 8) {
+            const f32x4 be = *(const f32x4*)(brow + k0), bo = *(const f32x4*)(brow + k0 + 4);
+            const f32x4 qe = *(const f32x4*)(qrow + k0), qo = *(const f32x4*)(qrow + k0 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                              // k = k0+2j, then k0+2j+1: ascending
+                acc = __fmaf_rn(qe[j], be[j], acc);
+                acc = __fmaf_rn(qo[j], bo[j], acc);
+            }
+        }
+        const float dist = distance_epilogue<METRIC>(acc, qn, p.bn[col]);
+        if (live) list[e] = ((u64)sortable_u32(dist) << 32) | col;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // compaction: sort one query's candidate list, (optionally) drop duplicate keys, keep k, tighten tau
 //   dynamic LDS: [cap] u64 keys | [2][cap] u32 scan buffers | 16 B scratch   (one array: keeps the base 16-B aligned)
 // ------------------------------------------------------------------------------------------------
@@ -1036,6 +1147,7 @@ __global__ __launch_bounds__(256) void nwk_compact_kernel(const NwkCompactParams
         }
         if (tid == 0) {
             p.cnt[q] = nvalid < k ? nvalid : k;
+            if (p.cnt0) p.cnt0[q] = nvalid < k ? nvalid : k;
             if (nvalid < k) p.tau[q] = ~0ull;
         }
     } else {
@@ -1048,6 +1160,7 @@ __global__ __launch_bounds__(256) void nwk_compact_kernel(const NwkCompactParams
         for (u32 i = tid; i < keep; i += 256) list[i] = s[i];
         if (tid == 0) {
             p.cnt[q] = keep;
+            if (p.cnt0) p.cnt0[q] = keep;
             p.tau[q] = (nvalid >= k) ? s[k - 1] : ~0ull;
         }
     }
@@ -1285,6 +1398,55 @@ hipError_t nwk_launch_maxsim(hipStream_t st, NwkTileParams p, bool dense)
     if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
     if (dense) hipLaunchKernelGGL((nwk_maxsim_kernel<true>), dim3((unsigned)grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((nwk_maxsim_kernel<false>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+// pre-screen launch of the fp16 tile kernel: p.qp/p.bp are the scaled fp16 copies, tiles are 256 x 256, never dense
+hipError_t nwk_launch_tile_prescreen(hipStream_t st, NwkTileParams p, int metric)
+{
+    if (p.n_qtiles <= 0 || p.n_btiles <= 0) return hipSuccess;
+    if (p.sq_shift < 0 || p.sq_shift > 6) return hipErrorInvalidValue;
+    const int SQ = 1 << p.sq_shift, SB = 64 >> p.sq_shift;
+    const long long n_super_q = (p.n_qtiles + SQ - 1) / SQ;
+    p.n_super_b = (p.n_btiles + SB - 1) / SB;
+    long long supers = n_super_q * p.n_super_b;
+    supers = (supers + 7) / 8 * 8;
+    const long long grid = supers * 64;
+    if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    if (metric == NWKNN_METRIC_SQEUCLIDEAN)
+        hipLaunchKernelGGL((nwk_tile_kernel_f16<NWKNN_METRIC_SQEUCLIDEAN, false, 0, 1>), dim3((unsigned)grid), dim3(512), 0, st, p);
+    else if (metric == NWKNN_METRIC_ONE_MINUS_DOT)
+        hipLaunchKernelGGL((nwk_tile_kernel_f16<NWKNN_METRIC_ONE_MINUS_DOT, false, 0, 1>), dim3((unsigned)grid), dim3(512), 0, st, p);
+    else return hipErrorInvalidValue;                      // cosine has no additive split: the caller stays on the fp32 kernel
+    return hipGetLastError();
+}
+
+hipError_t nwk_launch_rescore(hipStream_t st, const NwkRescoreParams& p, int metric, long long nq_pad)
+{
+    if (nq_pad <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((nq_pad + 3) / 4);          // nq_pad is a multiple of 256
+    if (metric == NWKNN_METRIC_SQEUCLIDEAN) hipLaunchKernelGGL((nwk_rescore_kernel<NWKNN_METRIC_SQEUCLIDEAN>), dim3(grid), dim3(256), 0, st, p);
+    else if (metric == NWKNN_METRIC_ONE_MINUS_DOT) hipLaunchKernelGGL((nwk_rescore_kernel<NWKNN_METRIC_ONE_MINUS_DOT>), dim3(grid), dim3(256), 0, st, p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t nwk_launch_maxabs(hipStream_t st, const float* x, long long n, unsigned int* out_bits)
+{
+    if (n <= 0) return hipSuccess;                              // n is a multiple of 4 (dp is a multiple of 32)
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(nwk_maxabs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n / 4, out_bits);
+    return hipGetLastError();
+}
+
+hipError_t nwk_launch_half_copy(hipStream_t st, const float* prepared, long long rows_pad, int dp32, int dp16, float scale, void* out16)
+{
+    const long long total = rows_pad * (dp16 / 8);
+    if (total <= 0) return hipSuccess;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(nwk_half_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, prepared, rows_pad, dp32, dp16, scale, (_Float16*)out16);
     return hipGetLastError();
 }
 

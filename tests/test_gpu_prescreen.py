@@ -1,0 +1,162 @@
+"""Option "prescreen": fp16 MFMA pre-screen + canonical fp32 rescoring.  The contract is the one of the direct fp32 kernel:
+indices AND distances bit-identical to the CPU oracle's canonical fmaf chain -- the fp16 pass may only ever list MORE pairs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ADDITIVE = ["sqeuclidean", "one_minus_dot"]
+
+
+def _bitwise(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+
+
+@pytest.fixture()
+def pre_engine():
+    from neighborhoodwatch_amd import KnnEngine
+    with KnnEngine(0) as eng:
+        eng.set_option("prescreen", 1)
+        eng.set_option("profile", 1)
+        yield eng
+
+
+def _check(eng, oracle, base, queries, k, metric, expect_pre=True):
+    dist, idx = eng.search(queries, k, metric)
+    rd, ri = oracle.knn_canonical(base, queries, k, metric)
+    assert eng.stats()["prescreen"] == (1 if expect_pre else 0)
+    assert np.array_equal(idx, ri), f"{metric}: indices differ at {(idx != ri).sum()} of {idx.size} positions"
+    assert _bitwise(dist, rd), f"{metric}: distances are not bit-identical"
+
+
+@pytest.mark.parametrize("metric", ADDITIVE)
+@pytest.mark.parametrize("shape", [(100, 1000, 384, 10), (37, 2000, 100, 16), (9, 130, 36, 130), (300, 5000, 768, 100),
+                                   (1, 129, 1, 1), (129, 4097, 33, 7), (64, 20000, 64, 100), (520, 9000, 1024, 50)])
+def test_prescreen_matches_oracle_bit_exact(pre_engine, oracle, shape, metric):
+    q, b, d, k = shape
+    base = oracle.gen(0x71 + d, 0, b, d)
+    queries = oracle.gen(0x72 + d, 0, q, d)
+    pre_engine.set_base(base)
+    _check(pre_engine, oracle, base, queries, k, metric)
+
+
+def test_prescreen_actually_runs_the_fp16_kernel_and_rescoring(pre_engine, oracle):
+    base = oracle.gen(1, 0, 30000, 128)
+    queries = oracle.gen(2, 0, 300, 128)
+    pre_engine.set_base(base)
+    pre_engine.search(queries, 10, "sqeuclidean")
+    st = pre_engine.stats()
+    assert st["prescreen"] == 1 and st["rescore_ms"] > 0.0 and st["tile_launches"] >= 3
+
+
+def test_cosine_stays_on_the_direct_kernel(pre_engine, oracle):
+    base = oracle.gen(3, 0, 3000, 96)
+    queries = oracle.gen(4, 0, 50, 96)
+    pre_engine.set_base(base)
+    _check(pre_engine, oracle, base, queries, 12, "cosine", expect_pre=False)
+
+
+@pytest.mark.parametrize("metric", ADDITIVE)
+def test_unit_norm_rows(pre_engine, oracle, metric):
+    """The reference's inputs are unit-norm embeddings (tests/test_02_cu_knn.py:38-41): the regime the bound is tightest in."""
+    base = oracle.gen_unit_rows(0xA1, 0, 20000, 384)
+    queries = oracle.gen_unit_rows(0xA2, 0, 200, 384)
+    pre_engine.set_base(base)
+    _check(pre_engine, oracle, base, queries, 100, metric)
+
+
+@pytest.mark.parametrize("metric", ADDITIVE)
+def test_near_duplicates_defeat_the_fp16_pass_but_not_the_result(pre_engine, oracle, metric):
+    """Rows that differ far below fp16 resolution: the pre-screen cannot separate them and lists (almost) everything, lists
+    overflow and get repaired; the result must still be the canonical fp32 one."""
+    rng = np.random.default_rng(5)
+    centre = rng.standard_normal(64).astype(np.float32)
+    base = (centre[None, :] + 1e-5 * rng.standard_normal((6000, 64))).astype(np.float32)
+    queries = (centre[None, :] + 1e-5 * rng.standard_normal((40, 64))).astype(np.float32)
+    pre_engine.set_base(base)
+    _check(pre_engine, oracle, base, queries, 20, metric)
+    assert pre_engine.stats()["overflowed_queries"] > 0
+
+
+@pytest.mark.parametrize("metric", ADDITIVE)
+def test_exact_ties_and_duplicated_rows(pre_engine, oracle, metric):
+    base = oracle.gen(0xB1, 0, 2000, 48)
+    base = np.concatenate([base, base[:700], base[100:300]])       # exact duplicates: lower index must win
+    queries = np.concatenate([oracle.gen(0xB2, 0, 30, 48), base[5:25]])
+    pre_engine.set_base(base)
+    _check(pre_engine, oracle, base, queries, 33, metric)
+
+
+@pytest.mark.parametrize("metric", ADDITIVE)
+@pytest.mark.parametrize("scale_q,scale_b", [(1e-4, 1e3), (3e5, 2e-6), (1.0, 1e9)])
+def test_mixed_magnitudes(pre_engine, oracle, metric, scale_q, scale_b):
+    """Per-matrix power-of-two scaling keeps the fp16 copies in range whatever the magnitudes of the two sides."""
+    rng = np.random.default_rng(11)
+    base = (scale_b * rng.standard_normal((5000, 80))).astype(np.float32)
+    base[::7] *= 1e-3                                                # rows far below the matrix maximum
+    queries = (scale_q * rng.standard_normal((70, 80))).astype(np.float32)
+    pre_engine.set_base(base)
+    _check(pre_engine, oracle, base, queries, 25, metric)
+
+
+def test_wide_dynamic_range_inside_rows(pre_engine, oracle):
+    """Elements spanning 12 decades inside one row: most of them fall below the fp16 range of the scaled copy."""
+    rng = np.random.default_rng(12)
+    base = (rng.standard_normal((4000, 128)) * 10.0 ** rng.uniform(-9, 3, size=(4000, 128))).astype(np.float32)
+    queries = (rng.standard_normal((50, 128)) * 10.0 ** rng.uniform(-9, 3, size=(50, 128))).astype(np.float32)
+    pre_engine.set_base(base)
+    for metric in ADDITIVE:
+        _check(pre_engine, oracle, base, queries, 15, metric)
+
+
+def test_non_finite_or_extreme_inputs_fall_back_to_the_direct_kernel(pre_engine, oracle):
+    base = oracle.gen(0xC1, 0, 3000, 40).copy()
+    queries = oracle.gen(0xC2, 0, 70, 40).copy()
+    bad = base.copy()
+    bad[17, 3] = np.nan
+    pre_engine.set_base(bad)
+    _check(pre_engine, oracle, bad, queries, 25, "sqeuclidean", expect_pre=False)
+    pre_engine.set_base(base)
+    badq = queries.copy()
+    badq[9, :] = 1e30
+    _check(pre_engine, oracle, base, badq, 25, "sqeuclidean", expect_pre=False)
+    _check(pre_engine, oracle, base, queries, 25, "sqeuclidean", expect_pre=True)      # and back
+
+
+def test_index_offset_columns_and_device_outputs(pre_engine, oracle):
+    import torch
+    base = oracle.gen(0xD1, 0, 7000, 72)
+    queries = oracle.gen(0xD2, 0, 90, 72)
+    rd, ri = oracle.knn_canonical(base, queries, 9, "sqeuclidean")
+    pre_engine.set_base_columns([np.ascontiguousarray(base[:, j]) for j in range(base.shape[1])])
+    dist, idx = pre_engine.search_columns([np.ascontiguousarray(queries[:, j]) for j in range(queries.shape[1])], 9, "sqeuclidean",
+                                          index_offset=123456789012)
+    assert np.array_equal(idx, ri + 123456789012) and _bitwise(dist, rd)
+    tb = torch.from_numpy(base).cuda()
+    tq = torch.from_numpy(queries).cuda()
+    pre_engine.set_base(tb)
+    dist, idx = pre_engine.search(tq, 9, "sqeuclidean")
+    assert pre_engine.stats()["prescreen"] == 1
+    assert np.array_equal(idx.cpu().numpy(), ri) and _bitwise(dist.cpu().numpy(), rd)
+
+
+def test_small_capacity_forces_repair(oracle):
+    from neighborhoodwatch_amd import KnnEngine
+    base = oracle.gen(0xE1, 0, 40000, 32)
+    queries = oracle.gen(0xE2, 0, 300, 32)
+    with KnnEngine(0) as eng:
+        eng.set_option("prescreen", 1)
+        eng.set_option("capacity", 512)
+        eng.set_option("first_chunk", 256)
+        eng.set_base(base)
+        for metric in ADDITIVE:
+            dist, idx = eng.search(queries, 100, metric)
+            rd, ri = oracle.knn_canonical(base, queries, 100, metric)
+            assert np.array_equal(idx, ri) and _bitwise(dist, rd)
+
+
+def test_k_1000(pre_engine, oracle):
+    base = oracle.gen(0xF1, 0, 12000, 128)
+    queries = oracle.gen(0xF2, 0, 40, 128)
+    pre_engine.set_base(base)
+    _check(pre_engine, oracle, base, queries, 1000, "one_minus_dot")
