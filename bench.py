@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prescreen", action="store_true", help="skip the second measurement (fp16 pre-screen + fp32 rescoring)")
     ap.add_argument("--verify", action="store_true", help="compare the merged result with a single-engine search of the whole base (small workloads)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option (nwknn_set_option), dev use")
     args = ap.parse_args()
@@ -148,44 +149,72 @@ def main():
         eng.set_base(base_raw)                                    # layout + norms are part of every job
         return eng.search(qs, kk, metric, index_offset=offset)
 
-    agg = {"tile_ms": 0.0, "tile_flops": 0.0, "tile_launches": 0, "compact_ms": 0.0, "prep_ms": 0.0, "rescan_launches": 0,
-           "overflowed_queries": 0, "rescore_ms": 0.0}
-
-    def step(record):
-        dist, idx = sharded_search(search_shard, eng.merge, queries, k, lo, None)
-        if rank == 0:
-            host_d.copy_(dist, non_blocking=True)
-            host_i.copy_(idx, non_blocking=True)
-        torch.cuda.synchronize()
-        if record:
-            s = eng.stats()
-            for key in agg:
-                agg[key] += s[key]
-        return dist, idx
-
     def fence():
         if world > 1:
             td.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = step(True)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        elapsed = float(t.item())
-        fl = torch.tensor([agg["tile_flops"], agg["tile_ms"]], dtype=torch.float64, device=red_dev)
-        td.all_reduce(fl, op=td.ReduceOp.SUM)
-        sum_flops, sum_ms = float(fl[0]), float(fl[1])
-    else:
-        sum_flops, sum_ms = agg["tile_flops"], agg["tile_ms"]
+    def measure():
+        """W untimed + K timed steps, fenced on both sides; MAX over ranks of the elapsed time, SUM of the kernel accounting."""
+        agg = {"tile_ms": 0.0, "tile_flops": 0.0, "tile_launches": 0, "compact_ms": 0.0, "prep_ms": 0.0, "rescan_launches": 0,
+               "overflowed_queries": 0, "rescore_ms": 0.0, "prescreen": 0}
+        last = None
+
+        def step(record):
+            dist, idx = sharded_search(search_shard, eng.merge, queries, k, lo, None)
+            if rank == 0:
+                host_d.copy_(dist, non_blocking=True)
+                host_i.copy_(idx, non_blocking=True)
+            torch.cuda.synchronize()
+            if record:
+                s = eng.stats()
+                for key in agg:
+                    agg[key] += s[key]
+            return dist, idx
+
+        for _ in range(args.warmup):
+            step(False)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            last = step(True)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            elapsed = float(t.item())
+            fl = torch.tensor([agg["tile_flops"], agg["tile_ms"]], dtype=torch.float64, device=red_dev)
+            td.all_reduce(fl, op=td.ReduceOp.SUM)
+            sum_flops, sum_ms = float(fl[0]), float(fl[1])
+        else:
+            sum_flops, sum_ms = agg["tile_flops"], agg["tile_ms"]
+        return elapsed, agg, sum_flops, sum_ms, last
+
+    elapsed, agg, sum_flops, sum_ms, last = measure()
+
+    # the same job through the fp16 pre-screen + fp32 rescoring (engine option "prescreen"): results must be the same bits
+    pre = None
+    if not maxsim and dtype == "f32" and metric != "cosine" and not args.no_prescreen and not any("prescreen" in o for o in args.opt):
+        direct = (last[0].clone(), last[1].clone()) if rank == 0 else None
+        eng.set_prescreen(True)
+        p_elapsed, p_agg, p_flops, p_ms, p_last = measure()
+        eng.set_prescreen(False)
+        if rank == 0:
+            p_ach = (p_flops / 1e12) / (p_ms / 1e3) / world if p_ms > 0 else 0.0
+            pre = {
+                "what": "same search, same bits out: fp16 MFMA pre-screen over scaled fp16 copies + canonical fp32 rescoring of every listed pair",
+                "value": Q * args.steps / p_elapsed, "unit": "queries/s", "ms_per_step": p_elapsed / args.steps * 1e3,
+                "pairwise_tflops": 2.0 * Q * B * d * args.steps / p_elapsed / 1e12,
+                "identical_to_direct": bool(torch.equal(direct[0], p_last[0])) and bool(torch.equal(direct[1], p_last[1])),
+                "prescreen_searches": p_agg["prescreen"],
+                "roofline": {"bound": "mfma", "achieved": p_ach, "peak": MFMA_PEAK_TFLOPS["f16"], "unit": "TFLOP/s",
+                             "frac": p_ach / MFMA_PEAK_TFLOPS["f16"], "kernel": "nwk_tile_kernel_f16 (PRE)",
+                             "launches": p_agg["tile_launches"], "avg_launch_ms": p_agg["tile_ms"] / max(p_agg["tile_launches"], 1)},
+                "breakdown_ms_per_step": {"tile": p_agg["tile_ms"] / args.steps, "rescore": p_agg["rescore_ms"] / args.steps,
+                                          "compact": p_agg["compact_ms"] / args.steps, "prep": p_agg["prep_ms"] / args.steps,
+                                          "rescan_launches": p_agg["rescan_launches"], "overflowed_queries": p_agg["overflowed_queries"]},
+            }
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -209,6 +238,8 @@ def main():
                                       "prep": agg["prep_ms"] / args.steps, "rescore": agg["rescore_ms"] / args.steps, "rescan_launches": agg["rescan_launches"],
                                       "overflowed_queries": agg["overflowed_queries"]},
         }
+        if pre is not None:
+            out["exact_prescreen"] = pre
         if world == 1 and not args.no_cpu_baseline and not maxsim:
             out["cpu_baseline"] = cpu_baseline(eng, base_raw, queries, k, metric, B)
         print(json.dumps(out), flush=True)

@@ -89,7 +89,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = 3, opt_prescreen = 0;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = 3, opt_prescreen = 0, opt_pre_prune = 1;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -223,6 +223,8 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
         h->opt_compute_f16 = value;      // takes effect at the next nwknn_set_base
     } else if (!strcmp(name, "prescreen")) {
         h->opt_prescreen = value ? 1 : 0;   // takes effect at the next nwknn_set_base (it builds the fp16 copy of the base)
+    } else if (!strcmp(name, "prescreen_prune")) {
+        h->opt_pre_prune = value ? 1 : 0;   // dev: 0 rescoring every listed pair (A/B of the bound-based pruning)
     } else if (!strcmp(name, "super_q_shift")) {
         if (value < 0 || value > 6) return fail(NWKNN_EINVAL, "super_q_shift must be 0..6");
         h->opt_sq_shift = value;         // super-tile of an XCD = 2^v query tiles x 2^(6-v) base tiles
@@ -466,6 +468,7 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
     EvPair* e = ev_begin(h, 0);
     if (prescreen) {
         tp.qp = h->qp16.as<float>(); tp.bp = h->bp16.as<float>(); tp.dp = h->dp16;
+        tp.pre_inv_scale = 1.0f / pl.pre_scale;
         tp.pre_scale = pl.pre_scale; tp.pre_eps_half = pl.pre_eps_half; tp.pre_aq = pl.pre_aq; tp.pre_ab = pl.pre_ab; tp.pre_cst = pl.pre_cst;
         HIPCHK(nwk_launch_tile_prescreen(h->stream, tp, metric));
     } else if (h->f16) HIPCHK(nwk_launch_tile_f16(h->stream, tp, metric, dense, (int)h->opt_diag));
@@ -475,7 +478,8 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         NwkRescoreParams rp;
         rp.qp = h->qp.as<float>(); rp.bp = h->bp.as<float>(); rp.qn = h->qn.as<float>(); rp.bn = h->bn.as<float>();
         rp.buf = h->buf.as<u64>(); rp.cnt = h->cnt.as<u32>(); rp.cnt0 = h->cnt0.as<u32>();
-        rp.dp = h->dp; rp.cap = pl.cap;
+        rp.dp = h->dp; rp.cap = pl.cap; rp.k = k; rp.prune = h->opt_pre_prune ? 1 : 0;
+        rp.eps_half = pl.pre_eps_half; rp.aq = pl.pre_aq; rp.ab = pl.pre_ab; rp.cst = pl.pre_cst;
         e = ev_begin(h, 3);
         HIPCHK(nwk_launch_rescore(h->stream, rp, metric, nq_pad));
         ev_end(h, e);
@@ -606,7 +610,8 @@ static int search_common(nwknn_ctx* h, const void* queries, const void* const* q
             HIPCHK(hipMemsetAsync(h->cnt0.p, 0, (size_t)nq_pad * 4, h->stream));
             const double u = 0x1p-24, dd = (double)h->dp16;
             // input rounding (1+2^-11)^2-1, the canonical chain (d u), the fp16 MFMA accumulation (allowed 4 d u), 2 % slack
-            const double eps = 1.02 * (0x1p-10 * (1.0 + 0x1p-11) + 5.5 * dd * u);
+            // + the column term that rides in the accumulator: 4 u (|c| + sum|products|) per MFMA step, dd/16 steps
+            const double eps = 1.02 * (0x1p-10 * (1.0 + 0x1p-11) + 5.5 * dd * u + 4.0 * (dd / 16.0 + 1.0) * u);
             const double a_q = 0x1p-14 / (double)q_scale, a_b = 0x1p-14 / (double)h->b_scale;   // absolute error per element
             const double sd = sqrt((double)h->d);
             pl.pre_scale = q_scale * h->b_scale;

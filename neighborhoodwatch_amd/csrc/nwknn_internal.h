@@ -38,6 +38,7 @@ struct NwkTileParams {
     float pre_eps_half;            // eps/2: relative error of the fp16 dot product w.r.t. (|q|^2 + |b|^2)/2
     float pre_aq, pre_ab;          // absolute terms: pre_aq * sqrt(|b|^2) and pre_ab * sqrt(|q|^2)
     float pre_cst;
+    float pre_inv_scale;           // 1 / pre_scale
 };
 
 struct NwkRescoreParams {
@@ -50,6 +51,9 @@ struct NwkRescoreParams {
     const unsigned int* cnt0;      // entries after the last compaction: [cnt0, min(cnt, cap)) are pre-screen candidates
     int dp;
     int cap;
+    int k;
+    int prune;                     // 1: derive bounds from the fp16 estimates and skip pairs that cannot reach the top k
+    float eps_half, aq, ab, cst;   // the constants of the pre-screen error bound (as in NwkTileParams)
 };
 
 struct NwkCompactParams {

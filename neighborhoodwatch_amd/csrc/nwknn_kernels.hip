@@ -423,6 +423,8 @@ __device__ __forceinline__ void tile_epilogue(const NwkTileParams& p, const f32x
 #pragma unroll
     for (int n = 0; n < 2; ++n)
         cpre[n] = colok[n] ? (PRE ? prescreen_col<METRIC>(bnv[n], p) : prefilter_col<METRIC>(bnv[n])) : __builtin_inff();   // padding columns never pass
+    // PRE: the kernel initialised the accumulators with -cpre[n] (the column term rides through the MFMAs for free), so the
+    // test is one compare per element:  acc = S*dot16 - col(b)  against  row(q)
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int rb = wrow0 + m * 32 + 4 * h;
@@ -458,7 +460,8 @@ __device__ __forceinline__ void tile_epilogue(const NwkTileParams& p, const f32x
                 maybe &= colok[n];
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) maybe |= !(acc[m][n][r] < pre4[r >> 2][r & 3] + cpre[n]);   // NaN falls through
+                for (int r = 0; r < 16; ++r)
+                    maybe |= PRE ? !(acc[m][n][r] < pre4[r >> 2][r & 3]) : !(acc[m][n][r] < pre4[r >> 2][r & 3] + cpre[n]);   // NaN falls through
             }
             if (!__ballot(maybe)) continue;                        // the common case: nothing in this 32x32 block can survive
             // exact pass over the block, four rows (one j) at a time to keep the register footprint small: norms and
@@ -473,9 +476,13 @@ __device__ __forceinline__ void tile_epilogue(const NwkTileParams& p, const f32x
                 bool pass[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if (PRE) {                                     // pre-screen: the additive test IS the filter; keys are rescored later
-                        key[i] = (u64)colv[n];
-                        pass[i] = !(acc[m][n][4 * j + i] < pre4[j][i] + cpre[n]) & colok[n];
+                    if (PRE) {     // pre-screen: the additive test IS the filter; the key carries the fp16 estimate of the distance,
+                                   // from which the rescore kernel derives bounds that let it skip most of the listed pairs
+                        const float sdot = acc[m][n][4 * j + i] + cpre[n];                     // S * dot16
+                        const float est = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? __fmaf_rn(-2.0f * p.pre_inv_scale, sdot, qn4[i] + bnv[n])
+                                                                               : 1.0f - sdot * p.pre_inv_scale;
+                        key[i] = ((u64)__float_as_uint(est) << 32) | colv[n];
+                        pass[i] = !(acc[m][n][4 * j + i] < pre4[j][i]) & colok[n];
                         continue;
                     }
                     const float dist = distance_epilogue<METRIC>(acc[m][n][4 * j + i], qn4[i], bnv[n]);
@@ -751,14 +758,6 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16(const NwkTileParam
         offB[n] = 32768 + rb * 128 + ((h ^ ((rb >> 1) & 7)) << 4);
     }
 
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-
     float bnv[2];
     u32 colv[2];
     bool colok[2];
@@ -768,6 +767,16 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16(const NwkTileParam
         colv[n] = (u32)col;
         colok[n] = col < p.nb_valid;
         bnv[n] = p.bn[col];
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        // PRE: start from minus the column term of the pre-screen test (see tile_epilogue); else from +0
+        const float a0 = PRE ? -(colok[n] ? prescreen_col<METRIC>(bnv[n], p) : __builtin_inff()) : 0.0f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = a0;
     }
     {   // query-side epilogue inputs go to their own LDS region now; the first barrier of the K loop publishes them
         float my_qn = 0.f;
@@ -1050,11 +1059,22 @@ __global__ __launch_bounds__(256) void nwk_half_copy_kernel(const float* __restr
     }
 }
 
+// One wave per query (blockDim = 64 * waves, dynamic LDS = waves * cap * 8 bytes).  The keys the pre-screen listed carry the
+// fp16 ESTIMATE of the distance; with the error bound e(q,b) the exact value lies in [est - e, est + e].  Phases:
+//   1. bounds of every list entry into LDS (entries of the compacted prefix [0, cnt0) are exact: lb = ub = their distance);
+//   2. U = k-th smallest UPPER bound (bisection over the sortable 32-bit space, ballot counts): at least k entries are <= U,
+//      so the k-th key after this chunk is <= U and every candidate whose LOWER bound is > U can be dropped unrescored;
+//   3. the survivors are packed and rescored 64 at a time: ascending-k fmaf chain over the prepared fp32 rows (the chain the
+//      fp32 MFMA accumulator performs), canonical epilogue, 64-bit key written back in place; dropped entries become ~0
+//      (the sentinel compaction already sorts last).
 template <int METRIC>
 __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams p)
 {
-    const int lane = threadIdx.x & 63;
-    const long long q = (long long)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    extern __shared__ __attribute__((aligned(16))) u32 rs_dyn[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const long long q = (long long)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + wv));
+    u32* s_ub = rs_dyn + (size_t)wv * 2 * p.cap;          // later: the packed survivor slots
+    u32* s_lb = s_ub + p.cap;
     const u32 start = p.cnt0[q];
     u32 end = p.cnt[q];
     if (end > (u32)p.cap) end = (u32)p.cap;
@@ -1062,9 +1082,62 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
     const float* __restrict__ qrow = p.qp + q * p.dp;
     const float qn = p.qn[q];
     u64* list = p.buf + q * p.cap;
-    for (u32 e0 = start; e0 < end; e0 += 64) {
-        const u32 e = e0 + lane;
-        const bool live = e < end;
+
+    u32 nsurv = 0;
+    if (p.prune && end >= (u32)p.k) {
+        const float row_err = p.eps_half * qn + p.ab * sqrtf(qn) + p.cst;
+        for (u32 e0 = 0; e0 < end; e0 += 64) {
+            const u32 e = e0 + lane;
+            if (e < end) {
+                const u64 key = list[e];
+                if (e < start) { s_ub[e] = (u32)(key >> 32); s_lb[e] = 0u; }
+                else {
+                    const float est = __uint_as_float((u32)(key >> 32));
+                    const float bn = p.bn[(u32)key];
+                    float err = row_err + p.eps_half * bn + p.aq * sqrtf(bn);          // >= |dot16 - dot32|
+                    if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) err = 2.0f * err;
+                    err = err * 1.0001f + 2.0e-6f * (fabsf(est) + qn + bn + 1.0f);       // roundings of est and of these lines
+                    float ub = est + err;
+                    if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ub = fmaxf(ub, 0.0f);       // the canonical distance is clamped at 0
+                    s_ub[e] = sortable_u32(ub);
+                    s_lb[e] = sortable_u32(est - err);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        u32 lo = 0u, hi = 0xFFFFFFFFu;
+        while (lo < hi) {                                   // smallest x with  #{ub <= x} >= k   (wave-uniform)
+            const u32 mid = lo + ((hi - lo) >> 1);
+            u32 c = 0;
+            for (u32 e0 = 0; e0 < end; e0 += 64) {
+                const u32 e = e0 + lane;
+                c += (u32)__popcll(__ballot(e < end && s_ub[e] <= mid));
+            }
+            if (c >= (u32)p.k) hi = mid; else lo = mid + 1u;
+        }
+        const u32 U = lo;
+        __builtin_amdgcn_wave_barrier();
+        for (u32 e0 = start; e0 < end; e0 += 64) {
+            const u32 e = e0 + lane;
+            const bool live = e < end;
+            const bool keep = live && s_lb[e] <= U;
+            const u64 mk = __ballot(keep);
+            const u32 pos = nsurv + (u32)__popcll(mk & ((1ull << lane) - 1ull));
+            __builtin_amdgcn_wave_barrier();
+            if (keep) s_ub[pos] = e;                        // s_ub is free after the bisection: it now holds the packed survivor slots
+            else if (live) list[e] = ~0ull;
+            nsurv += (u32)__popcll(mk);
+        }
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        nsurv = end - start;
+    }
+    const bool packed = p.prune && end >= (u32)p.k;
+
+    for (u32 i0 = 0; i0 < nsurv; i0 += 64) {
+        const u32 i = i0 + lane;
+        const bool live = i < nsurv;
+        const u32 e = live ? (packed ? s_ub[i] : start + i) : start;
         const u32 col = live ? (u32)list[e] : 0u;
         const float* __restrict__ brow = p.bp + (long long)col * p.dp;
         float acc = 0.0f;
@@ -1424,9 +1497,13 @@ hipError_t nwk_launch_tile_prescreen(hipStream_t st, NwkTileParams p, int metric
 hipError_t nwk_launch_rescore(hipStream_t st, const NwkRescoreParams& p, int metric, long long nq_pad)
 {
     if (nq_pad <= 0) return hipSuccess;
-    const unsigned grid = (unsigned)((nq_pad + 3) / 4);          // nq_pad is a multiple of 256
-    if (metric == NWKNN_METRIC_SQEUCLIDEAN) hipLaunchKernelGGL((nwk_rescore_kernel<NWKNN_METRIC_SQEUCLIDEAN>), dim3(grid), dim3(256), 0, st, p);
-    else if (metric == NWKNN_METRIC_ONE_MINUS_DOT) hipLaunchKernelGGL((nwk_rescore_kernel<NWKNN_METRIC_ONE_MINUS_DOT>), dim3(grid), dim3(256), 0, st, p);
+    const int waves = p.cap <= 1024 ? 4 : (p.cap <= 2048 ? 2 : 1);         // nq_pad is a multiple of 256
+    const unsigned grid = (unsigned)(nq_pad / waves);
+    const size_t lds = (size_t)waves * p.cap * 8 + 512;        // + slack: predicated-off lanes may still address past `end`
+    if (metric == NWKNN_METRIC_SQEUCLIDEAN)
+        hipLaunchKernelGGL((nwk_rescore_kernel<NWKNN_METRIC_SQEUCLIDEAN>), dim3(grid), dim3(64 * waves), lds, st, p);
+    else if (metric == NWKNN_METRIC_ONE_MINUS_DOT)
+        hipLaunchKernelGGL((nwk_rescore_kernel<NWKNN_METRIC_ONE_MINUS_DOT>), dim3(grid), dim3(64 * waves), lds, st, p);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -20,7 +20,8 @@ sqeuclidean, cosine, 1 - dot (cu_knn.py:243-262).
 Keyword-only additions (defaults keep the reference behaviour): ``metric`` (overrides ``engine``), ``dtype``
 ('fp32' bit-exact | 'fp16' MFMA path), ``device`` / ``devices`` (base tiles are dealt round-robin to the listed GPUs,
 one engine and one host thread per GPU -- the reference is pinned to GPU 0, cu_knn.py:65), ``resume`` (skip base tiles
-whose partial pair already exists; the reference always recomputes).
+whose partial pair already exists; the reference always recomputes), ``prescreen`` (fp32 results, bit for bit,
+through the fp16 MFMA pre-screen + fp32 rescoring of KnnEngine.set_prescreen).
 """
 from __future__ import annotations
 
@@ -181,7 +182,8 @@ def compute_knn(data_dir,
                 dtype: str = 'fp32',
                 device: int = 0,
                 devices: Optional[Sequence[int]] = None,
-                resume: bool = False):
+                resume: bool = False,
+                prescreen: bool = False):
     batch_size = initial_batch_size
     print("-- prepare query source table for brute-force KNN computation.")
     query_table = prep_table(data_dir, model_name, query_filename, query_count, dimensions)
@@ -196,7 +198,7 @@ def compute_knn(data_dir,
         f"Cannot generate k of {k} with only {len(base_table)} rows and batch_size of {batch_size}."      # cu_knn.py:177-178
 
     process_batches(data_dir, base_table, query_table, batch_count, batch_size, k, split, engine, metric=metric, dtype=dtype,
-                    device=device, devices=devices, resume=resume)
+                    device=device, devices=devices, resume=resume, prescreen=prescreen)
 
 
 def _partial_pair_exists(data_dir, i, rows) -> bool:
@@ -221,7 +223,8 @@ def process_batches(data_dir,
                     dtype: str = 'fp32',
                     device: int = 0,
                     devices: Optional[Sequence[int]] = None,
-                    resume: bool = False):
+                    resume: bool = False,
+                    prescreen: bool = False):
     """One partial (distances, indices) parquet pair per base tile (cu_knn.py:193-287)."""
     metric = resolve_metric(metric, engine)
     devices = list(devices) if devices else [device]
@@ -231,6 +234,7 @@ def process_batches(data_dir,
         # tiles slot, slot+n, slot+2n, ... on GPU devices[slot]; engines are per (device, slot) so that two slots may share a device
         eng: KnnEngine = default_engine(devices[slot]) if len(devices) == 1 else KnnEngine(devices[slot])
         eng.set_compute_dtype(dtype)
+        eng.set_prescreen(prescreen)
         try:
             for start in range(slot, batch_count, len(devices)):
                 batch_offset = start * batch_size
@@ -250,6 +254,7 @@ def process_batches(data_dir,
                 cleanup(dataset, distances, indices)
         finally:
             eng.set_compute_dtype('fp32')
+            eng.set_prescreen(False)
             if len(devices) > 1:
                 eng.close()
 

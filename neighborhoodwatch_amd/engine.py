@@ -103,6 +103,12 @@ class KnnEngine:
         Takes effect at the next set_base."""
         self.set_option("compute_dtype", {"f32": DTYPE_F32, "fp32": DTYPE_F32, "f16": DTYPE_F16, "fp16": DTYPE_F16}[dtype])
 
+    def set_prescreen(self, on: bool) -> None:
+        """fp32 searches (sqeuclidean / one_minus_dot) run an fp16 MFMA pre-screen over scaled fp16 copies of both sides and
+        rescore every listed pair with the canonical fp32 chain: the SAME bits out as the direct fp32 kernel, several times
+        faster (DESIGN.md "pre-screen").  Costs an extra fp16 copy of the base in HBM.  Takes effect at the next set_base."""
+        self.set_option("prescreen", 1 if on else 0)
+
     def set_base(self, dataset) -> None:
         ptr, rows, dim, dt, loc, keep = self._matrix(dataset, "dataset")
         if rows == 0 or dim == 0:
@@ -311,12 +317,17 @@ def default_engine(device: int = 0) -> KnnEngine:
     return eng
 
 
-def knn(dataset, queries, k: int, metric: Optional[str] = None, engine: Optional[str] = None, device: int = 0) -> Tuple:
+def knn(dataset, queries, k: int, metric: Optional[str] = None, engine: Optional[str] = None, device: int = 0,
+        prescreen: bool = False) -> Tuple:
     """Drop-in for ``pylibraft.neighbors.brute_force.knn(dataset, queries, k)`` as used at cu_knn.py:243-245:
     returns ``(distances float32 [q,k], indices int64 [q,k])``, ascending, indices local to ``dataset``."""
     eng = default_engine(device)
-    eng.set_base(dataset)
-    return eng.search(queries, k, resolve_metric(metric, engine))
+    eng.set_prescreen(prescreen)
+    try:
+        eng.set_base(dataset)
+        return eng.search(queries, k, resolve_metric(metric, engine))
+    finally:
+        eng.set_prescreen(False)
 
 
 def device_count() -> int:

@@ -76,6 +76,8 @@ Some example commands:\n
     parser.add_argument('--devices', type=lambda s: [int(x) for x in s.split(',')], default=None,
                         help='comma separated GPU ids: base tiles are dealt round-robin to them')
     parser.add_argument('--dtype', choices=['fp32', 'fp16'], default='fp32', help='compute path (fp32 is bit-exact; fp16 uses the fp16 MFMA kernel)')
+    parser.add_argument('--prescreen', action='store_true',
+                        help='fp32 results bit for bit, several times faster: fp16 MFMA pre-screen + canonical fp32 rescoring')
     parser.add_argument('--resume', action='store_true', help='keep existing partial files and skip their base tiles')
     return parser
 
@@ -119,7 +121,7 @@ def main(argv=None):
     else:
         compute_knn(data_dir, args.model_name, output_dimension, query_filename, args.query_count, base_filename,
                     args.base_count, args.enable_memory_tuning, args.k, engine=args.engine, device=args.device,
-                    devices=args.devices, dtype=args.dtype, resume=args.resume)
+                    devices=args.devices, dtype=args.dtype, resume=args.resume, prescreen=args.prescreen)
     print(f"(Duration: {time.time() - section:.2f} seconds out of {time.time() - start_time:.2f} seconds)")
 
     print("Merging indices and distances ......")

@@ -111,9 +111,10 @@ def test_merge_drops_rownum_and_handles_many_lists(tmp_path, oracle):
     assert np.array_equal(_arr(fi, np.int64), ri) and np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
 
 
-def test_cli_end_to_end(tmp_path, oracle):
+@pytest.mark.parametrize("extra", [[], ["--prescreen"]])
+def test_cli_end_to_end(tmp_path, oracle, extra):
     from neighborhoodwatch_amd.neighborhoodwatch import main
-    assert main(["200", "3000", "-k", "20", "-m", "intfloat/e5-small-v2", "--data-dir", str(tmp_path), "--disable-memory-tuning"]) == 0
+    assert main(["200", "3000", "-k", "20", "-m", "intfloat/e5-small-v2", "--data-dir", str(tmp_path), "--disable-memory-tuning"] + extra) == 0
     data_dir = nw_utils.get_model_data_homedir(str(tmp_path), "intfloat/e5-small-v2", 200, 3000, 20)
     fd, fi = _final(data_dir)
     base = synth.gen_rows(synth.SEED_BASE, 0, 3000, 384); queries = synth.gen_rows(synth.SEED_QUERY, 0, 200, 384)
