@@ -89,7 +89,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = 3, opt_prescreen = 0, opt_pre_prune = 1;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = 3, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = 1, opt_pre_eps_pct = 100;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -223,6 +223,11 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
         h->opt_compute_f16 = value;      // takes effect at the next nwknn_set_base
     } else if (!strcmp(name, "prescreen")) {
         h->opt_prescreen = value ? 1 : 0;   // takes effect at the next nwknn_set_base (it builds the fp16 copy of the base)
+    } else if (!strcmp(name, "pre_eps_pct")) {
+        h->opt_pre_eps_pct = value;         // dev: scales the pre-screen error bound (results are only guaranteed at >= 100)
+    } else if (!strcmp(name, "f16_mfma")) {
+        if (value != 0 && value != 1) return fail(NWKNN_EINVAL, "f16_mfma must be 0 (32x32x16) or 1 (16x16x32)");
+        h->opt_f16_shape = value;
     } else if (!strcmp(name, "prescreen_prune")) {
         h->opt_pre_prune = value ? 1 : 0;   // dev: 0 rescoring every listed pair (A/B of the bound-based pruning)
     } else if (!strcmp(name, "super_q_shift")) {
@@ -440,6 +445,7 @@ static NwkTileParams tile_params(nwknn_ctx* h, const SearchPlan& pl, long long n
     p.n_qtiles = (int)(nq_pad / pl.tile_rows);
     p.dp = h->dp; p.cap = pl.cap;
     p.sq_shift = (int)h->opt_sq_shift;
+    p.f16_shape = (int)h->opt_f16_shape;
     p.dbg = h->opt_dbg_ptr ? (unsigned long long*)(uintptr_t)h->opt_dbg_ptr : nullptr;
     return p;
 }
@@ -610,12 +616,11 @@ static int search_common(nwknn_ctx* h, const void* queries, const void* const* q
             HIPCHK(hipMemsetAsync(h->cnt0.p, 0, (size_t)nq_pad * 4, h->stream));
             const double u = 0x1p-24, dd = (double)h->dp16;
             // input rounding (1+2^-11)^2-1, the canonical chain (d u), the fp16 MFMA accumulation (allowed 4 d u), 2 % slack
-            // + the column term that rides in the accumulator: 4 u (|c| + sum|products|) per MFMA step, dd/16 steps
-            const double eps = 1.02 * (0x1p-10 * (1.0 + 0x1p-11) + 5.5 * dd * u + 4.0 * (dd / 16.0 + 1.0) * u);
+            const double eps = 1.02 * (0x1p-10 * (1.0 + 0x1p-11) + 5.5 * dd * u);
             const double a_q = 0x1p-14 / (double)q_scale, a_b = 0x1p-14 / (double)h->b_scale;   // absolute error per element
             const double sd = sqrt((double)h->d);
             pl.pre_scale = q_scale * h->b_scale;
-            pl.pre_eps_half = (float)(0.5 * eps);
+            pl.pre_eps_half = (float)(0.5 * eps * (double)h->opt_pre_eps_pct / 100.0);
             pl.pre_aq = (float)(1.01 * a_q * sd);       // times sqrt(|b|^2) >= |b|_1 / sqrt(d)
             pl.pre_ab = (float)(1.01 * a_b * sd);       // times sqrt(|q|^2)
             pl.pre_cst = (float)(1.01 * (double)h->d * a_q * a_b);

@@ -39,6 +39,7 @@ struct NwkTileParams {
     float pre_aq, pre_ab;          // absolute terms: pre_aq * sqrt(|b|^2) and pre_ab * sqrt(|q|^2)
     float pre_cst;
     float pre_inv_scale;           // 1 / pre_scale
+    int f16_shape;                 // fp16 kernels: 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16
 };
 
 struct NwkRescoreParams {

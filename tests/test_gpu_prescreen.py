@@ -160,3 +160,29 @@ def test_k_1000(pre_engine, oracle):
     queries = oracle.gen(0xF2, 0, 40, 128)
     pre_engine.set_base(base)
     _check(pre_engine, oracle, base, queries, 1000, "one_minus_dot")
+
+
+@pytest.mark.parametrize("shape_opt", [0, 1])
+def test_both_fp16_mfma_shapes(oracle, shape_opt):
+    """f16_mfma = 0: v_mfma_f32_32x32x16_f16 tiles, 1 (default): v_mfma_f32_16x16x32_f16 -- pre-screened results are the same bits;
+    on the fp16 compute path the two may differ in the last place of a distance (different summation trees inside the MFMA)."""
+    from neighborhoodwatch_amd import KnnEngine
+    base = oracle.gen(0x91, 0, 9000, 200)
+    queries = oracle.gen(0x92, 0, 300, 200)
+    with KnnEngine(0) as eng:
+        eng.set_option("f16_mfma", shape_opt)
+        eng.set_prescreen(True)
+        eng.set_base(base)
+        for metric in ADDITIVE:
+            dist, idx = eng.search(queries, 40, metric)
+            rd, ri = oracle.knn_canonical(base, queries, 40, metric)
+            assert eng.stats()["prescreen"] == 1
+            assert np.array_equal(idx, ri) and _bitwise(dist, rd)
+        eng.set_prescreen(False)
+        eng.set_compute_dtype("fp16")
+        eng.set_base(base)
+        for metric in ["sqeuclidean", "one_minus_dot", "cosine"]:
+            dist, idx = eng.search(queries, 40, metric)
+            b16 = base.astype(np.float16).astype(np.float32); q16 = queries.astype(np.float16).astype(np.float32)
+            ed = np.sort(oracle.distances_fp64(b16, q16, metric), axis=1)[:, :40]
+            assert np.allclose(dist, ed, rtol=2e-3, atol=2e-3 * float(np.abs(ed).max()))
