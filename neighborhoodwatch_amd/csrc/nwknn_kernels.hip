@@ -391,13 +391,14 @@ __device__ __forceinline__ float prefilter_col(float bn)
 // whose CANONICAL fp32 distance is <= tau_d satisfies  S*dot16 >= S * (row(q) + col(b))  with
 //     sqeuclidean   : row = (qn - tau_d)/2 - eps/2 qn - ab sqrt(qn) - cst,   col = bn/2 - eps/2 bn - aq sqrt(bn)
 //     one_minus_dot : row = (1 - tau_d)    - eps/2 qn - ab sqrt(qn) - cst,   col =        - eps/2 bn - aq sqrt(bn)
-// each lowered by a few ulps of its operands for the fp32 evaluation of these very expressions.
+// each lowered by a few ulps of its operands for the fp32 evaluation of these very expressions (the square roots are bare
+// v_sqrt_f32, 1 ulp: the a_q / a_b constants carry 1 % of slack).
 template <int METRIC>
 __device__ __forceinline__ float prescreen_row(float qn, u64 tau, const NwkTileParams& p)
 {
     if (tau == ~0ull) return -__builtin_inff();
     const float td = unsortable_f32((u32)(tau >> 32));
-    const float err = p.pre_eps_half * qn + p.pre_ab * sqrtf(qn) + p.pre_cst;
+    const float err = p.pre_eps_half * qn + p.pre_ab * __builtin_amdgcn_sqrtf(qn) + p.pre_cst;
     float r;
     if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) r = 0.5f * (qn - td) - err - 2.0e-6f * (fabsf(qn) + fabsf(td)) - 1.0e-30f;
     else r = (1.0f - td) - err - 2.0e-6f * (1.0f + fabsf(td) + err);
@@ -406,7 +407,7 @@ __device__ __forceinline__ float prescreen_row(float qn, u64 tau, const NwkTileP
 template <int METRIC>
 __device__ __forceinline__ float prescreen_col(float bn, const NwkTileParams& p)
 {
-    const float err = p.pre_eps_half * bn + p.pre_aq * sqrtf(bn);
+    const float err = p.pre_eps_half * bn + p.pre_aq * __builtin_amdgcn_sqrtf(bn);
     float c;
     if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) c = 0.5f * bn - err - 2.0e-6f * fabsf(bn);
     else c = -err - 2.0e-6f * err;
@@ -775,14 +776,13 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16(const NwkTileParam
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-    {   // query-side epilogue inputs go to their own LDS region now; the first barrier of the K loop publishes them
-        float my_qn = 0.f;
-        u64 my_tau = ~0ull;
-        if (tid < H_TM) {
-            my_qn = p.qn[q0 + tid];
-            if (!DENSE) my_tau = p.tau[q0 + tid];
-        }
-        stage_query_side<METRIC, DENSE, PRE>(epi, H_TM, tid, my_qn, my_tau, p);
+    // query-side epilogue inputs: the loads go out here, the first two slabs' DMA right behind them (below), and only then
+    // are the values used and staged in their own LDS region -- the first barrier of the K loop publishes them
+    float my_qn = 0.f;
+    u64 my_tau = ~0ull;
+    if (tid < H_TM) {
+        my_qn = p.qn[q0 + tid];
+        if (!DENSE) my_tau = p.tau[q0 + tid];
     }
 
     // Software pipeline: fragment registers are double buffered (set S feeds the MFMAs of k-step s while the ds_reads of
@@ -816,13 +816,13 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16(const NwkTileParam
         __builtin_amdgcn_sched_barrier(0);               \
     } while (0)
 
+    __builtin_amdgcn_sched_barrier(0);
     issue_stage(0, 0);
-    if (nk > 1) {
-        issue_stage(1, 1);
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");       // slab 0 landed; my epilogue-input ds_writes are done
-    } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    }
+    if (nk > 1) issue_stage(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_query_side<METRIC, DENSE, PRE>(epi, H_TM, tid, my_qn, my_tau, p);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");       // slab 0 landed; my epilogue-input ds_writes are done
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (p.dbg) st1 = __builtin_amdgcn_s_memtime();
     read_frags(0, 0, 0);
@@ -909,6 +909,17 @@ __device__ __forceinline__ void tile_epilogue16(const NwkTileParams& p, const f3
                 for (int i = 0; i < 4; ++i) mn |= !(distance_epilogue<METRIC>(acc[m][n][i], qn4[i], bnv[n]) > pre4[i]);
                 maybe |= mn & colok[n];
             }
+        } else if (PRE) {
+            // pre-screen operands are finite by construction, so "some acc >= threshold" can be a running maximum of the
+            // differences (v_max3), with no per-element compare into SGPRs
+            float mx = -__builtin_inff();
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const f32x4 dlt = acc[m][n] - (pre4 + cpre[n]);
+                mx = fmaxf(fmaxf(mx, dlt[0]), dlt[1]);
+                mx = fmaxf(fmaxf(mx, dlt[2]), dlt[3]);
+            }
+            maybe = !(mx < 0.0f);
         } else {
 #pragma unroll
             for (int n = 0; n < 4; ++n)
@@ -964,6 +975,8 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTilePara
     __shared__ __attribute__((aligned(16))) char smem[2 * H_STAGE + H_TM * 16];
     char* const epi = smem + 2 * H_STAGE;
 
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;       // dev stamps (p.dbg): see tools/stamps2.py
+    if (p.dbg) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     const TileCoord tc = tile_from_block(p);
     if (!tc.ok) return;
 
@@ -1007,11 +1020,6 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTilePara
     // column-side epilogue inputs are (re)computed where they are used, so that nothing but the accumulators, the fragment
     // buffers and a few addresses lives across the K loop (256 VGPRs at two waves per SIMD)
     const long long col0 = b0 + wc * 64 + c16;
-    auto col_term = [&](const float* bn_base, int n) -> float {
-        const long long col = col0 + n * 16;
-        const float bn = bn_base[col];
-        return col < p.nb_valid ? (PRE ? prescreen_col<METRIC>(bn, p) : prefilter_col<METRIC>(bn)) : __builtin_inff();
-    };
     f32x4 acc[8][4];
 #pragma unroll
     for (int n = 0; n < 4; ++n)
@@ -1019,14 +1027,11 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTilePara
         for (int m = 0; m < 8; ++m)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[m][n][i] = 0.0f;
-    {
-        float my_qn = 0.f;
-        u64 my_tau = ~0ull;
-        if (tid < H_TM) {
-            my_qn = p.qn[q0 + tid];
-            if (!DENSE) my_tau = p.tau[q0 + tid];
-        }
-        stage_query_side<METRIC, DENSE, PRE>(epi, H_TM, tid, my_qn, my_tau, p);
+    float my_qn = 0.f;                                   // loads out now, used after the first DMAs have been issued
+    u64 my_tau = ~0ull;
+    if (tid < H_TM) {
+        my_qn = p.qn[q0 + tid];
+        if (!DENSE) my_tau = p.tau[q0 + tid];
     }
 
     f16x8 fa[2][4], fb[2][4];
@@ -1058,14 +1063,15 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTilePara
         __builtin_amdgcn_sched_barrier(0);               \
     } while (0)
 
+    __builtin_amdgcn_sched_barrier(0);
     issue_stage(0, 0);
-    if (nk > 1) {
-        issue_stage(1, 1);
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    }
+    if (nk > 1) issue_stage(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_query_side<METRIC, DENSE, PRE>(epi, H_TM, tid, my_qn, my_tau, p);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (p.dbg) st1 = __builtin_amdgcn_s_memtime();
     read_A(0, 0, 0, 0);
     read_B(0, 0, 0);
 
@@ -1079,6 +1085,9 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTilePara
         if (kt + 2 < nk) issue_stage(cur, kt + 2);
         NWK_SPHASE(1, 1, 1, read_A(0, cur ^ 1, 0, 0); read_B(0, cur ^ 1, 0));
     }
+    float bnv[4];                                        // column norms: requested under the last slab's MFMAs
+#pragma unroll
+    for (int n = 0; n < 4; ++n) bnv[n] = p.bn[col0 + n * 16];
     {
         const int cur = (nk - 1) & 1;
         NWK_SPHASE(0, 0, 0, read_A(1, cur, 0, 1));
@@ -1088,8 +1097,9 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTilePara
         mma(1, 1, 1, 0, 4);
     }
 #undef NWK_SPHASE
+    if (p.dbg) st2 = __builtin_amdgcn_s_memtime();
 
-    float bnv[4], cpre[4];
+    float cpre[4];
     u32 colv[4];
     bool colok[4];
 #pragma unroll
@@ -1097,11 +1107,25 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTilePara
         const long long col = col0 + n * 16;
         colv[n] = (u32)col;
         colok[n] = col < p.nb_valid;
-        bnv[n] = p.bn[col];
-        cpre[n] = col_term(p.bn, n);
+        const float c = PRE ? prescreen_col<METRIC>(bnv[n], p) : prefilter_col<METRIC>(bnv[n]);
+        cpre[n] = colok[n] ? c : __builtin_inff();
     }
     tile_epilogue16<METRIC, DENSE, PRE>(p, acc, (const float*)epi, (const u64*)(epi + H_TM * 4), (const float*)(epi + H_TM * 12), bnv, colv,
                                         colok, cpre, q0, wr * 128, g, c16);
+    if (p.dbg && l == 0) {          // wave 0 writes its own stamps; every wave folds its end times in (the tile ends with its last wave)
+        unsigned long long* o = p.dbg + (size_t)blockIdx.x * 8;
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime(), r3 = __builtin_amdgcn_s_memrealtime();
+        if (w == 0) {
+            o[0] = st0; o[1] = st1; o[2] = st2; o[4] = rt0;
+            o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32      // HW_REG_XCC_ID[3:0]
+                 | (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));           // HW_REG_HW_ID
+            o[7] = 1;
+        }
+        atomicMax(o + 3, t3);
+        atomicMax(o + 5, r3);
+        unsigned long long* o2 = p.dbg + (size_t)gridDim.x * 8 + (size_t)blockIdx.x * 16 + w * 2;     // per wave: end of its K loop, end of its epilogue
+        o2[0] = st2; o2[1] = t3;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1321,7 +1345,7 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
 
     u32 nsurv = 0;
     if (p.prune && end >= (u32)p.k) {
-        const float row_err = p.eps_half * qn + p.ab * sqrtf(qn) + p.cst;
+        const float row_err = p.eps_half * qn + p.ab * __builtin_amdgcn_sqrtf(qn) + p.cst;
         for (u32 e0 = 0; e0 < end; e0 += 64) {
             const u32 e = e0 + lane;
             if (e < end) {
@@ -1330,7 +1354,7 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
                 else {
                     const float est = __uint_as_float((u32)(key >> 32));
                     const float bn = p.bn[(u32)key];
-                    float err = row_err + p.eps_half * bn + p.aq * sqrtf(bn);          // >= |dot16 - dot32|
+                    float err = row_err + p.eps_half * bn + p.aq * __builtin_amdgcn_sqrtf(bn);          // >= |dot16 - dot32|
                     if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) err = 2.0f * err;
                     err = err * 1.0001f + 2.0e-6f * (fabsf(est) + qn + bn + 1.0f);       // roundings of est and of these lines
                     float ub = est + err;
