@@ -226,7 +226,7 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
     } else if (!strcmp(name, "pre_eps_pct")) {
         h->opt_pre_eps_pct = value;         // dev: scales the pre-screen error bound (results are only guaranteed at >= 100)
     } else if (!strcmp(name, "f16_mfma")) {
-        if (value != 0 && value != 1) return fail(NWKNN_EINVAL, "f16_mfma must be 0 (32x32x16) or 1 (16x16x32)");
+        if (value < 0 || value > 2) return fail(NWKNN_EINVAL, "f16_mfma must be 0 (32x32x16), 1 (16x16x32) or 2 (16x16x32, two 4-wave workgroups per CU)");
         h->opt_f16_shape = value;
     } else if (!strcmp(name, "prescreen_prune")) {
         h->opt_pre_prune = value ? 1 : 0;   // dev: 0 rescoring every listed pair (A/B of the bound-based pruning)
@@ -466,7 +466,7 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
 {
     NwkTileParams tp = tile_params(h, pl, nq_pad);
     const bool prescreen = pl.pre && !dense;               // the dense first chunk of a pre-screened search runs the fp32 kernel
-    const int btile = (h->f16 || prescreen) ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS;
+    const int btile = ((h->f16 || prescreen) && h->opt_f16_shape != 2) ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS;   // f16_mfma=2: 256 x 128 tiles
     tp.bt0 = (int)(lo / btile);
     tp.n_btiles = (int)(rows / btile);
     tp.dense_col0 = lo;

@@ -1129,6 +1129,167 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTilePara
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp16 distance tile, "two workgroups per CU" form (option f16_mfma = 2).  The 8-wave kernels above keep ONE workgroup per CU:
+// its prologue (first DMA round trip), its epilogue and the dispatch gap to the next workgroup leave the MFMA pipes idle for
+// ~25 % of a d=1024 tile (tools/stamps2.py), and both waves of a SIMD stall at the same barriers.  Here a workgroup is 4 waves
+// (2 x 2, a wave still owns 128 x 64 = 8 x 4 accumulators of v_mfma_f32_16x16x32_f16) on a 256 x 128 tile with 32-half slabs
+// (64-B LDS rows, one k-step per slab) in a THREE-stage ring of 24 KiB: 76 KiB per workgroup, so two INDEPENDENT workgroups
+// share a CU, one wave of each per SIMD, and one's barriers / prologue / epilogue overlap the other's MFMAs.
+//   LDS image: row r, 16-B chunk c at slot c ^ f(r), f(r) = (-(r >> 2)) & 3: ds_read_b128 by (row l%16, chunk l/16) is
+//   conflict-free (each 16-lane service group covers all 64 banks once).
+//   Ring: the DMA of slab t+3 goes into the stage slab t is leaving, right behind the barrier in the middle of slab t (every wave
+//   has then finished reading it); that barrier also publishes slab t+1, which was issued two slabs earlier (vmcnt(6): 6 DMA
+//   instructions per wave and slab: 4 x A, 2 x B).
+// ------------------------------------------------------------------------------------------------
+#define Q_TM 256
+#define Q_TN 128
+#define Q_BK 32
+#define Q_STAGE (Q_TM * 64 + Q_TN * 64)        // 24 KiB
+#define Q_NST 3
+
+template <int METRIC, bool DENSE, int PRE = 0>
+__global__ __launch_bounds__(256, 2) void nwk_tile_kernel_f16q(const NwkTileParams p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[Q_NST * Q_STAGE + Q_TM * 16];
+    char* const epi = smem + Q_NST * Q_STAGE;
+
+    const TileCoord tc = tile_from_block(p);
+    if (!tc.ok) return;
+
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, l = tid & 63;
+    const int wr = w >> 1, wc = w & 1;
+    const int g = l >> 4, c16 = l & 15;
+    const long long q0 = (long long)tc.qt * Q_TM;
+    const long long b0 = (long long)tc.bt * Q_TN;
+    const int dp = p.dp;
+    const int nk = dp / Q_BK;                                // even: dp is a multiple of 64
+    const _Float16* qp = (const _Float16*)p.qp;
+    const _Float16* bp = (const _Float16*)p.bp;
+
+    // DMA: one wave-instruction = 16 rows x 64 B (4 lanes per row).  Wave w brings A rows [64w, 64w+64) and B rows [32w, 32w+32).
+    // The swizzle term f(row) depends on (row >> 2) & 3 = (l >> 4) & 3 only (row origins are multiples of 16), so ONE per-lane
+    // offset serves every instruction and the row origin goes into the scalar offset with the slab position.
+    const unsigned voff = (unsigned)((l >> 2) * dp * 2 + (((l & 3) ^ ((0 - (l >> 4)) & 3)) << 4));
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(qp + q0 * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(bp + b0 * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int lds_wA = wu * 4096;
+    const int lds_wB = Q_TM * 64 + wu * 2048;
+    const int rowsA = wu * 64 * dp * 2, rowsB = wu * 32 * dp * 2, step16 = 16 * dp * 2;      // byte offsets of row origins (SGPRs)
+    auto issue_slab = [&](int kt) {
+        char* st = smem + (kt % Q_NST) * Q_STAGE;
+        const int soff = kt * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(st + lds_wA + i * 1024), 16, voff, soff + rowsA + i * step16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(st + lds_wB + i * 1024), 16, voff, soff + rowsB + i * step16, 0, 0);
+    };
+
+    const int swz = (0 - (c16 >> 2)) & 3;
+    const int offA0 = (wr * 128 + c16) * 64 + ((g ^ swz) << 4);
+    const int offB0 = Q_TM * 64 + (wc * 64 + c16) * 64 + ((g ^ swz) << 4);
+    const long long col0 = b0 + wc * 64 + c16;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[m][n][i] = 0.0f;
+
+    float my_qn = p.qn[q0 + tid];                            // 256 threads = 256 query rows
+    u64 my_tau = ~0ull;
+    if (!DENSE) my_tau = p.tau[q0 + tid];
+
+    f16x8 fa[2][4], fb[2][4];
+    auto read_A = [&](int buf, int kt, int mh) {
+        const char* sb = smem + (kt % Q_NST) * Q_STAGE + offA0 + mh * 4 * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fa[buf][j] = *(const f16x8*)(sb + j * 1024);
+    };
+    auto read_B = [&](int set, int kt) {
+        const char* sb = smem + (kt % Q_NST) * Q_STAGE + offB0;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) fb[set][n] = *(const f16x8*)(sb + n * 1024);
+    };
+    auto mma = [&](int abuf, int bset, int mh, int j0, int j1) {
+#pragma unroll
+        for (int j = j0; j < j1; ++j)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                acc[mh * 4 + j][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[abuf][j], fb[bset][n], acc[mh * 4 + j][n], 0, 0, 0);
+    };
+#define NWK_QPHASE(ABUF, BSET, MH, LOADS)                \
+    do {                                                 \
+        __builtin_amdgcn_sched_barrier(0);               \
+        mma(ABUF, BSET, MH, 0, 1);                       \
+        __builtin_amdgcn_sched_barrier(0);               \
+        LOADS;                                           \
+        __builtin_amdgcn_sched_barrier(0);               \
+        mma(ABUF, BSET, MH, 1, 4);                       \
+        __builtin_amdgcn_sched_barrier(0);               \
+    } while (0)
+    // one slab: rows 0-63 of the wave's tile, barrier + restage, rows 64-127 (during which the next slab's first fragments load).
+    // No MFMA sits inside a runtime branch (that would make the compiler copy accumulators): the last slab is peeled.
+#define NWK_QSLAB(KT, BSET)                                                                          \
+    do {                                                                                             \
+        NWK_QPHASE(0, BSET, 0, read_A(1, (KT), 1));                                                  \
+        if ((KT) + 2 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");               \
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                             \
+        __builtin_amdgcn_s_barrier();                                                                \
+        if ((KT) + 3 < nk) issue_slab((KT) + 3);                                                     \
+        NWK_QPHASE(1, BSET, 1, read_A(0, (KT) + 1, 0); read_B((BSET) ^ 1, (KT) + 1));                \
+    } while (0)
+
+    __builtin_amdgcn_sched_barrier(0);
+    issue_slab(0);
+    issue_slab(1);                                           // nk >= 2
+    if (nk > 2) issue_slab(2);
+    __builtin_amdgcn_sched_barrier(0);
+    stage_query_side<METRIC, DENSE, PRE>(epi, Q_TM, tid, my_qn, my_tau, p);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");     // slab 0 landed; my epilogue-input ds_writes are done
+    else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_A(0, 0, 0);
+    read_B(0, 0);
+
+    for (int kt = 0; kt + 2 < nk; kt += 2) {
+        NWK_QSLAB(kt, 0);
+        NWK_QSLAB(kt + 1, 1);
+    }
+    NWK_QSLAB(nk - 2, 0);
+    {                                                        // last slab (odd index: B set 1), nothing left to stage or prefetch
+        NWK_QPHASE(0, 1, 0, read_A(1, nk - 1, 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, 1, 1, 0, 4);
+    }
+#undef NWK_QSLAB
+#undef NWK_QPHASE
+
+    float bnv[4], cpre[4];
+    u32 colv[4];
+    bool colok[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const long long col = col0 + n * 16;
+        colv[n] = (u32)col;
+        colok[n] = col < p.nb_valid;
+        bnv[n] = p.bn[col];
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const float c = PRE ? prescreen_col<METRIC>(bnv[n], p) : prefilter_col<METRIC>(bnv[n]);
+        cpre[n] = colok[n] ? c : __builtin_inff();
+    }
+    tile_epilogue16<METRIC, DENSE, PRE>(p, acc, (const float*)epi, (const u64*)(epi + Q_TM * 4), (const float*)(epi + Q_TM * 12), bnv, colv,
+                                        colok, cpre, q0, wr * 128, g, c16);
+}
+
+// ------------------------------------------------------------------------------------------------
 // MaxSim late interaction (BASELINE config 5; NOT in the reference -- its `ck` is flat token-level kNN):
 //     score(query, doc) = sum over the query's TQK tokens of  max over the doc's TDK tokens of  (q_token . d_token)
 // and the k docs with the highest score per query.  One workgroup multiplies 256 doc-token rows (4 docs of 64 tokens)
@@ -1684,6 +1845,11 @@ hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool den
 template <int METRIC>
 static hipError_t launch_tile_f16_metric(hipStream_t st, const NwkTileParams& p, bool dense, unsigned grid, int diag)
 {
+    if (p.f16_shape == 2 && diag == 0) {                   // 4-wave workgroups on 256 x 128 tiles, two per CU
+        if (dense) hipLaunchKernelGGL((nwk_tile_kernel_f16q<METRIC, true, 0>), dim3(grid), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((nwk_tile_kernel_f16q<METRIC, false, 0>), dim3(grid), dim3(256), 0, st, p);
+        return hipGetLastError();
+    }
     if (p.f16_shape == 1 && diag == 0) {                   // v_mfma_f32_16x16x32_f16 form
         if (dense) hipLaunchKernelGGL((nwk_tile_kernel_f16s<METRIC, true, 0>), dim3(grid), dim3(512), 0, st, p);
         else hipLaunchKernelGGL((nwk_tile_kernel_f16s<METRIC, false, 0>), dim3(grid), dim3(512), 0, st, p);
@@ -1702,7 +1868,8 @@ static hipError_t launch_tile_f16_metric(hipStream_t st, const NwkTileParams& p,
     return hipGetLastError();
 }
 
-// fp16 path: p.n_qtiles and p.n_btiles both count 256-row tiles; p.bt0 is in 256-row units; p.qp/p.bp point at halves.
+// fp16 path: p.n_qtiles counts 256-row query tiles; p.n_btiles / p.bt0 count base tiles of 256 rows (f16_shape 0, 1) or 128 rows
+// (f16_shape 2); p.qp/p.bp point at halves.
 hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool dense, int diag)
 {
     if (p.n_qtiles <= 0 || p.n_btiles <= 0) return hipSuccess;
@@ -1751,6 +1918,14 @@ hipError_t nwk_launch_tile_prescreen(hipStream_t st, NwkTileParams p, int metric
     supers = (supers + 7) / 8 * 8;
     const long long grid = supers * 64;
     if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    if (p.f16_shape == 2) {
+        if (metric == NWKNN_METRIC_SQEUCLIDEAN)
+            hipLaunchKernelGGL((nwk_tile_kernel_f16q<NWKNN_METRIC_SQEUCLIDEAN, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, p);
+        else if (metric == NWKNN_METRIC_ONE_MINUS_DOT)
+            hipLaunchKernelGGL((nwk_tile_kernel_f16q<NWKNN_METRIC_ONE_MINUS_DOT, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, p);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if (metric == NWKNN_METRIC_SQEUCLIDEAN) {
         if (p.f16_shape == 1) hipLaunchKernelGGL((nwk_tile_kernel_f16s<NWKNN_METRIC_SQEUCLIDEAN, false, 1>), dim3((unsigned)grid), dim3(512), 0, st, p);
         else hipLaunchKernelGGL((nwk_tile_kernel_f16<NWKNN_METRIC_SQEUCLIDEAN, false, 0, 1>), dim3((unsigned)grid), dim3(512), 0, st, p);
