@@ -186,3 +186,26 @@ def test_both_fp16_mfma_shapes(oracle, shape_opt):
             b16 = base.astype(np.float16).astype(np.float32); q16 = queries.astype(np.float16).astype(np.float32)
             ed = np.sort(oracle.distances_fp64(b16, q16, metric), axis=1)[:, :40]
             assert np.allclose(dist, ed, rtol=2e-3, atol=2e-3 * float(np.abs(ed).max()))
+
+
+@pytest.mark.parametrize("d", [256, 1024, 4096])
+def test_fp16_mfma_accumulation_error_is_far_inside_the_allowance(oracle, d):
+    """The pre-screen bound allows the fp16 MFMA's (architecturally unspecified) internal summation an error of 4*d*u*sum|products|,
+    u = 2^-24.  Measured here on the fp16 compute path (same kernel, same MFMA): 1 - dist recovers dot16; it is compared with the
+    float64 dot product of the SAME fp16-rounded operands.  The epilogue's own rounding (u*|1-dot|) is charged to the error too."""
+    from neighborhoodwatch_amd import KnnEngine
+    rng = np.random.default_rng(d)
+    base = (rng.standard_normal((1024, d)) * 8.0).astype(np.float16)
+    queries = (rng.standard_normal((256, d)) * 8.0).astype(np.float16)
+    with KnnEngine(0) as eng:
+        eng.set_base(base)                                      # fp16 input selects the fp16 compute path
+        dist, idx = eng.search(queries, 1024, "one_minus_dot")   # k = B: every pair comes back
+    b64, q64 = base.astype(np.float64), queries.astype(np.float64)
+    exact = q64 @ b64.T
+    sum_abs = np.abs(q64) @ np.abs(b64).T
+    got = 1.0 - dist.astype(np.float64)                      # dot16 of pair (q, idx[q, j])
+    err = np.abs(got - np.take_along_axis(exact, idx, 1))
+    unit = 2.0 ** -24 * np.take_along_axis(sum_abs, idx, 1)
+    ratio = float((err / unit).max())
+    assert ratio < 0.25 * 4 * d, f"fp16 MFMA accumulation error {ratio:.1f} u*sum|products| is not far inside the allowance {4 * d}"
+    print(f"d={d}: max accumulation error {ratio:.2f} x u*sum|products| (allowance {4 * d})")
