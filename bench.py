@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prescreen", action="store_true", help="skip the second measurement (fp16 pre-screen + fp32 rescoring)")
     ap.add_argument("--verify", action="store_true", help="compare the merged result with a single-engine search of the whole base (small workloads)")
+    ap.add_argument("--metric", default=None, choices=["sqeuclidean", "one_minus_dot", "cosine"], help="override the workload's metric (dev)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option (nwknn_set_option), dev use")
     args = ap.parse_args()
 
@@ -124,6 +125,9 @@ def main():
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
     Q, B, d, k, metric, dtype, desc = WORKLOADS[args.workload]
+    if args.metric and metric != "maxsim":
+        metric = args.metric
+        desc += f" [metric overridden: {metric}]"
     peak = MFMA_PEAK_TFLOPS[dtype]
     lo, hi = shard_bounds(B, world, rank)
     eng = KnnEngine(dev_index, profile=True)
@@ -195,7 +199,7 @@ def main():
 
     # the same job through the fp16 pre-screen + fp32 rescoring (engine option "prescreen"): results must be the same bits
     pre = None
-    if not maxsim and dtype == "f32" and metric != "cosine" and not args.no_prescreen and not any("prescreen" in o for o in args.opt):
+    if not maxsim and dtype == "f32" and not args.no_prescreen and not any("prescreen" in o for o in args.opt):
         direct = (last[0].clone(), last[1].clone()) if rank == 0 else None
         eng.set_prescreen(True)
         p_elapsed, p_agg, p_flops, p_ms, p_last = measure()

@@ -89,10 +89,11 @@ int nwknn_set_stream(nwknn_handle h, void* hip_stream);
  * (base rows per launch, multiples of 128), "profile" (0/1: per-kernel HIP-event timing into nwknn_stats),
  * "compute_dtype" (NWKNN_DTYPE_F32 | NWKNN_DTYPE_F16: with F16 the next nwknn_set_base rounds fp32 input to fp16 and
  * distance tiles run on the fp16 MFMA path with fp32 accumulation), "tile_rows" (0 auto | 128 | 256, fp32 path),
- * "prescreen" (0/1, fp32 compute path, sqeuclidean and one_minus_dot: the next nwknn_set_base also keeps a scaled fp16 copy of
+ * "prescreen" (0/1, fp32 compute path, all three metrics: the next nwknn_set_base also keeps a scaled fp16 copy of
  * the base; searches then filter with the fp16 MFMA kernel under a conservative error bound and rescore every listed pair
  * with the canonical fp32 chain -- the same bits out as with 0, several times faster; nwknn_stats.prescreen reports whether a
- * search used it: cosine, non-finite or extreme-magnitude inputs fall back to the direct kernel). */
+ * search used it: non-finite or extreme-magnitude inputs fall back to the direct kernel),
+ * "f16_mfma" (fp16 tile kernel build: 1 = v_mfma_f32_16x16x32_f16, default; 0 = 32x32x16; 2 = two 4-wave workgroups per CU). */
 int nwknn_set_option(nwknn_handle h, const char* name, int64_t value);
 int nwknn_get_stats(nwknn_handle h, nwknn_stats* out);
 /* Wait for everything queued on the handle's stream. */

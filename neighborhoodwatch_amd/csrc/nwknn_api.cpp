@@ -83,9 +83,12 @@ struct nwknn_ctx {
     DevBuf qraw, qp, qn;
     // fp16 pre-screen of the exact fp32 search (option "prescreen"): scaled fp16 copies of bp / qp
     DevBuf bp16, qp16, cnt0, scal;
-    int pre_ok = 0;                 // the current base has a usable fp16 copy
+    int pre_ok = 0;                 // the current base can be pre-screened (finite, sane magnitudes); bp16 holds a copy of kind pre_kind
+    int pre_kind = -1;              // 0: rows scaled by b_scale (sqeuclidean, one_minus_dot); 1: unit rows x 2^14 (cosine); -1: none yet
     int dp16 = 0;
     float b_scale = 1.f, b_maxabs = 0.f;
+    long long nb_pad_for_copy = 0;
+    int dp_for_copy = 0;
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
@@ -347,6 +350,21 @@ static float prescreen_scale(float maxabs)
     return ldexpf(1.0f, 15 - e);
 }
 
+static const float NWK_COS_SCALE = 0x1p14f;       // unit rows times this: elements in [-2^14, 2^14]
+
+// (re)build the fp16 copy of the base in the flavour a search needs
+static int ensure_base_copy(nwknn_ctx* h, int kind)
+{
+    if (h->pre_kind == kind) return NWKNN_OK;
+    RCCHK(h->bp16.ensure((size_t)h->nb_pad_for_copy * h->dp16 * 2));
+    EvPair* e = ev_begin(h, 2);
+    if (kind == 0) HIPCHK(nwk_launch_half_copy(h->stream, h->bp.as<float>(), h->nb_pad_for_copy, h->dp_for_copy, h->dp16, h->b_scale, nullptr, h->bp16.p));
+    else HIPCHK(nwk_launch_half_copy(h->stream, h->bp.as<float>(), h->nb_pad_for_copy, h->dp_for_copy, h->dp16, NWK_COS_SCALE, h->bn.as<float>(), h->bp16.p));
+    ev_end(h, e);
+    h->pre_kind = kind;
+    return NWKNN_OK;
+}
+
 static int set_base_common(nwknn_ctx* h, const void* base, const void* const* columns, int64_t rows, int32_t d, int dtype, int location)
 {
     if (!h || (!base && !columns)) return fail(NWKNN_EINVAL, "nwknn_set_base: null handle or base pointer");
@@ -371,14 +389,13 @@ static int set_base_common(nwknn_ctx* h, const void* base, const void* const* co
     if (pre) {
         bool usable = false;
         RCCHK(matrix_maxabs(h, h->bp.as<float>(), rows_pad * (long long)dp, &h->b_maxabs, &usable));
+        h->nb_pad_for_copy = rows_pad; h->dp_for_copy = dp;
         if (usable) {       // else (NaN/Inf/extreme magnitudes/all zero): searches on this base run the direct fp32 kernel
             h->dp16 = (int)round_up(d, NWK_K_ALIGN_F16);
             h->b_scale = prescreen_scale(h->b_maxabs);
-            RCCHK(h->bp16.ensure((size_t)rows_pad * h->dp16 * 2));
-            EvPair* e = ev_begin(h, 2);
-            HIPCHK(nwk_launch_half_copy(h->stream, h->bp.as<float>(), rows_pad, dp, h->dp16, h->b_scale, h->bp16.p));
-            ev_end(h, e);
             h->pre_ok = 1;
+            h->pre_kind = -1;
+            RCCHK(ensure_base_copy(h, 0));          // the cosine flavour is made on demand by the first cosine search
         }
     }
     if (h->opt_profile) {
@@ -442,6 +459,7 @@ static NwkTileParams tile_params(nwknn_ctx* h, const SearchPlan& pl, long long n
     p.tau = h->tau.as<u64>(); p.cnt = h->cnt.as<u32>(); p.buf = h->buf.as<u64>();
     p.qtile_list = nullptr;
     p.nb_valid = h->nb;
+    p.nq_valid = h->stats.nq;
     p.n_qtiles = (int)(nq_pad / pl.tile_rows);
     p.dp = h->dp; p.cap = pl.cap;
     p.sq_shift = (int)h->opt_sq_shift;
@@ -578,7 +596,7 @@ static int search_common(nwknn_ctx* h, const void* queries, const void* const* q
     if ((location != NWKNN_HOST && location != NWKNN_DEVICE) || (out_location != NWKNN_HOST && out_location != NWKNN_DEVICE))
         return fail(NWKNN_EINVAL, "nwknn_search: bad location");
     RCCHK(use_device(h));
-    bool pre = h->pre_ok && !h->f16 && metric != NWKNN_METRIC_COSINE;      // cosine has no additive split: direct fp32 kernel
+    bool pre = h->pre_ok && !h->f16;
     SearchPlan pl;
     RCCHK(make_plan(h, k, nq, pre, &pl));
 
@@ -607,11 +625,13 @@ static int search_common(nwknn_ctx* h, const void* queries, const void* const* q
             pre = false;
             RCCHK(make_plan(h, k, nq, false, &pl));                          // same cap; granule/tile shape of the direct path
         } else {
-            const float q_scale = prescreen_scale(q_maxabs);
+            const bool cosine = metric == NWKNN_METRIC_COSINE;
+            const float q_scale = cosine ? NWK_COS_SCALE : prescreen_scale(q_maxabs);
+            RCCHK(ensure_base_copy(h, cosine ? 1 : 0));
             RCCHK(h->qp16.ensure((size_t)nq_pad * h->dp16 * 2));
             RCCHK(h->cnt0.ensure((size_t)nq_pad * 4));
             EvPair* e = ev_begin(h, 2);
-            HIPCHK(nwk_launch_half_copy(h->stream, h->qp.as<float>(), nq_pad, h->dp, h->dp16, q_scale, h->qp16.p));
+            HIPCHK(nwk_launch_half_copy(h->stream, h->qp.as<float>(), nq_pad, h->dp, h->dp16, q_scale, cosine ? h->qn.as<float>() : nullptr, h->qp16.p));
             ev_end(h, e);
             HIPCHK(hipMemsetAsync(h->cnt0.p, 0, (size_t)nq_pad * 4, h->stream));
             const double u = 0x1p-24, dd = (double)h->dp16;
@@ -624,6 +644,15 @@ static int search_common(nwknn_ctx* h, const void* queries, const void* const* q
             pl.pre_aq = (float)(1.01 * a_q * sd);       // times sqrt(|b|^2) >= |b|_1 / sqrt(d)
             pl.pre_ab = (float)(1.01 * a_b * sd);       // times sqrt(|q|^2)
             pl.pre_cst = (float)(1.01 * (double)h->d * a_q * a_b);
+            if (cosine) {
+                // unit rows: |S^-1 dot16 - cos| <= input rounding + fp16 MFMA sum (4 d u) + normalisation (d u + 8 u) + flushed elements;
+                // |canonical cosine distance - (1 - cos)| <= 2.1 d u + 8 u.  One constant, no norm-dependent terms.
+                const double a = 0x1p-14 / (double)NWK_COS_SCALE;
+                pl.pre_scale = NWK_COS_SCALE * NWK_COS_SCALE;
+                pl.pre_eps_half = 0.f; pl.pre_aq = 0.f; pl.pre_ab = 0.f;
+                pl.pre_cst = (float)((1.02 * (0x1p-10 * (1.0 + 0x1p-11) + 7.5 * dd * u + 16.0 * u) + 2.02 * a * sd + (double)h->d * a * a)
+                                     * (double)h->opt_pre_eps_pct / 100.0);
+            }
         }
     }
     h->stats.prescreen = pre ? 1 : 0;

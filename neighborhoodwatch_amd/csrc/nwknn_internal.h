@@ -23,6 +23,7 @@ struct NwkTileParams {
     unsigned long long* buf;       // candidate lists [nq_pad][cap]
     const int* qtile_list;         // optional indirection (rescans); nullptr = tiles 0..n_qtiles-1
     long long nb_valid;            // base rows >= nb_valid are zero padding and never listed
+    long long nq_valid;            // query rows >= nq_valid are zero padding: their pre-filter term rejects everything
     long long dense_col0;          // dense mode: list slot = column - dense_col0
     int n_qtiles;
     int bt0;                       // first base tile of this launch
@@ -83,7 +84,8 @@ hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool den
 hipError_t nwk_launch_tile_prescreen(hipStream_t st, NwkTileParams p, int metric);
 hipError_t nwk_launch_rescore(hipStream_t st, const NwkRescoreParams& p, int metric, long long nq_pad);
 hipError_t nwk_launch_maxabs(hipStream_t st, const float* x, long long n, unsigned int* out_bits);
-hipError_t nwk_launch_half_copy(hipStream_t st, const float* prepared, long long rows_pad, int dp32, int dp16, float scale, void* out16);
+hipError_t nwk_launch_half_copy(hipStream_t st, const float* prepared, long long rows_pad, int dp32, int dp16, float scale, const float* norms,
+                                void* out16);
 hipError_t nwk_launch_compact(hipStream_t st, const NwkCompactParams& p, long long n_queries);
 hipError_t nwk_launch_finalize(hipStream_t st, const unsigned long long* buf, const unsigned int* cnt, int cap, int k, long long nq,
                                long long index_offset, float* out_d, long long* out_i, int negate);

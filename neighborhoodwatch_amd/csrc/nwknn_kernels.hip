@@ -393,10 +393,16 @@ __device__ __forceinline__ float prefilter_col(float bn)
 //     one_minus_dot : row = (1 - tau_d)    - eps/2 qn - ab sqrt(qn) - cst,   col =        - eps/2 bn - aq sqrt(bn)
 // each lowered by a few ulps of its operands for the fp32 evaluation of these very expressions (the square roots are bare
 // v_sqrt_f32, 1 ulp: the a_q / a_b constants carry 1 % of slack).
+// Cosine: the copies are NORMALISED rows (x / |x| * 2^14), the accumulator is S * cos(q,b) up to the bound in pre_cst (eps_half, aq, ab
+// are zero), and the test is the one_minus_dot one.  A row whose squared norm is outside [2^-80, 2^80] (zero rows included) has an
+// all-zero copy and a threshold of -inf: everything involving it is listed and the canonical arithmetic decides.
+__device__ __forceinline__ bool cosine_norm_ok(float n) { return n >= 0x1p-80f && n <= 0x1p80f; }
+
 template <int METRIC>
 __device__ __forceinline__ float prescreen_row(float qn, u64 tau, const NwkTileParams& p)
 {
     if (tau == ~0ull) return -__builtin_inff();
+    if (METRIC == NWKNN_METRIC_COSINE && !cosine_norm_ok(qn)) return -__builtin_inff();
     const float td = unsortable_f32((u32)(tau >> 32));
     const float err = p.pre_eps_half * qn + p.pre_ab * __builtin_amdgcn_sqrtf(qn) + p.pre_cst;
     float r;
@@ -407,6 +413,7 @@ __device__ __forceinline__ float prescreen_row(float qn, u64 tau, const NwkTileP
 template <int METRIC>
 __device__ __forceinline__ float prescreen_col(float bn, const NwkTileParams& p)
 {
+    if (METRIC == NWKNN_METRIC_COSINE) return cosine_norm_ok(bn) ? 0.0f : -__builtin_inff();
     const float err = p.pre_eps_half * bn + p.pre_aq * __builtin_amdgcn_sqrtf(bn);
     float c;
     if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) c = 0.5f * bn - err - 2.0e-6f * fabsf(bn);
@@ -451,7 +458,7 @@ __device__ __forceinline__ void tile_epilogue(const NwkTileParams& p, const f32x
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             bool maybe = false;
-            if (METRIC == NWKNN_METRIC_COSINE) {
+            if (METRIC == NWKNN_METRIC_COSINE && !PRE) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rb + (r & 3) + 8 * (r >> 2);
@@ -516,7 +523,7 @@ __device__ __forceinline__ void tile_epilogue(const NwkTileParams& p, const f32x
 
 // staging of the tile's query-side epilogue inputs in LDS: norms | 64-bit thresholds | pre-filter row terms
 template <int METRIC, bool DENSE, int PRE = 0>
-__device__ __forceinline__ void stage_query_side(char* lds, int rows, int tid, float my_qn, u64 my_tau, const NwkTileParams& p)
+__device__ __forceinline__ void stage_query_side(char* lds, int rows, int tid, float my_qn, u64 my_tau, const NwkTileParams& p, long long q0)
 {
     float* s_qn = (float*)lds;
     u64* s_tau = (u64*)(lds + rows * 4);
@@ -525,7 +532,12 @@ __device__ __forceinline__ void stage_query_side(char* lds, int rows, int tid, f
         s_qn[tid] = my_qn;
         if (!DENSE) {
             s_tau[tid] = my_tau;
-            s_pre[tid] = PRE ? prescreen_row<METRIC>(my_qn, my_tau, p) : prefilter_row<METRIC>(my_qn, my_tau);
+            float pre = PRE ? prescreen_row<METRIC>(my_qn, my_tau, p) : prefilter_row<METRIC>(my_qn, my_tau);
+            // padding query rows (all zero) must list nothing: with one_minus_dot / cosine they tie with every base row, which
+            // the pre-screen cannot break by index and would list wholesale.  (The direct cosine test is on the distance: -inf.)
+            if (p.nq_valid > 0 && q0 + tid >= p.nq_valid)
+                pre = (METRIC == NWKNN_METRIC_COSINE && !PRE) ? -__builtin_inff() : __builtin_inff();
+            s_pre[tid] = pre;
         }
     }
 }
@@ -680,7 +692,7 @@ __global__ __launch_bounds__(256, 2) void nwk_tile_kernel(const NwkTileParams p)
 
     if (p.dbg) st2 = __builtin_amdgcn_s_memtime();
     // ---- epilogue: accumulators -> keys -> filter -> candidate lists (staging reuses the idle operand stages)
-    stage_query_side<METRIC, DENSE>(smem, TM, tid, my_qn, my_tau, p);
+    stage_query_side<METRIC, DENSE>(smem, TM, tid, my_qn, my_tau, p, q0);
     __syncthreads();
     tile_epilogue<METRIC, DENSE, MT>(p, acc, (const float*)smem, (const u64*)(smem + TM * 4), (const float*)(smem + TM * 12), bnv, colv, colok,
                                      q0, wr * (TM / 2), h, c32);
@@ -820,7 +832,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16(const NwkTileParam
     issue_stage(0, 0);
     if (nk > 1) issue_stage(1, 1);
     __builtin_amdgcn_sched_barrier(0);
-    stage_query_side<METRIC, DENSE, PRE>(epi, H_TM, tid, my_qn, my_tau, p);
+    stage_query_side<METRIC, DENSE, PRE>(epi, H_TM, tid, my_qn, my_tau, p, q0);
     if (nk > 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");       // slab 0 landed; my epilogue-input ds_writes are done
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -900,7 +912,7 @@ __device__ __forceinline__ void tile_epilogue16(const NwkTileParams& p, const f3
         }
         const f32x4 pre4 = *(const f32x4*)(s_pre + rb);
         bool maybe = false;
-        if (METRIC == NWKNN_METRIC_COSINE) {
+        if (METRIC == NWKNN_METRIC_COSINE && !PRE) {
             const f32x4 qn4 = *(const f32x4*)(s_qn + rb);
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
@@ -1067,7 +1079,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTilePara
     issue_stage(0, 0);
     if (nk > 1) issue_stage(1, 1);
     __builtin_amdgcn_sched_barrier(0);
-    stage_query_side<METRIC, DENSE, PRE>(epi, H_TM, tid, my_qn, my_tau, p);
+    stage_query_side<METRIC, DENSE, PRE>(epi, H_TM, tid, my_qn, my_tau, p, q0);
     if (nk > 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1250,7 +1262,7 @@ __global__ __launch_bounds__(256, 2) void nwk_tile_kernel_f16q(const NwkTilePara
     issue_slab(1);                                           // nk >= 2
     if (nk > 2) issue_slab(2);
     __builtin_amdgcn_sched_barrier(0);
-    stage_query_side<METRIC, DENSE, PRE>(epi, Q_TM, tid, my_qn, my_tau, p);
+    stage_query_side<METRIC, DENSE, PRE>(epi, Q_TM, tid, my_qn, my_tau, p, q0);
     if (nk > 2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");     // slab 0 landed; my epilogue-input ds_writes are done
     else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1460,7 +1472,7 @@ __global__ __launch_bounds__(256) void nwk_maxabs_kernel(const float* __restrict
 }
 
 __global__ __launch_bounds__(256) void nwk_half_copy_kernel(const float* __restrict__ prepared, long long rows_pad, int dp32, int dp16,
-                                                             float scale, _Float16* __restrict__ out)
+                                                             float scale0, const float* __restrict__ norms, _Float16* __restrict__ out)
 {
     const int g16 = dp16 >> 3;
     const long long total = rows_pad * g16;
@@ -1468,7 +1480,12 @@ __global__ __launch_bounds__(256) void nwk_half_copy_kernel(const float* __restr
         const long long r = i / g16;
         const int k0 = (int)(i - r * g16) << 3;
         f16x8 hv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (k0 < dp32) {
+        float scale = scale0;
+        if (norms) {                                       // cosine: unit rows (degenerate norms: an all-zero copy, see cosine_norm_ok)
+            const float n = norms[r];
+            scale = cosine_norm_ok(n) ? scale0 * (1.0f / sqrtf(n)) : 0.0f;
+        }
+        if (k0 < dp32 && scale != 0.0f) {
             const f32x4 ev = *(const f32x4*)(prepared + r * dp32 + k0), od = *(const f32x4*)(prepared + r * dp32 + k0 + 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1517,11 +1534,16 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
                     const float bn = p.bn[(u32)key];
                     float err = row_err + p.eps_half * bn + p.aq * __builtin_amdgcn_sqrtf(bn);          // >= |dot16 - dot32|
                     if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) err = 2.0f * err;
-                    err = err * 1.0001f + 2.0e-6f * (fabsf(est) + qn + bn + 1.0f);       // roundings of est and of these lines
+                    if (METRIC == NWKNN_METRIC_COSINE) err = err * 1.0001f + 2.0e-6f * (fabsf(est) + 1.0f);
+                    else err = err * 1.0001f + 2.0e-6f * (fabsf(est) + qn + bn + 1.0f);  // roundings of est and of these lines
                     float ub = est + err;
                     if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ub = fmaxf(ub, 0.0f);       // the canonical distance is clamped at 0
-                    s_ub[e] = sortable_u32(ub);
-                    s_lb[e] = sortable_u32(est - err);
+                    u32 sub = sortable_u32(ub), slb = sortable_u32(est - err);
+                    if (METRIC == NWKNN_METRIC_COSINE && !(cosine_norm_ok(qn) && cosine_norm_ok(bn))) {
+                        sub = 0xFFC00000u; slb = 0u;                                   // no estimate for degenerate rows: [-inf, NaN rank]
+                    }
+                    s_ub[e] = sub;
+                    s_lb[e] = slb;
                 }
             }
         }
@@ -1923,7 +1945,13 @@ hipError_t nwk_launch_tile_prescreen(hipStream_t st, NwkTileParams p, int metric
             hipLaunchKernelGGL((nwk_tile_kernel_f16q<NWKNN_METRIC_SQEUCLIDEAN, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, p);
         else if (metric == NWKNN_METRIC_ONE_MINUS_DOT)
             hipLaunchKernelGGL((nwk_tile_kernel_f16q<NWKNN_METRIC_ONE_MINUS_DOT, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, p);
+        else if (metric == NWKNN_METRIC_COSINE)
+            hipLaunchKernelGGL((nwk_tile_kernel_f16q<NWKNN_METRIC_COSINE, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, p);
         else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
+    if (metric == NWKNN_METRIC_COSINE) {                   // cosine: 16x16x32 kernel only (f16_mfma 0 falls back to it)
+        hipLaunchKernelGGL((nwk_tile_kernel_f16s<NWKNN_METRIC_COSINE, false, 1>), dim3((unsigned)grid), dim3(512), 0, st, p);
         return hipGetLastError();
     }
     if (metric == NWKNN_METRIC_SQEUCLIDEAN) {
@@ -1933,7 +1961,7 @@ hipError_t nwk_launch_tile_prescreen(hipStream_t st, NwkTileParams p, int metric
         if (p.f16_shape == 1) hipLaunchKernelGGL((nwk_tile_kernel_f16s<NWKNN_METRIC_ONE_MINUS_DOT, false, 1>), dim3((unsigned)grid), dim3(512), 0, st, p);
         else hipLaunchKernelGGL((nwk_tile_kernel_f16<NWKNN_METRIC_ONE_MINUS_DOT, false, 0, 1>), dim3((unsigned)grid), dim3(512), 0, st, p);
     }
-    else return hipErrorInvalidValue;                      // cosine has no additive split: the caller stays on the fp32 kernel
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -1947,6 +1975,8 @@ hipError_t nwk_launch_rescore(hipStream_t st, const NwkRescoreParams& p, int met
         hipLaunchKernelGGL((nwk_rescore_kernel<NWKNN_METRIC_SQEUCLIDEAN>), dim3(grid), dim3(64 * waves), lds, st, p);
     else if (metric == NWKNN_METRIC_ONE_MINUS_DOT)
         hipLaunchKernelGGL((nwk_rescore_kernel<NWKNN_METRIC_ONE_MINUS_DOT>), dim3(grid), dim3(64 * waves), lds, st, p);
+    else if (metric == NWKNN_METRIC_COSINE)
+        hipLaunchKernelGGL((nwk_rescore_kernel<NWKNN_METRIC_COSINE>), dim3(grid), dim3(64 * waves), lds, st, p);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -1960,13 +1990,14 @@ hipError_t nwk_launch_maxabs(hipStream_t st, const float* x, long long n, unsign
     return hipGetLastError();
 }
 
-hipError_t nwk_launch_half_copy(hipStream_t st, const float* prepared, long long rows_pad, int dp32, int dp16, float scale, void* out16)
+hipError_t nwk_launch_half_copy(hipStream_t st, const float* prepared, long long rows_pad, int dp32, int dp16, float scale, const float* norms,
+                                void* out16)
 {
     const long long total = rows_pad * (dp16 / 8);
     if (total <= 0) return hipSuccess;
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(nwk_half_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, prepared, rows_pad, dp32, dp16, scale, (_Float16*)out16);
+    hipLaunchKernelGGL(nwk_half_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, prepared, rows_pad, dp32, dp16, scale, norms, (_Float16*)out16);
     return hipGetLastError();
 }
 

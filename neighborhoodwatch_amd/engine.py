@@ -104,7 +104,7 @@ class KnnEngine:
         self.set_option("compute_dtype", {"f32": DTYPE_F32, "fp32": DTYPE_F32, "f16": DTYPE_F16, "fp16": DTYPE_F16}[dtype])
 
     def set_prescreen(self, on: bool) -> None:
-        """fp32 searches (sqeuclidean / one_minus_dot) run an fp16 MFMA pre-screen over scaled fp16 copies of both sides and
+        """fp32 searches (all three metrics) run an fp16 MFMA pre-screen over scaled fp16 copies of both sides and
         rescore every listed pair with the canonical fp32 chain: the SAME bits out as the direct fp32 kernel, several times
         faster (DESIGN.md "pre-screen").  Costs an extra fp16 copy of the base in HBM.  Takes effect at the next set_base."""
         self.set_option("prescreen", 1 if on else 0)

@@ -5,7 +5,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-ADDITIVE = ["sqeuclidean", "one_minus_dot"]
+ADDITIVE = ["sqeuclidean", "one_minus_dot", "cosine"]       # all three metrics are pre-screened
 
 
 def _bitwise(a, b):
@@ -49,11 +49,21 @@ def test_prescreen_actually_runs_the_fp16_kernel_and_rescoring(pre_engine, oracl
     assert st["prescreen"] == 1 and st["rescore_ms"] > 0.0 and st["tile_launches"] >= 3
 
 
-def test_cosine_stays_on_the_direct_kernel(pre_engine, oracle):
-    base = oracle.gen(3, 0, 3000, 96)
-    queries = oracle.gen(4, 0, 50, 96)
+def test_cosine_with_zero_and_degenerate_rows(pre_engine, oracle):
+    """Zero rows give 0/0 = NaN (ranked last), rows with a squared norm outside [2^-80, 2^80] give whatever the canonical fp32
+    arithmetic gives (inf, NaN, huge): the pre-screen lists every pair involving such a row and lets the rescoring decide."""
+    base = oracle.gen(3, 0, 3000, 96).copy()
+    queries = oracle.gen(4, 0, 50, 96).copy()
+    base[5] = 0.0
+    base[77] *= 1e-30                       # squared norm underflows to 0 / denormal in fp32
+    base[200] *= 1e-15
+    base[1234] *= 5e11                      # squared norm above 2^80 (the matrix maximum stays below 2^40)
+    queries[3] = 0.0
+    queries[7] *= 1e-25
     pre_engine.set_base(base)
-    _check(pre_engine, oracle, base, queries, 12, "cosine", expect_pre=False)
+    _check(pre_engine, oracle, base, queries, 12, "cosine")
+    pre_engine.set_base(base[:40])
+    _check(pre_engine, oracle, base[:40], queries, 40, "cosine")    # k = B: the NaN / degenerate rows must all come back, in order
 
 
 @pytest.mark.parametrize("metric", ADDITIVE)
@@ -173,7 +183,7 @@ def test_both_fp16_mfma_shapes(oracle, shape_opt):
         eng.set_option("f16_mfma", shape_opt)
         eng.set_prescreen(True)
         eng.set_base(base)
-        for metric in ADDITIVE:
+        for metric in ADDITIVE:                                          # (cosine always runs on a 16x16x32 build)
             dist, idx = eng.search(queries, 40, metric)
             rd, ri = oracle.knn_canonical(base, queries, 40, metric)
             assert eng.stats()["prescreen"] == 1
@@ -209,3 +219,15 @@ def test_fp16_mfma_accumulation_error_is_far_inside_the_allowance(oracle, d):
     ratio = float((err / unit).max())
     assert ratio < 0.25 * 4 * d, f"fp16 MFMA accumulation error {ratio:.1f} u*sum|products| is not far inside the allowance {4 * d}"
     print(f"d={d}: max accumulation error {ratio:.2f} x u*sum|products| (allowance {4 * d})")
+
+
+@pytest.mark.parametrize("metric", ADDITIVE)
+def test_query_count_not_a_multiple_of_the_tile_does_not_flood_the_lists(pre_engine, oracle, metric):
+    """The zero rows that pad the query matrix to 256 tie with every base row under one_minus_dot / cosine; they must not list
+    anything (a first version listed every base row for them and sent the whole search through overflow repair)."""
+    base = oracle.gen(0x33, 0, 30000, 64)
+    queries = oracle.gen(0x34, 0, 300, 64)           # 212 padding rows
+    pre_engine.set_base(base)
+    _check(pre_engine, oracle, base, queries, 10, metric)
+    st = pre_engine.stats()
+    assert st["overflowed_queries"] == 0 and st["rescan_launches"] == 0
