@@ -30,7 +30,8 @@ def process_knn_computation(data_dir,
                             split=False,
                             engine='torch',
                             *,
-                            device: int = 0):
+                            device: int = 0,
+                            prescreen: bool = False):
     if engine == 'torch' and initial_batch_size > 100000:
         initial_batch_size = 9000                                          # colbert_knn.py:95-98
     print("-- prepare query source table for brute-force KNN computation.")
@@ -44,4 +45,5 @@ def process_knn_computation(data_dir,
     batch_count = math.ceil(len(base_table) / batch_size)
     assert (len(base_table) % batch_size == 0) or k <= (len(base_table) % batch_size), \
         f"Cannot generate k of {k} with only {len(base_table)} rows and batch_size of {batch_size}."   # colbert_knn.py:112-113
-    process_batches(data_dir, base_table, query_table, batch_count, batch_size, k, split, engine=engine, device=device)
+    process_batches(data_dir, base_table, query_table, batch_count, batch_size, k, split, engine=engine, device=device,
+                    prescreen=prescreen)

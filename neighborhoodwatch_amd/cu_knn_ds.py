@@ -81,7 +81,8 @@ def compute_knn_ds(data_dir,
                    *,
                    engine='raft',
                    metric=None,
-                   device: int = 0):
+                   device: int = 0,
+                   prescreen: bool = False):
     batch_size = initial_batch_size
     query_dataset = slice_dataset(load_dataset(data_dir, query_filename), 0, query_count)
     query_column_names = get_dataset_columns(query_dataset, dimensions)
@@ -92,7 +93,7 @@ def compute_knn_ds(data_dir,
     assert (base_count % batch_size == 0) or k <= (base_count % batch_size), \
         f"Cannot generate k of {k} with only {base_count} rows and batch_size of {batch_size}."           # cu_knn_ds.py:167
     process_dataset_batches(data_dir, base_dataset, base_column_names, query_dataset, query_column_names, batch_size,
-                            query_count, k, split, engine=engine, metric=metric, device=device)
+                            query_count, k, split, engine=engine, metric=metric, device=device, prescreen=prescreen)
 
 
 def process_dataset_batches(data_dir,
@@ -107,9 +108,11 @@ def process_dataset_batches(data_dir,
                             *,
                             engine='raft',
                             metric=None,
-                            device: int = 0):
+                            device: int = 0,
+                            prescreen: bool = False):
     metric = resolve_metric(metric, engine)
     eng = default_engine(device)
+    eng.set_prescreen(prescreen)
     query_table = query_dataset.to_table(columns=query_column_names)
     queries = table_columns(query_table)
     assert len(query_table) == query_count                                        # cu_knn_ds.py:229-230
@@ -142,6 +145,7 @@ def process_dataset_batches(data_dir,
                 flush()
     if pending_rows:
         flush()
+    eng.set_prescreen(False)
     assert run_d is not None and len(run_d) == query_count
     stream_cudf_to_parquet(get_partial_distances_filename(data_dir, -1), run_d, PARQUET_ROW_GROUP)
     stream_cudf_to_parquet(get_partial_indices_filename(data_dir, -1), run_i, PARQUET_ROW_GROUP)

@@ -117,7 +117,7 @@ def main(argv=None):
     section = time.time()
     if args.use_dataset_api:
         compute_knn_ds(data_dir, output_dimension, query_filename, args.query_count, base_filename, args.base_count,
-                       args.enable_memory_tuning, args.k, engine=args.engine, device=args.device)
+                       args.enable_memory_tuning, args.k, engine=args.engine, device=args.device, prescreen=args.prescreen)
     else:
         compute_knn(data_dir, args.model_name, output_dimension, query_filename, args.query_count, base_filename,
                     args.base_count, args.enable_memory_tuning, args.k, engine=args.engine, device=args.device,

@@ -79,9 +79,10 @@ def test_row_counts_slice_the_files(dataset, oracle):
     assert np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
 
 
-def test_dataset_api_writes_the_final_tables_once(dataset, oracle):
+@pytest.mark.parametrize("prescreen", [False, True])
+def test_dataset_api_writes_the_final_tables_once(dataset, oracle, prescreen):
     data_dir, qf, bf = dataset
-    cu_knn_ds.compute_knn_ds(data_dir, 384, qf, 300, bf, 2600, False, 10, 800)            # 4 base batches: 800,800,800,200
+    cu_knn_ds.compute_knn_ds(data_dir, 384, qf, 300, bf, 2600, False, 10, 800, prescreen=prescreen)   # 4 base batches: 800,800,800,200
     assert merge.get_file_count(f"{data_dir}/partial") == 0
     merge.merge_indices_and_distances(data_dir, k=10)                                     # no partial files: no-op, merge.py:40-42
     fd, fi = _final(data_dir)
@@ -127,14 +128,16 @@ def test_cli_end_to_end(tmp_path, oracle, extra):
     assert np.array_equal(ptf.read_vectors(data_dir, iv), ri.astype(np.int32)) and np.array_equal(ptf.read_vectors(data_dir, dv), rd)
 
 
-def test_ck_token_level_knn(tmp_path, oracle):
+@pytest.mark.parametrize("prescreen", [False, True])
+def test_ck_token_level_knn(tmp_path, oracle, prescreen):
     """colbert_knn.process_knn_computation: token_embedding_<i> columns, d=128, 1 - dot, 9000-row base tiles, split=False."""
     from neighborhoodwatch_amd.colbert_knn import process_knn_computation
     (tmp_path / "partial").mkdir()
     synth.write_source_parquet(str(tmp_path / "q_src.parquet"), 0x31, 150, 128, normalize=True, column_prefix="token_embedding_")
     synth.write_source_parquet(str(tmp_path / "b_src.parquet"), 0x32, 20000, 128, normalize=True, column_prefix="token_embedding_")
     # only the vector columns reach the engine (the reference selects float columns, cu_knn.py:208)
-    process_knn_computation(str(tmp_path), str(tmp_path / "b_src.parquet"), 20000, str(tmp_path / "q_src.parquet"), 150, k=10)
+    process_knn_computation(str(tmp_path), str(tmp_path / "b_src.parquet"), 20000, str(tmp_path / "q_src.parquet"), 150, k=10,
+                            prescreen=prescreen)
     assert merge.get_file_count(f"{tmp_path}/partial") == 3                     # ceil(20000 / 9000), colbert_knn.py:95-98
     merge.merge_indices_and_distances(str(tmp_path), k=10)
     fd, fi = _final(str(tmp_path))
