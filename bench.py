@@ -53,7 +53,8 @@ def recorded_traffic(workload):
     this process, so the figure is the recorded one for this workload, or None."""
     f = ROOT / "profiles" / f"traffic_{workload}.json"
     try:
-        return float(json.loads(f.read_text())["hbm_fabric_bytes_per_launch"])
+        rec = json.loads(f.read_text())
+        return float(rec.get("tile", rec)["hbm_fabric_bytes_per_launch"])
     except Exception:
         return None
 
@@ -213,7 +214,8 @@ def main():
                 "identical_to_direct": bool(torch.equal(direct[0], p_last[0])) and bool(torch.equal(direct[1], p_last[1])),
                 "prescreen_searches": p_agg["prescreen"],
                 "roofline": {"bound": "mfma", "achieved": p_ach, "peak": MFMA_PEAK_TFLOPS["f16"], "unit": "TFLOP/s",
-                             "frac": p_ach / MFMA_PEAK_TFLOPS["f16"], "kernel": "nwk_tile_kernel_f16 (PRE)",
+                             "frac": p_ach / MFMA_PEAK_TFLOPS["f16"], "kernel": "nwk_tile_kernel_f16s<metric, false, PRE=1>",
+                             "traffic": recorded_traffic(args.workload + "_prescreen"),
                              "launches": p_agg["tile_launches"], "avg_launch_ms": p_agg["tile_ms"] / max(p_agg["tile_launches"], 1)},
                 "breakdown_ms_per_step": {"tile": p_agg["tile_ms"] / args.steps, "rescore": p_agg["rescore_ms"] / args.steps,
                                           "compact": p_agg["compact_ms"] / args.steps, "prep": p_agg["prep_ms"] / args.steps,
