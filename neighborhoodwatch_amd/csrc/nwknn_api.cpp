@@ -502,7 +502,10 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         NwkRescoreParams rp;
         rp.qp = h->qp.as<float>(); rp.bp = h->bp.as<float>(); rp.qn = h->qn.as<float>(); rp.bn = h->bn.as<float>();
         rp.buf = h->buf.as<u64>(); rp.cnt = h->cnt.as<u32>(); rp.cnt0 = h->cnt0.as<u32>();
-        rp.dp = h->dp; rp.cap = pl.cap; rp.k = k; rp.prune = h->opt_pre_prune ? 1 : 0;
+        rp.dp = h->dp; rp.cap = pl.cap; rp.k = k;
+        // no pruning on a repair pass: it re-finds pairs that are already listed, and the k-th smallest upper bound over a list
+        // with duplicates can lie below the k-th distinct distance
+        rp.prune = (h->opt_pre_prune && !dedupe) ? 1 : 0;
         rp.eps_half = pl.pre_eps_half; rp.aq = pl.pre_aq; rp.ab = pl.pre_ab; rp.cst = pl.pre_cst;
         e = ev_begin(h, 3);
         HIPCHK(nwk_launch_rescore(h->stream, rp, metric, nq_pad));

@@ -231,3 +231,29 @@ def test_query_count_not_a_multiple_of_the_tile_does_not_flood_the_lists(pre_eng
     _check(pre_engine, oracle, base, queries, 10, metric)
     st = pre_engine.stats()
     assert st["overflowed_queries"] == 0 and st["rescan_launches"] == 0
+
+
+@pytest.mark.parametrize("metric", ADDITIVE)
+def test_repair_pass_with_duplicates_in_the_lists(oracle, metric):
+    """Overflow repair re-walks the base and re-finds pairs that are already listed.  Bound-based pruning must be off there: the
+    k-th smallest upper bound over a list WITH duplicates can lie below the k-th distinct distance.  Tiny lists (capacity 256... the
+    minimum the planner accepts) and an approaching arrival order make nearly every query overflow repeatedly."""
+    from neighborhoodwatch_amd import KnnEngine
+    d, B, Q, k = 24, 12000, 200, 5
+    rng = np.random.default_rng(17)
+    centre = rng.standard_normal(d).astype(np.float32)
+    base = (centre[None, :] + rng.standard_normal((B, d)).astype(np.float32) * np.linspace(3.0, 0.02, B, dtype=np.float32)[:, None]).astype(np.float32)
+    if metric == "one_minus_dot":          # "approaching" for a dot product: later rows are longer
+        base = (centre[None, :] * np.linspace(0.2, 30.0, B, dtype=np.float32)[:, None]
+                + 1e-4 * rng.standard_normal((B, d)).astype(np.float32)).astype(np.float32)
+    queries = (centre[None, :] + 0.01 * rng.standard_normal((Q, d))).astype(np.float32)
+    with KnnEngine(0) as eng:
+        eng.set_prescreen(True)
+        eng.set_option("capacity", 512)
+        eng.set_option("first_chunk", 256)
+        eng.set_base(base)
+        dist, idx = eng.search(queries, k, metric)
+        st = eng.stats()
+        rd, ri = oracle.knn_canonical(base, queries, k, metric)
+        assert st["prescreen"] == 1 and st["overflowed_queries"] > 0 and st["rescan_launches"] > 0
+        assert np.array_equal(idx, ri) and _bitwise(dist, rd)
