@@ -21,6 +21,16 @@ def test_c2_full_size_properties_and_sampled_parity(oracle):
         # queries that ARE base rows must find themselves first at distance exactly 0
         probe = base[123_456:123_456 + 64].clone()
         pd_, pi_ = eng.search(probe, 3)
+        # every metric, direct kernel vs fp16 pre-screen + fp32 rescoring: the whole result must be the same bits
+        direct = {m: eng.search(queries, k, m) for m in ("sqeuclidean", "one_minus_dot", "cosine")}
+        eng.set_prescreen(True)
+        eng.set_base(base)
+        for m, (dd, di_) in direct.items():
+            pd2, pi2 = eng.search(queries, k, m)
+            assert eng.stats()["prescreen"] == 1 and eng.stats()["overflowed_queries"] == 0
+            assert torch.equal(pi2, di_) and torch.equal(pd2.view(torch.int32), dd.view(torch.int32)), m
+        eng.set_prescreen(False)
+        del direct
     assert torch.equal(idx, idx2) and torch.equal(dist, dist2)                      # deterministic
     assert st["overflowed_queries"] == 0
     di, ii = dist.cpu().numpy(), idx.cpu().numpy()
@@ -55,6 +65,15 @@ def test_c3_headline_size_properties_and_sampled_parity(oracle):
         st = eng.stats()
         probe = base[9_876_543:9_876_543 + 16].clone()            # base rows as queries: each must find itself at distance 0
         pd_, pi_ = eng.search(probe, 2)
+        # the same search through the fp16 pre-screen + fp32 rescoring: all 10^7 result entries must be the same bits
+        eng.set_prescreen(True)
+        eng.set_base(base)
+        pdist, pidx = eng.search(queries, k)
+        pst = eng.stats()
+        eng.set_prescreen(False)
+    assert pst["prescreen"] == 1 and pst["overflowed_queries"] == 0
+    assert torch.equal(pidx, idx) and torch.equal(pdist.view(torch.int32), dist.view(torch.int32))
+    del pdist, pidx
     assert st["overflowed_queries"] == 0 and st["tile_launches"] == 21
     assert bool((dist[:, 1:] >= dist[:, :-1]).all())                                    # ascending (merge.py:104)
     assert int(idx.min()) >= 0 and int(idx.max()) < B
