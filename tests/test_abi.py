@@ -81,3 +81,19 @@ def test_product_never_imports_the_oracle():
         assert "libnwknn_oracle" not in src
     for path in (ROOT / "neighborhoodwatch_amd" / "csrc").iterdir():
         assert "oracle/" not in path.read_text().replace("oracle/nwknn_oracle.c", "").replace("oracle/cpu_oracle", ""), path
+
+
+def test_stats_struct_layout_matches_the_header(tmp_path):
+    """sizeof/offsetof of nwknn_stats as gcc sees include/nwknn.h == the ctypes mirror in _lib.py (guards against ABI drift)."""
+    import ctypes
+    import subprocess
+    from neighborhoodwatch_amd._lib import NwknnStats
+    src = tmp_path / "layout.c"
+    fields = [name for name, _ in NwknnStats._fields_]
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "nwknn.h"\nint main(void){printf("%zu", sizeof(nwknn_stats));'
+                   + "".join(f'printf(" %zu", offsetof(nwknn_stats, {f}));' for f in fields) + 'return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(NwknnStats)
+    assert out[1:] == [getattr(NwknnStats, f).offset for f in fields]

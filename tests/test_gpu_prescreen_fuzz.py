@@ -1,0 +1,60 @@
+"""Randomised agreement of the two exact paths: direct fp32 kernel vs fp16 pre-screen + fp32 rescoring, same engine, same inputs,
+bit for bit (the direct kernel itself is pinned to the CPU oracle by test_gpu_parity.py).  Seeds are fixed: the cases are the same
+on every run.  The data families are chosen to stress the bound and the tie handling: heavy exact ties (small integers), clustered
+rows, low-rank rows, wide magnitude spreads, unit rows, and k from 1 to a few hundred."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+METRICS = ["sqeuclidean", "one_minus_dot", "cosine"]
+
+
+def _make(rng, family, rows, d):
+    if family == "normal":
+        return rng.standard_normal((rows, d)).astype(np.float32)
+    if family == "integers":                                   # exact arithmetic everywhere: masses of exactly equal distances
+        return rng.integers(-3, 4, size=(rows, d)).astype(np.float32)
+    if family == "clustered":
+        centres = rng.standard_normal((8, d)).astype(np.float32) * 4.0
+        return (centres[rng.integers(0, 8, rows)] + 0.05 * rng.standard_normal((rows, d))).astype(np.float32)
+    if family == "lowrank":
+        r = max(1, d // 8)
+        return (rng.standard_normal((rows, r)) @ rng.standard_normal((r, d))).astype(np.float32)
+    if family == "spread":
+        return (rng.standard_normal((rows, d)) * 10.0 ** rng.uniform(-4, 4, size=(rows, 1))).astype(np.float32)
+    if family == "unit":
+        x = rng.standard_normal((rows, d))
+        return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+    raise ValueError(family)
+
+
+FAMILIES = ["normal", "integers", "clustered", "lowrank", "spread", "unit"]
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_prescreened_search_equals_direct_search(seed):
+    import torch
+    from neighborhoodwatch_amd import KnnEngine
+    rng = np.random.default_rng(1000 + seed)
+    family = FAMILIES[seed % len(FAMILIES)]
+    d = int(rng.choice([1, 3, 17, 32, 64, 100, 129, 256, 384]))
+    B = int(rng.integers(50, 60000))
+    Q = int(rng.integers(1, 700))
+    k = int(min(B, rng.choice([1, 2, 10, 37, 100, 257, 600])))
+    base = _make(rng, family, B, d)
+    queries = _make(rng, family, Q, d)
+    if seed % 5 == 0:                                          # some queries ARE base rows (distance exactly 0 / similarity exactly 1)
+        queries[: min(Q, 20)] = base[rng.integers(0, B, min(Q, 20))]
+    tb, tq = torch.from_numpy(base).cuda(), torch.from_numpy(queries).cuda()
+    with KnnEngine(0) as eng:
+        eng.set_base(tb)
+        direct = {m: eng.search(tq, k, m) for m in METRICS}
+        eng.set_prescreen(True)
+        eng.set_base(tb)
+        for m in METRICS:
+            dist, idx = eng.search(tq, k, m)
+            assert eng.stats()["prescreen"] == 1, (family, m)
+            dd, di = direct[m]
+            assert torch.equal(idx, di), f"seed {seed} {family} {m} Q={Q} B={B} d={d} k={k}: indices differ at {(idx != di).sum().item()} positions"
+            assert torch.equal(dist.view(torch.int32), dd.view(torch.int32)), f"seed {seed} {family} {m}: distances differ"
