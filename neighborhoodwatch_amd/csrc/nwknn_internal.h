@@ -40,7 +40,9 @@ struct NwkTileParams {
     float pre_aq, pre_ab;          // absolute terms: pre_aq * sqrt(|b|^2) and pre_ab * sqrt(|q|^2)
     float pre_cst;
     float pre_inv_scale;           // 1 / pre_scale
-    int f16_shape;                 // fp16 kernels: 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16
+    int f16_shape;                 // fp16 kernels: 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16, 2 = 4-wave workgroups, two per CU
+    int tiles_per_wg;              // 16x16x32 kernel: consecutive base tiles a workgroup walks (strip); the launcher turns n_btiles into strips
+    int n_btiles_real;             // filled in by the launcher: base tiles of this launch
 };
 
 struct NwkRescoreParams {

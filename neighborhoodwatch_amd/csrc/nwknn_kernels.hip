@@ -997,30 +997,39 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTilePara
     const int wr = w >> 2, wc = w & 3;
     const int g = l >> 4, c16 = l & 15;
     const long long q0 = (long long)tc.qt * H_TM;
-    const long long b0 = (long long)tc.bt * H_TN;
+    // A workgroup walks up to p.tiles_per_wg consecutive base tiles of its query tile ("strip"): the next tile's first two slabs are
+    // requested before the current tile's epilogue, so from the second tile on the DMA round trip, the query-side staging and the
+    // dispatch gap (~4k of a d=1024 tile's ~59k cycles) are hidden or gone.  tc.bt numbers the strip, not the tile.
+    const int T = p.tiles_per_wg > 1 ? p.tiles_per_wg : 1;
+    const int bt_first = p.bt0 + (tc.bt - p.bt0) * T;
+    int n_here = p.bt0 + p.n_btiles_real - bt_first;
+    if (n_here > T) n_here = T;
+    long long b0 = (long long)bt_first * H_TN;
     const int dp = p.dp;
     const int nk = dp / H_BK;
     const _Float16* qp = (const _Float16*)p.qp;
     const _Float16* bp = (const _Float16*)p.bp;
 
-    unsigned voff[4];
+    // DMA: a wave-instruction brings 8 rows x 128 B; wave w owns rows [32w, 32w+32) of both operand tiles.  The swizzle term
+    // ((row >> 1) & 7) of row = 32w + 8i + l/8 is ((i & 1) * 4 + l/16) & 7: two per-lane offsets (i even / odd) serve all four
+    // instructions, the row origins go into the scalar offset next to the slab position.
+    unsigned voff2[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (w * 4 + i) * 8 + (l >> 3);
-        voff[i] = (unsigned)(row * dp * 2 + (((l & 7) ^ ((row >> 1) & 7)) << 4));
-    }
+    for (int i = 0; i < 2; ++i) voff2[i] = (unsigned)((l >> 3) * dp * 2 + (((l & 7) ^ ((i * 4 + (l >> 4)) & 7)) << 4));
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int row_org = wu * 32 * dp * 2, row_step = 8 * dp * 2;                 // bytes (SGPRs)
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(qp + q0 * dp), 0, 0x7FFFFFFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(bp + b0 * dp), 0, 0x7FFFFFFF, 0x00020000);
-    const int lds_w = __builtin_amdgcn_readfirstlane(w * 4096);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(bp + b0 * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const int lds_w = wu * 4096;
     auto issue_stage = [&](int stage, int kt) {
         char* base = smem + stage * H_STAGE + lds_w;
-        const int soff = kt * 128;
+        const int soff = kt * 128 + row_org;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(base + i * 1024), 16, voff[i], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(base + i * 1024), 16, voff2[i & 1], soff + i * row_step, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(base + 32768 + i * 1024), 16, voff[i], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(base + 32768 + i * 1024), 16, voff2[i & 1], soff + i * row_step, 0, 0);
     };
 
     // fragment addresses: row = block*16 + l%16, chunk = 4*ks + l/16, slot = chunk ^ ((row >> 1) & 7); block*16 and the
@@ -1031,14 +1040,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTilePara
 
     // column-side epilogue inputs are (re)computed where they are used, so that nothing but the accumulators, the fragment
     // buffers and a few addresses lives across the K loop (256 VGPRs at two waves per SIMD)
-    const long long col0 = b0 + wc * 64 + c16;
     f32x4 acc[8][4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int m = 0; m < 8; ++m)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[m][n][i] = 0.0f;
     float my_qn = 0.f;                                   // loads out now, used after the first DMAs have been issued
     u64 my_tau = ~0ull;
     if (tid < H_TM) {
@@ -1080,15 +1082,25 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTilePara
     if (nk > 1) issue_stage(1, 1);
     __builtin_amdgcn_sched_barrier(0);
     stage_query_side<METRIC, DENSE, PRE>(epi, H_TM, tid, my_qn, my_tau, p, q0);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    int par = 0;                                         // slab kt of the current tile lives in stage (kt & 1) ^ par
+  for (int t = 0; t < n_here; ++t) {
+    const long long col0 = b0 + wc * 64 + c16;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[m][n][i] = 0.0f;
+    // first tile: only the two slab requests are outstanding; later tiles: the previous epilogue's stores follow them in the counter
+    if (t == 0 && nk > 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (p.dbg) st1 = __builtin_amdgcn_s_memtime();
-    read_A(0, 0, 0, 0);
-    read_B(0, 0, 0);
+    if (p.dbg && t == 0) st1 = __builtin_amdgcn_s_memtime();
+    read_A(0, par, 0, 0);
+    read_B(0, par, 0);
 
     for (int kt = 0; kt + 1 < nk; ++kt) {
-        const int cur = kt & 1;
+        const int cur = (kt & 1) ^ par;
         NWK_SPHASE(0, 0, 0, read_A(1, cur, 0, 1));
         NWK_SPHASE(1, 0, 1, read_A(0, cur, 1, 0); read_B(1, cur, 1));
         NWK_SPHASE(0, 1, 0, read_A(1, cur, 1, 1));
@@ -1101,15 +1113,24 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTilePara
 #pragma unroll
     for (int n = 0; n < 4; ++n) bnv[n] = p.bn[col0 + n * 16];
     {
-        const int cur = (nk - 1) & 1;
+        const int cur = ((nk - 1) & 1) ^ par;
         NWK_SPHASE(0, 0, 0, read_A(1, cur, 0, 1));
         NWK_SPHASE(1, 0, 1, read_A(0, cur, 1, 0); read_B(1, cur, 1));
         NWK_SPHASE(0, 1, 0, read_A(1, cur, 1, 1));
         __builtin_amdgcn_sched_barrier(0);
         mma(1, 1, 1, 0, 4);
     }
-#undef NWK_SPHASE
     if (p.dbg) st2 = __builtin_amdgcn_s_memtime();
+    if (t + 1 < n_here) {                                // wave-uniform: request the next tile's first slabs before this tile's epilogue
+        __builtin_amdgcn_s_barrier();                    // every wave has read its last fragments: both stages are free
+        b0 += H_TN;
+        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(bp + b0 * dp), 0, 0x7FFFFFFF, 0x00020000);
+        par ^= nk & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        issue_stage(par, 0);
+        if (nk > 1) issue_stage(par ^ 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     float cpre[4];
     u32 colv[4];
@@ -1122,8 +1143,14 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTilePara
         const float c = PRE ? prescreen_col<METRIC>(bnv[n], p) : prefilter_col<METRIC>(bnv[n]);
         cpre[n] = colok[n] ? c : __builtin_inff();
     }
+    int g_here = g;                                      // opaque per tile: otherwise the epilogue's 32 list-row addresses are hoisted
+    asm volatile("" : "+v"(g_here));                     // out of the strip loop and live (spilled) through every K loop
+    int c_here = c16;
+    asm volatile("" : "+v"(c_here));
     tile_epilogue16<METRIC, DENSE, PRE>(p, acc, (const float*)epi, (const u64*)(epi + H_TM * 4), (const float*)(epi + H_TM * 12), bnv, colv,
-                                        colok, cpre, q0, wr * 128, g, c16);
+                                        colok, cpre, q0, wr * 128, g_here, c_here);
+  }
+#undef NWK_SPHASE
     if (p.dbg && l == 0) {          // wave 0 writes its own stamps; every wave folds its end times in (the tile ends with its last wave)
         unsigned long long* o = p.dbg + (size_t)blockIdx.x * 8;
         const unsigned long long t3 = __builtin_amdgcn_s_memtime(), r3 = __builtin_amdgcn_s_memrealtime();
@@ -1872,7 +1899,7 @@ static hipError_t launch_tile_f16_metric(hipStream_t st, const NwkTileParams& p,
         else hipLaunchKernelGGL((nwk_tile_kernel_f16q<METRIC, false, 0>), dim3(grid), dim3(256), 0, st, p);
         return hipGetLastError();
     }
-    if (p.f16_shape == 1 && diag == 0) {                   // v_mfma_f32_16x16x32_f16 form
+    if (p.f16_shape == 1 && diag == 0) {                   // v_mfma_f32_16x16x32_f16 form (the caller has set up strips)
         if (dense) hipLaunchKernelGGL((nwk_tile_kernel_f16s<METRIC, true, 0>), dim3(grid), dim3(512), 0, st, p);
         else hipLaunchKernelGGL((nwk_tile_kernel_f16s<METRIC, false, 0>), dim3(grid), dim3(512), 0, st, p);
         return hipGetLastError();
@@ -1892,10 +1919,19 @@ static hipError_t launch_tile_f16_metric(hipStream_t st, const NwkTileParams& p,
 
 // fp16 path: p.n_qtiles counts 256-row query tiles; p.n_btiles / p.bt0 count base tiles of 256 rows (f16_shape 0, 1) or 128 rows
 // (f16_shape 2); p.qp/p.bp point at halves.
+// the 16x16x32 kernel walks strips of p.tiles_per_wg base tiles per workgroup: p.n_btiles becomes the number of strips
+static void setup_strips(NwkTileParams& p, bool dense, int diag)
+{
+    p.n_btiles_real = p.n_btiles;
+    if (p.f16_shape == 1 && diag == 0 && !dense && p.tiles_per_wg > 1) p.n_btiles = (p.n_btiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
+    else p.tiles_per_wg = 1;
+}
+
 hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool dense, int diag)
 {
     if (p.n_qtiles <= 0 || p.n_btiles <= 0) return hipSuccess;
     if (p.sq_shift < 0 || p.sq_shift > 6) return hipErrorInvalidValue;
+    setup_strips(p, dense, diag);
     const int SQ = 1 << p.sq_shift, SB = 64 >> p.sq_shift;
     const long long n_super_q = (p.n_qtiles + SQ - 1) / SQ;
     p.n_super_b = (p.n_btiles + SB - 1) / SB;
@@ -1933,6 +1969,8 @@ hipError_t nwk_launch_tile_prescreen(hipStream_t st, NwkTileParams p, int metric
 {
     if (p.n_qtiles <= 0 || p.n_btiles <= 0) return hipSuccess;
     if (p.sq_shift < 0 || p.sq_shift > 6) return hipErrorInvalidValue;
+    if (metric == NWKNN_METRIC_COSINE && p.f16_shape == 0) p.f16_shape = 1;       // cosine has 16x16x32 builds only
+    setup_strips(p, false, 0);
     const int SQ = 1 << p.sq_shift, SB = 64 >> p.sq_shift;
     const long long n_super_q = (p.n_qtiles + SQ - 1) / SQ;
     p.n_super_b = (p.n_btiles + SB - 1) / SB;

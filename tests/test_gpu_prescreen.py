@@ -257,3 +257,22 @@ def test_repair_pass_with_duplicates_in_the_lists(oracle, metric):
         rd, ri = oracle.knn_canonical(base, queries, k, metric)
         assert st["prescreen"] == 1 and st["overflowed_queries"] > 0 and st["rescan_launches"] > 0
         assert np.array_equal(idx, ri) and _bitwise(dist, rd)
+
+
+@pytest.mark.parametrize("strip", [2, 3, 5])
+@pytest.mark.parametrize("d", [40, 64, 192, 200])            # 1, 1, 3, 4 slabs of 64 halves: odd counts flip the LDS stage parity per tile
+def test_strips_of_base_tiles_per_workgroup(oracle, strip, d):
+    """Option f16_strip: a workgroup of the 16x16x32 fp16 kernel walks several consecutive base tiles, requesting the next tile's
+    first slabs before the current tile's epilogue (measured +1 % at best, so 1 is the default; the path must still be exact)."""
+    from neighborhoodwatch_amd import KnnEngine
+    base = oracle.gen(0x41 + d, 0, 7000, d)                    # 28 base tiles of 256 rows: strips of 3 and 5 leave a remainder
+    queries = oracle.gen(0x42 + d, 0, 300, d)
+    with KnnEngine(0) as eng:
+        eng.set_option("f16_strip", strip)
+        eng.set_prescreen(True)
+        eng.set_base(base)
+        for metric in ADDITIVE:
+            dist, idx = eng.search(queries, 20, metric)
+            rd, ri = oracle.knn_canonical(base, queries, 20, metric)
+            assert eng.stats()["prescreen"] == 1
+            assert np.array_equal(idx, ri) and _bitwise(dist, rd), (metric, strip, d)
