@@ -398,7 +398,9 @@ static int set_base_common(nwknn_ctx* h, const void* base, const void* const* co
             h->b_scale = prescreen_scale(h->b_maxabs);
             h->pre_ok = 1;
             h->pre_kind = -1;
-            RCCHK(ensure_base_copy(h, 0));          // the cosine flavour is made on demand by the first cosine search
+            const int rc = ensure_base_copy(h, 0);  // the cosine flavour is made on demand by the first cosine search
+            if (rc == NWKNN_ENOMEM) h->pre_ok = 0;  // no room for the fp16 copy next to the fp32 base: searches use the direct kernel
+            else RCCHK(rc);
         }
     }
     if (h->opt_profile) {
