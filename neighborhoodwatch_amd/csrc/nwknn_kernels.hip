@@ -699,7 +699,9 @@ __global__ __launch_bounds__(256, 2) void nwk_tile_kernel(const NwkTileParams p)
     if (p.dbg && tid == 0) {
         unsigned long long* o = p.dbg + (size_t)blockIdx.x * 8;
         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memtime(); o[4] = rt0; o[5] = __builtin_amdgcn_s_memrealtime();
-        o[6] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); o[7] = 1;      // HW_REG_XCC_ID (id 20), bits [3:0]
+        o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32      // HW_REG_XCC_ID[3:0]
+             | (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));           // HW_REG_HW_ID
+        o[7] = 1;
     }
 }
 

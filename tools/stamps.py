@@ -31,3 +31,22 @@ for name, v in (("prologue", pro), ("k-loop", loop), ("epilogue", epi), ("total"
     print(f"  {name:9s} cycles: median {np.median(v):9.0f}  p10 {np.percentile(v,10):9.0f}  p90 {np.percentile(v,90):9.0f}")
 mfma = (d // 2) * 8 * 64 if dtype == "f32" else (d // 16) * 8 * 32
 print(f"  ideal MFMA cycles per wave per tile: {mfma}; x2 (two waves share a SIMD): {2*mfma}")
+
+if dtype == "f32":
+    hw = a[:, 6]
+    cu_key = ((hw >> 32) << 16) | (hw & 0xFF00)
+    util = []; gaps = []
+    for key in np.unique(cu_key):
+        m = a[cu_key == key]
+        span = (m[:, 5].max() - m[:, 4].min()) * 10.0
+        util.append(((m[:, 5] - m[:, 4]) * 10.0).sum() / (2.0 * span))
+        # two slots per CU: greedy assignment of workgroups (by start time) to the slot that frees first
+        m = m[np.argsort(m[:, 4])]
+        free = [None, None]
+        for st, en in zip(m[:, 4], m[:, 5]):
+            j = 0 if (free[0] is None or (free[1] is not None and free[0] <= free[1])) else 1
+            if free[j] is not None: gaps.append((st - free[j]) * 10.0)
+            free[j] = en
+    gaps = np.array(gaps)
+    print(f"  CUs seen {len(util)}; slot occupancy (sum of workgroup residency / 2 / span): median {np.median(util):.3f}; "
+          f"gap slot-free -> next workgroup start ns: median {np.median(gaps):.0f} p10 {np.percentile(gaps,10):.0f} p90 {np.percentile(gaps,90):.0f}")
