@@ -2,6 +2,8 @@
 bit for bit (the direct kernel itself is pinned to the CPU oracle by test_gpu_parity.py).  Seeds are fixed: the cases are the same
 on every run.  The data families are chosen to stress the bound and the tie handling: heavy exact ties (small integers), clustered
 rows, low-rank rows, wide magnitude spreads, unit rows, and k from 1 to a few hundred."""
+import os
+
 import numpy as np
 import pytest
 
@@ -32,7 +34,11 @@ def _make(rng, family, rows, d):
 FAMILIES = ["normal", "integers", "clustered", "lowrank", "spread", "unit"]
 
 
-@pytest.mark.parametrize("seed", range(150))
+SEED0 = int(os.environ.get("NWKNN_FUZZ_SEED0", "0"))          # one-off soaks: NWKNN_FUZZ_SEED0=1000 NWKNN_FUZZ_CASES=2000 pytest ...
+CASES = int(os.environ.get("NWKNN_FUZZ_CASES", "150"))
+
+
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + CASES))
 def test_prescreened_search_equals_direct_search(seed):
     import torch
     from neighborhoodwatch_amd import KnnEngine
