@@ -92,7 +92,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = 3, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = 1, opt_pre_eps_pct = 100, opt_f16_strip = 1;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = 3, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = 1, opt_pre_eps_pct = 100, opt_f16_strip = 4;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -228,7 +228,7 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
         h->opt_prescreen = value ? 1 : 0;   // takes effect at the next nwknn_set_base (it builds the fp16 copy of the base)
     } else if (!strcmp(name, "f16_strip")) {
         if (value < 1 || value > 64) return fail(NWKNN_EINVAL, "f16_strip must be 1..64");
-        h->opt_f16_strip = value;           // base tiles a workgroup of the 16x16x32 fp16 kernel walks in a row
+        h->opt_f16_strip = value;           // base tiles a workgroup of the 16x16x32 fp16 kernel walks in a row (default 4)
     } else if (!strcmp(name, "pre_eps_pct")) {
         h->opt_pre_eps_pct = value;         // dev: scales the pre-screen error bound (results are only guaranteed at >= 100)
     } else if (!strcmp(name, "f16_mfma")) {

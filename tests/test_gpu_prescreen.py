@@ -259,11 +259,11 @@ def test_repair_pass_with_duplicates_in_the_lists(oracle, metric):
         assert np.array_equal(idx, ri) and _bitwise(dist, rd)
 
 
-@pytest.mark.parametrize("strip", [2, 3, 5])
+@pytest.mark.parametrize("strip", [1, 2, 3, 5])
 @pytest.mark.parametrize("d", [40, 64, 192, 200])            # 1, 1, 3, 4 slabs of 64 halves: odd counts flip the LDS stage parity per tile
 def test_strips_of_base_tiles_per_workgroup(oracle, strip, d):
     """Option f16_strip: a workgroup of the 16x16x32 fp16 kernel walks several consecutive base tiles, requesting the next tile's
-    first slabs before the current tile's epilogue (measured +1 % at best, so 1 is the default; the path must still be exact)."""
+    first slabs before the current tile's epilogue (+1 % at d=1024, +5 % at d=128; default 4)."""
     from neighborhoodwatch_amd import KnnEngine
     base = oracle.gen(0x41 + d, 0, 7000, d)                    # 28 base tiles of 256 rows: strips of 3 and 5 leave a remainder
     queries = oracle.gen(0x42 + d, 0, 300, d)
