@@ -84,6 +84,7 @@ struct nwknn_ctx {
     // fp16 pre-screen of the exact fp32 search (option "prescreen"): scaled fp16 copies of bp / qp
     DevBuf bp16, qp16, cnt0, scal;
     int pre_ok = 0;                 // the current base can be pre-screened (finite, sane magnitudes); bp16 holds a copy of kind pre_kind
+    int f16_finite = 0;             // fp16 compute path: the prepared base holds no Inf/NaN (exact fp16 mode is possible)
     int pre_kind = -1;              // 0: rows scaled by b_scale (sqeuclidean, one_minus_dot); 1: unit rows x 2^14 (cosine); -1: none yet
     int dp16 = 0;
     float b_scale = 1.f, b_maxabs = 0.f;
@@ -92,7 +93,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = 3, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = 1, opt_pre_eps_pct = 100, opt_f16_strip = 4;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = 3, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = 1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -226,6 +227,8 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
         h->opt_compute_f16 = value;      // takes effect at the next nwknn_set_base
     } else if (!strcmp(name, "prescreen")) {
         h->opt_prescreen = value ? 1 : 0;   // takes effect at the next nwknn_set_base (it builds the fp16 copy of the base)
+    } else if (!strcmp(name, "f16_exact")) {
+        h->opt_f16_exact = value ? 1 : 0;   // fp16 compute path: 1 (default) rescoring to the canonical fp32 chain over the fp16 values, 0 raw MFMA sums
     } else if (!strcmp(name, "f16_strip")) {
         if (value < 1 || value > 64) return fail(NWKNN_EINVAL, "f16_strip must be 1..64");
         h->opt_f16_strip = value;           // base tiles a workgroup of the 16x16x32 fp16 kernel walks in a row (default 4)
@@ -345,6 +348,18 @@ static int matrix_maxabs(nwknn_ctx* h, const float* x, long long n, float* maxab
     *usable = bits < 0x7F800000u && v >= 0x1p-40f && v <= 0x1p40f;
     return NWKNN_OK;
 }
+// fp16 matrix: true when it holds no Inf/NaN
+static int matrix_finite_f16(nwknn_ctx* h, const void* x, long long n, bool* finite)
+{
+    RCCHK(h->scal.ensure(16));
+    HIPCHK(hipMemsetAsync(h->scal.p, 0, 4, h->stream));
+    HIPCHK(nwk_launch_maxabs_f16(h->stream, x, n, h->scal.as<u32>()));
+    u32 bits = 0;
+    HIPCHK(hipMemcpyAsync(&bits, h->scal.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *finite = bits < 0x7C00u;
+    return NWKNN_OK;
+}
 // power of two that puts maxabs in [2^14, 2^15)
 static float prescreen_scale(float maxabs)
 {
@@ -389,6 +404,12 @@ static int set_base_common(nwknn_ctx* h, const void* base, const void* const* co
     else RCCHK(stage_and_prep(h, base, location, dtype == NWKNN_DTYPE_F16, f16, rows, d, rows_pad, dp, h->braw, h->bp.p, h->bn.as<float>()));
     h->nb = rows; h->nb_pad = rows_pad; h->d = d; h->dp = dp; h->f16 = f16; h->ms_docs = 0;
     h->pre_ok = 0;
+    h->f16_finite = 0;
+    if (f16 && h->opt_f16_exact) {
+        bool finite = false;
+        RCCHK(matrix_finite_f16(h, h->bp.p, rows_pad * (long long)dp, &finite));
+        h->f16_finite = finite ? 1 : 0;
+    }
     if (pre) {
         bool usable = false;
         RCCHK(matrix_maxabs(h, h->bp.as<float>(), rows_pad * (long long)dp, &h->b_maxabs, &usable));
@@ -428,6 +449,7 @@ extern "C" int nwknn_set_base_columns(nwknn_handle h, const void* const* columns
 struct SearchPlan {
     int cap; long long first, max_chunk, safe; int tile_rows; int granule;
     bool pre;                                   // filtered chunks run the fp16 pre-screen + fp32 rescoring
+    bool native16;                              // exact fp16 mode: the fp16 rows ARE the data (no copies); the dense chunk is rescored too
     float pre_scale, pre_eps_half, pre_aq, pre_ab, pre_cst;
 };
 
@@ -451,6 +473,7 @@ static int make_plan(nwknn_ctx* h, int k, long long nq, bool pre, SearchPlan* pl
     // to fill the chip with such tiles, else 128 (less padding waste)
     pl->tile_rows = (h->f16 || pre) ? NWK_F16_TILE_ROWS : (h->opt_tile_rows ? (int)h->opt_tile_rows : (nq >= 2048 ? 256 : 128));
     pl->pre = pre;
+    pl->native16 = false;
     pl->pre_scale = 1.f; pl->pre_eps_half = pl->pre_aq = pl->pre_ab = pl->pre_cst = 0.f;
     return NWKNN_OK;
 }
@@ -489,7 +512,7 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
                      const int* qtile_list, int n_list_tiles, bool dedupe, bool rescan)
 {
     NwkTileParams tp = tile_params(h, pl, nq_pad);
-    const bool prescreen = pl.pre && !dense;               // the dense first chunk of a pre-screened search runs the fp32 kernel
+    const bool prescreen = pl.pre && (!dense || pl.native16);   // fp32 data: the dense first chunk runs the fp32 kernel
     const int btile = ((h->f16 || prescreen) && h->opt_f16_shape != 2) ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS;   // f16_mfma=2: 256 x 128 tiles
     tp.bt0 = (int)(lo / btile);
     tp.n_btiles = (int)(rows / btile);
@@ -497,21 +520,26 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
     if (qtile_list) { tp.qtile_list = qtile_list; tp.n_qtiles = n_list_tiles; }
     EvPair* e = ev_begin(h, 0);
     if (prescreen) {
-        tp.qp = h->qp16.as<float>(); tp.bp = h->bp16.as<float>(); tp.dp = h->dp16;
+        if (!pl.native16) { tp.qp = h->qp16.as<float>(); tp.bp = h->bp16.as<float>(); tp.dp = h->dp16; }
         tp.pre_inv_scale = 1.0f / pl.pre_scale;
         tp.pre_scale = pl.pre_scale; tp.pre_eps_half = pl.pre_eps_half; tp.pre_aq = pl.pre_aq; tp.pre_ab = pl.pre_ab; tp.pre_cst = pl.pre_cst;
-        HIPCHK(nwk_launch_tile_prescreen(h->stream, tp, metric));
+        HIPCHK(nwk_launch_tile_prescreen(h->stream, tp, metric, dense));
     } else if (h->f16) HIPCHK(nwk_launch_tile_f16(h->stream, tp, metric, dense, (int)h->opt_diag));
     else HIPCHK(nwk_launch_tile(h->stream, tp, metric, dense, pl.tile_rows, (int)h->opt_diag));
     ev_end(h, e);
     if (prescreen) {                                       // listed pairs -> canonical fp32 keys, in place
+        if (dense) {                                       // (exact fp16 mode) every slot of the dense chunk is a candidate: [0, rows)
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)h->cnt.p, (int)rows, (size_t)nq_pad, h->stream));
+            HIPCHK(hipMemsetAsync(h->cnt0.p, 0, (size_t)nq_pad * 4, h->stream));
+        }
         NwkRescoreParams rp;
         rp.qp = h->qp.as<float>(); rp.bp = h->bp.as<float>(); rp.qn = h->qn.as<float>(); rp.bn = h->bn.as<float>();
         rp.buf = h->buf.as<u64>(); rp.cnt = h->cnt.as<u32>(); rp.cnt0 = h->cnt0.as<u32>();
         rp.dp = h->dp; rp.cap = pl.cap; rp.k = k;
         // no pruning on a repair pass: it re-finds pairs that are already listed, and the k-th smallest upper bound over a list
         // with duplicates can lie below the k-th distinct distance
-        rp.prune = (h->opt_pre_prune && !dedupe) ? 1 : 0;
+        rp.prune = (h->opt_pre_prune && !dedupe && !dense) ? 1 : 0;
+        rp.rows16 = pl.native16 ? 1 : 0;
         rp.eps_half = pl.pre_eps_half; rp.aq = pl.pre_aq; rp.ab = pl.pre_ab; rp.cst = pl.pre_cst;
         e = ev_begin(h, 3);
         HIPCHK(nwk_launch_rescore(h->stream, rp, metric, nq_pad));
@@ -606,6 +634,9 @@ static int search_common(nwknn_ctx* h, const void* queries, const void* const* q
         return fail(NWKNN_EINVAL, "nwknn_search: bad location");
     RCCHK(use_device(h));
     bool pre = h->pre_ok && !h->f16;
+    // exact fp16 mode (fp16 compute path, option f16_exact): the fp16 MFMA kernel pre-screens, every listed pair is rescored with
+    // the fp32 chain over the fp16 values.  Cosine keeps the raw MFMA sums (its pre-screen wants unit-row copies).
+    bool native16 = h->f16 && h->opt_f16_exact && h->f16_finite && metric != NWKNN_METRIC_COSINE;
     SearchPlan pl;
     RCCHK(make_plan(h, k, nq, pre, &pl));
 
@@ -664,7 +695,24 @@ static int search_common(nwknn_ctx* h, const void* queries, const void* const* q
             }
         }
     }
-    h->stats.prescreen = pre ? 1 : 0;
+    if (native16) {
+        bool finite = false;
+        RCCHK(matrix_finite_f16(h, h->qp.p, nq_pad * (long long)h->dp, &finite));
+        if (finite) {
+            RCCHK(h->cnt0.ensure((size_t)nq_pad * 4));
+            HIPCHK(hipMemsetAsync(h->cnt0.p, 0, (size_t)nq_pad * 4, h->stream));
+            const double u = 0x1p-24, dd = (double)h->dp;
+            // the inputs are exact (the fp16 MFMA keeps subnormals: tools/f16_denorm.py): only the two summations differ --
+            // the canonical chain (d u) and the MFMA's own (allowed 4 d u, measured ~2 u), 2 % slack
+            pl.pre = true; pl.native16 = true;
+            pl.pre_scale = 1.0f;
+            pl.pre_eps_half = (float)(0.5 * 1.02 * 5.5 * dd * u * (double)h->opt_pre_eps_pct / 100.0);
+            pl.pre_aq = pl.pre_ab = pl.pre_cst = 0.0f;
+        } else {
+            native16 = false;
+        }
+    }
+    h->stats.prescreen = (pre || native16) ? 1 : 0;
     HIPCHK(hipMemsetAsync(h->tau.p, 0xFF, (size_t)nq_pad * 8, h->stream));
     HIPCHK(hipMemsetAsync(h->cnt.p, 0, (size_t)nq_pad * 4, h->stream));
     HIPCHK(hipMemsetAsync(h->ovf.p, 0, (size_t)nq_pad * 4, h->stream));

@@ -56,6 +56,7 @@ struct NwkRescoreParams {
     int dp;
     int cap;
     int k;
+    int rows16;                    // 1: qp / bp hold fp16 rows in natural k order (exact fp16 mode); 0: prepared fp32 rows
     int prune;                     // 1: derive bounds from the fp16 estimates and skip pairs that cannot reach the top k
     float eps_half, aq, ab, cst;   // the constants of the pre-screen error bound (as in NwkTileParams)
 };
@@ -83,7 +84,8 @@ hipError_t nwk_launch_prep_strided(hipStream_t st, const void* raw, int in_dtype
                                    long long rows_pad, int dp, int out_f16, void* prepared, float* norms);
 hipError_t nwk_launch_prep(hipStream_t st, const float* raw, long long rows, int d, long long rows_pad, int dp, float* prepared, float* norms);
 hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool dense, int tile_rows, int diag);
-hipError_t nwk_launch_tile_prescreen(hipStream_t st, NwkTileParams p, int metric);
+hipError_t nwk_launch_tile_prescreen(hipStream_t st, NwkTileParams p, int metric, bool dense);
+hipError_t nwk_launch_maxabs_f16(hipStream_t st, const void* x, long long n, unsigned int* out_bits);
 hipError_t nwk_launch_rescore(hipStream_t st, const NwkRescoreParams& p, int metric, long long nq_pad);
 hipError_t nwk_launch_maxabs(hipStream_t st, const float* x, long long n, unsigned int* out_bits);
 hipError_t nwk_launch_half_copy(hipStream_t st, const float* prepared, long long rows_pad, int dp32, int dp16, float scale, const float* norms,

@@ -905,10 +905,18 @@ __device__ __forceinline__ void tile_epilogue16(const NwkTileParams& p, const f3
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float dist = distance_epilogue<METRIC>(acc[m][n][i], qn4[i], bnv[n]);
-                    const u32 sd = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? (__float_as_uint(dist) | 0x80000000u) : sortable_u32(dist);
+                    u32 hi;
+                    if (PRE) {                                     // exact fp16 mode: every slot carries the estimate and is rescored
+                        const float sdot = acc[m][n][i];
+                        const float est = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? __fmaf_rn(-2.0f * p.pre_inv_scale, sdot, qn4[i] + bnv[n])
+                                                                               : 1.0f - sdot * p.pre_inv_scale;
+                        hi = __float_as_uint(est);
+                    } else {
+                        const float dist = distance_epilogue<METRIC>(acc[m][n][i], qn4[i], bnv[n]);
+                        hi = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? (__float_as_uint(dist) | 0x80000000u) : sortable_u32(dist);
+                    }
                     const long long slot = (long long)(colv[n] - (u32)p.dense_col0);
-                    p.buf[(q0 + rb + i) * cap + slot] = colok[n] ? (((u64)sd << 32) | colv[n]) : ~0ull;
+                    p.buf[(q0 + rb + i) * cap + slot] = colok[n] ? (((u64)hi << 32) | colv[n]) : ~0ull;
                 }
             continue;
         }
@@ -1500,6 +1508,23 @@ __global__ __launch_bounds__(256) void nwk_maxabs_kernel(const float* __restrict
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out_bits, m);
 }
 
+// max |bits| over an fp16 matrix (n8 groups of 8 halves): >= 0x7C00 means Inf/NaN somewhere
+__global__ __launch_bounds__(256) void nwk_maxabs_f16_kernel(const _Float16* __restrict__ x, long long n8, u32* __restrict__ out_bits)
+{
+    u32 m = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const u32x4 v = *(const u32x4*)(x + 8 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32 lo = v[j] & 0x7FFFu, hi = (v[j] >> 16) & 0x7FFFu;
+            m = lo > m ? lo : m; m = hi > m ? hi : m;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const u32 o = (u32)__shfl_xor((int)m, off); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out_bits, m);
+}
+
 __global__ __launch_bounds__(256) void nwk_half_copy_kernel(const float* __restrict__ prepared, long long rows_pad, int dp32, int dp16,
                                                              float scale0, const float* __restrict__ norms, _Float16* __restrict__ out)
 {
@@ -1534,7 +1559,7 @@ __global__ __launch_bounds__(256) void nwk_half_copy_kernel(const float* __restr
 //   3. the survivors are packed and rescored 64 at a time: ascending-k fmaf chain over the prepared fp32 rows (the chain the
 //      fp32 MFMA accumulator performs), canonical epilogue, 64-bit key written back in place; dropped entries become ~0
 //      (the sentinel compaction already sorts last).
-template <int METRIC>
+template <int METRIC, bool ROWS16>
 __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams p)
 {
     extern __shared__ __attribute__((aligned(16))) u32 rs_dyn[];
@@ -1546,7 +1571,8 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
     u32 end = p.cnt[q];
     if (end > (u32)p.cap) end = (u32)p.cap;
     if (start >= end) return;
-    const float* __restrict__ qrow = p.qp + q * p.dp;
+    const float* __restrict__ qrow = ROWS16 ? nullptr : p.qp + q * p.dp;
+    const _Float16* __restrict__ qrow16 = ROWS16 ? (const _Float16*)p.qp + q * p.dp : nullptr;      // exact fp16 mode: the rows ARE the data
     const float qn = p.qn[q];
     u64* list = p.buf + q * p.cap;
 
@@ -1558,6 +1584,7 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
             if (e < end) {
                 const u64 key = list[e];
                 if (e < start) { s_ub[e] = (u32)(key >> 32); s_lb[e] = 0u; }
+                else if (key == ~0ull) { s_ub[e] = 0xFFFFFFFFu; s_lb[e] = 0xFFFFFFFFu; }       // empty slot of a dense chunk
                 else {
                     const float est = __uint_as_float((u32)(key >> 32));
                     const float bn = p.bn[(u32)key];
@@ -1610,20 +1637,31 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
         const u32 i = i0 + lane;
         const bool live = i < nsurv;
         const u32 e = live ? (packed ? s_ub[i] : start + i) : start;
-        const u32 col = live ? (u32)list[e] : 0u;
-        const float* __restrict__ brow = p.bp + (long long)col * p.dp;
+        const u64 old = live ? list[e] : ~0ull;
+        const bool valid = old != ~0ull;                               // dense chunks leave ~0 in the slots of padding columns
+        const u32 col = valid ? (u32)old : 0u;
         float acc = 0.0f;
-        for (int k0 = 0; k0 < p.dp; k0 += 8) {
-            const f32x4 be = *(const f32x4*)(brow + k0), bo = *(const f32x4*)(brow + k0 + 4);
-            const f32x4 qe = *(const f32x4*)(qrow + k0), qo = *(const f32x4*)(qrow + k0 + 4);
+        if (ROWS16) {
+            const _Float16* __restrict__ brow = (const _Float16*)p.bp + (long long)col * p.dp;
+            for (int k0 = 0; k0 < p.dp; k0 += 8) {
+                const f16x8 bv = *(const f16x8*)(brow + k0), qv = *(const f16x8*)(qrow16 + k0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {                              // k = k0+2j, then k0+2j+1: ascending
-                acc = __fmaf_rn(qe[j], be[j], acc);
-                acc = __fmaf_rn(qo[j], bo[j], acc);
+                for (int j = 0; j < 8; ++j) acc = __fmaf_rn((float)qv[j], (float)bv[j], acc);       // natural order: ascending k
+            }
+        } else {
+            const float* __restrict__ brow = p.bp + (long long)col * p.dp;
+            for (int k0 = 0; k0 < p.dp; k0 += 8) {
+                const f32x4 be = *(const f32x4*)(brow + k0), bo = *(const f32x4*)(brow + k0 + 4);
+                const f32x4 qe = *(const f32x4*)(qrow + k0), qo = *(const f32x4*)(qrow + k0 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                          // k = k0+2j, then k0+2j+1: ascending
+                    acc = __fmaf_rn(qe[j], be[j], acc);
+                    acc = __fmaf_rn(qo[j], bo[j], acc);
+                }
             }
         }
         const float dist = distance_epilogue<METRIC>(acc, qn, p.bn[col]);
-        if (live) list[e] = ((u64)sortable_u32(dist) << 32) | col;
+        if (valid) list[e] = ((u64)sortable_u32(dist) << 32) | col;
     }
 }
 
@@ -1967,12 +2005,13 @@ hipError_t nwk_launch_maxsim(hipStream_t st, NwkTileParams p, bool dense)
 }
 
 // pre-screen launch of the fp16 tile kernel: p.qp/p.bp are the scaled fp16 copies, tiles are 256 x 256, never dense
-hipError_t nwk_launch_tile_prescreen(hipStream_t st, NwkTileParams p, int metric)
+hipError_t nwk_launch_tile_prescreen(hipStream_t st, NwkTileParams p, int metric, bool dense)
 {
     if (p.n_qtiles <= 0 || p.n_btiles <= 0) return hipSuccess;
     if (p.sq_shift < 0 || p.sq_shift > 6) return hipErrorInvalidValue;
     if (metric == NWKNN_METRIC_COSINE && p.f16_shape == 0) p.f16_shape = 1;       // cosine has 16x16x32 builds only
-    setup_strips(p, false, 0);
+    if (dense) p.f16_shape = 1;                                                    // dense + estimate keys (exact fp16 mode): 16x16x32 build
+    setup_strips(p, dense, 0);
     const int SQ = 1 << p.sq_shift, SB = 64 >> p.sq_shift;
     const long long n_super_q = (p.n_qtiles + SQ - 1) / SQ;
     p.n_super_b = (p.n_btiles + SB - 1) / SB;
@@ -1980,6 +2019,14 @@ hipError_t nwk_launch_tile_prescreen(hipStream_t st, NwkTileParams p, int metric
     supers = (supers + 7) / 8 * 8;
     const long long grid = supers * 64;
     if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    if (dense) {
+        if (metric == NWKNN_METRIC_SQEUCLIDEAN)
+            hipLaunchKernelGGL((nwk_tile_kernel_f16s<NWKNN_METRIC_SQEUCLIDEAN, true, 1>), dim3((unsigned)grid), dim3(512), 0, st, p);
+        else if (metric == NWKNN_METRIC_ONE_MINUS_DOT)
+            hipLaunchKernelGGL((nwk_tile_kernel_f16s<NWKNN_METRIC_ONE_MINUS_DOT, true, 1>), dim3((unsigned)grid), dim3(512), 0, st, p);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if (p.f16_shape == 2) {
         if (metric == NWKNN_METRIC_SQEUCLIDEAN)
             hipLaunchKernelGGL((nwk_tile_kernel_f16q<NWKNN_METRIC_SQEUCLIDEAN, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, p);
@@ -2011,13 +2058,16 @@ hipError_t nwk_launch_rescore(hipStream_t st, const NwkRescoreParams& p, int met
     const int waves = p.cap <= 1024 ? 4 : (p.cap <= 2048 ? 2 : 1);         // nq_pad is a multiple of 256
     const unsigned grid = (unsigned)(nq_pad / waves);
     const size_t lds = (size_t)waves * p.cap * 8 + 512;        // + slack: predicated-off lanes may still address past `end`
-    if (metric == NWKNN_METRIC_SQEUCLIDEAN)
-        hipLaunchKernelGGL((nwk_rescore_kernel<NWKNN_METRIC_SQEUCLIDEAN>), dim3(grid), dim3(64 * waves), lds, st, p);
-    else if (metric == NWKNN_METRIC_ONE_MINUS_DOT)
-        hipLaunchKernelGGL((nwk_rescore_kernel<NWKNN_METRIC_ONE_MINUS_DOT>), dim3(grid), dim3(64 * waves), lds, st, p);
-    else if (metric == NWKNN_METRIC_COSINE)
-        hipLaunchKernelGGL((nwk_rescore_kernel<NWKNN_METRIC_COSINE>), dim3(grid), dim3(64 * waves), lds, st, p);
+#define NWK_RS(M)                                                                                                        \
+    do {                                                                                                                  \
+        if (p.rows16) hipLaunchKernelGGL((nwk_rescore_kernel<M, true>), dim3(grid), dim3(64 * waves), lds, st, p);        \
+        else hipLaunchKernelGGL((nwk_rescore_kernel<M, false>), dim3(grid), dim3(64 * waves), lds, st, p);                \
+    } while (0)
+    if (metric == NWKNN_METRIC_SQEUCLIDEAN) NWK_RS(NWKNN_METRIC_SQEUCLIDEAN);
+    else if (metric == NWKNN_METRIC_ONE_MINUS_DOT) NWK_RS(NWKNN_METRIC_ONE_MINUS_DOT);
+    else if (metric == NWKNN_METRIC_COSINE) NWK_RS(NWKNN_METRIC_COSINE);
     else return hipErrorInvalidValue;
+#undef NWK_RS
     return hipGetLastError();
 }
 
@@ -2027,6 +2077,15 @@ hipError_t nwk_launch_maxabs(hipStream_t st, const float* x, long long n, unsign
     long long blocks = (n / 4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(nwk_maxabs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n / 4, out_bits);
+    return hipGetLastError();
+}
+
+hipError_t nwk_launch_maxabs_f16(hipStream_t st, const void* x, long long n, unsigned int* out_bits)
+{
+    if (n <= 0) return hipSuccess;                              // n is a multiple of 64 halves
+    long long blocks = (n / 8 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(nwk_maxabs_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const _Float16*)x, n / 8, out_bits);
     return hipGetLastError();
 }
 

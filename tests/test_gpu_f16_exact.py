@@ -1,0 +1,103 @@
+"""Exact fp16 mode (default on the fp16 compute path): the fp16 MFMA kernel only pre-screens; every listed pair, the dense first
+chunk included, is rescored with the fp32 ascending-k fmaf chain over the fp16 VALUES.  The result is therefore the canonical one of
+the fp32 oracle applied to the fp16-rounded inputs -- bit for bit, indices and distances -- instead of "whatever order the MFMA sums in"."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EXACT = ["sqeuclidean", "one_minus_dot"]
+
+
+def _bitwise(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", EXACT)
+@pytest.mark.parametrize("shape", [(100, 1000, 384, 10), (37, 2000, 100, 16), (9, 130, 36, 130), (300, 5000, 768, 100),
+                                   (1, 129, 1, 1), (129, 4097, 33, 7), (520, 9000, 1536, 50), (64, 20000, 64, 1000)])
+def test_fp16_inputs_give_the_canonical_result_bit_for_bit(oracle, shape, metric):
+    from neighborhoodwatch_amd import KnnEngine
+    q, b, d, k = shape
+    rng = np.random.default_rng(d * 7 + k)
+    base16 = rng.standard_normal((b, d)).astype(np.float16)
+    queries16 = rng.standard_normal((q, d)).astype(np.float16)
+    with KnnEngine(0) as eng:
+        eng.set_base(base16)                                   # fp16 input selects the fp16 compute path
+        dist, idx = eng.search(queries16, k, metric)
+        assert eng.stats()["prescreen"] == 1
+    rd, ri = oracle.knn_canonical(base16.astype(np.float32), queries16.astype(np.float32), k, metric)
+    assert np.array_equal(idx, ri), f"indices differ at {(idx != ri).sum()} of {idx.size} positions"
+    assert _bitwise(dist, rd)
+
+
+def test_fp32_input_on_the_fp16_path_is_canonical_on_the_rounded_values(oracle):
+    from neighborhoodwatch_amd import KnnEngine
+    base, queries = oracle.gen(0x81, 0, 6000, 200), oracle.gen(0x82, 0, 250, 200)
+    with KnnEngine(0) as eng:
+        eng.set_compute_dtype("f16")
+        eng.set_base(base)
+        for metric in EXACT:
+            dist, idx = eng.search(queries, 40, metric)
+            rd, ri = oracle.knn_canonical(base.astype(np.float16).astype(np.float32), queries.astype(np.float16).astype(np.float32), 40, metric)
+            assert np.array_equal(idx, ri) and _bitwise(dist, rd)
+
+
+def test_ties_subnormals_and_shards(oracle):
+    from neighborhoodwatch_amd import KnnEngine
+    from neighborhoodwatch_amd.distributed import shard_bounds
+    rng = np.random.default_rng(3)
+    base16 = rng.integers(-4, 5, size=(9000, 48)).astype(np.float16)           # small integers: masses of exactly equal distances
+    base16[::11] *= np.float16(2.0 ** -20)                                      # rows of fp16 subnormals (the MFMA keeps them)
+    queries16 = rng.integers(-4, 5, size=(200, 48)).astype(np.float16)
+    bf, qf = base16.astype(np.float32), queries16.astype(np.float32)
+    with KnnEngine(0) as eng:
+        for metric in EXACT:
+            eng.set_base(base16)
+            dist, idx = eng.search(queries16, 60, metric)
+            rd, ri = oracle.knn_canonical(bf, qf, 60, metric)
+            assert np.array_equal(idx, ri) and _bitwise(dist, rd)
+            pd, pi = [], []
+            for r in range(3):
+                lo, hi = shard_bounds(9000, 3, r)
+                eng.set_base(base16[lo:hi])
+                dd, ii = eng.search(queries16, 60, metric, index_offset=lo)
+                pd.append(dd); pi.append(ii)
+            md, mi = eng.merge(np.stack(pd), np.stack(pi), 60)
+            assert np.array_equal(mi, ri) and _bitwise(md, rd)
+
+
+def test_overflow_repair_in_exact_fp16_mode(oracle):
+    from neighborhoodwatch_amd import KnnEngine
+    d, B, Q, k = 32, 8000, 150, 10
+    rng = np.random.default_rng(5)
+    centre = rng.standard_normal(d).astype(np.float32)
+    base16 = (centre[None, :] + rng.standard_normal((B, d)).astype(np.float32) * np.linspace(4.0, 0.05, B, dtype=np.float32)[:, None]).astype(np.float16)
+    queries16 = (centre[None, :] + 0.01 * rng.standard_normal((Q, d))).astype(np.float16)
+    with KnnEngine(0) as eng:
+        eng.set_option("capacity", 512)
+        eng.set_option("first_chunk", 256)
+        eng.set_base(base16)
+        dist, idx = eng.search(queries16, k)
+        st = eng.stats()
+    rd, ri = oracle.knn_canonical(base16.astype(np.float32), queries16.astype(np.float32), k)
+    assert st["overflowed_queries"] > 0 and st["rescan_launches"] > 0
+    assert np.array_equal(idx, ri) and _bitwise(dist, rd)
+
+
+def test_non_finite_fp16_inputs_and_the_legacy_switch(oracle):
+    """Inf/NaN in fp16 data and option f16_exact=0 both run the raw MFMA-sum path (tolerance parity, stats.prescreen == 0)."""
+    from neighborhoodwatch_amd import KnnEngine
+    base16 = oracle.gen_f16_numpy(0x71, 0, 3000, 64)
+    queries16 = oracle.gen_f16_numpy(0x72, 0, 50, 64)
+    bad = base16.copy(); bad[7, 3] = np.float16(np.inf)
+    with KnnEngine(0) as eng:
+        eng.set_base(bad)
+        eng.search(queries16, 10)
+        assert eng.stats()["prescreen"] == 0
+        eng.set_option("f16_exact", 0)
+        eng.set_base(base16)
+        dist, idx = eng.search(queries16, 10)
+        assert eng.stats()["prescreen"] == 0
+    ed = np.sort(oracle.distances_fp64(base16.astype(np.float32), queries16.astype(np.float32), "sqeuclidean"), axis=1)[:, :10]
+    assert np.allclose(dist, ed, rtol=1e-4, atol=1e-3)
