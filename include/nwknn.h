@@ -93,7 +93,7 @@ int nwknn_set_stream(nwknn_handle h, void* hip_stream);
  * the base; searches then filter with the fp16 MFMA kernel under a conservative error bound and rescore every listed pair
  * with the canonical fp32 chain -- the same bits out as with 0, several times faster; nwknn_stats.prescreen reports whether a
  * search used it: non-finite or extreme-magnitude inputs fall back to the direct kernel),
- * "f16_exact" (fp16 compute path, default 1: sqeuclidean / one_minus_dot results are the canonical fp32 arithmetic applied to the
+ * "f16_exact" (fp16 compute path, default 1: results are the canonical fp32 arithmetic applied to the
  * fp16 values, bit for bit -- the fp16 MFMA kernel pre-screens, listed pairs are rescored; 0: raw fp16-MFMA sums),
  * "f16_mfma" (fp16 tile kernel build: 1 = v_mfma_f32_16x16x32_f16, default; 0 = 32x32x16; 2 = two 4-wave workgroups per CU). */
 int nwknn_set_option(nwknn_handle h, const char* name, int64_t value);
@@ -108,8 +108,8 @@ int nwknn_synchronize(nwknn_handle h);
  * NWKNN_DEVICE the copy is queued on the handle's stream and the buffer may be reused after
  * nwknn_synchronize or any later blocking call).  dtype = element type of `base`; an fp16 base (or option
  * "compute_dtype" = NWKNN_DTYPE_F16) selects the fp16 compute path: results then carry fp16 input rounding; with option
- * "f16_exact" (default) sqeuclidean / one_minus_dot are the canonical fp32 arithmetic on the fp16 values, bit for bit; cosine and
- * inputs holding Inf/NaN are checked against the float64 truth with a tolerance. */
+ * "f16_exact" (default) they are the canonical fp32 arithmetic on the fp16 values, bit for bit; inputs holding Inf/NaN run the
+ * raw fp16-MFMA sums and are checked against the float64 truth with a tolerance. */
 int nwknn_set_base(nwknn_handle h, const void* base, int64_t rows, int32_t d, int dtype, int location);
 /* Same, from COLUMN-major host data: columns[j] points at `rows` contiguous values of dimension j -- the layout parquet /
  * arrow / cuDF hold (one column per dimension, generate_dataset.py:219-262).  Replaces the device transpose

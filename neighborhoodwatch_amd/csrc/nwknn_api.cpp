@@ -376,7 +376,8 @@ static int ensure_base_copy(nwknn_ctx* h, int kind)
     if (h->pre_kind == kind) return NWKNN_OK;
     RCCHK(h->bp16.ensure((size_t)h->nb_pad_for_copy * h->dp16 * 2));
     EvPair* e = ev_begin(h, 2);
-    if (kind == 0) HIPCHK(nwk_launch_half_copy(h->stream, h->bp.as<float>(), h->nb_pad_for_copy, h->dp_for_copy, h->dp16, h->b_scale, nullptr, h->bp16.p));
+    if (kind == 2) HIPCHK(nwk_launch_half_copy16(h->stream, h->bp.p, h->nb_pad_for_copy, h->dp16, NWK_COS_SCALE, h->bn.as<float>(), h->bp16.p));
+    else if (kind == 0) HIPCHK(nwk_launch_half_copy(h->stream, h->bp.as<float>(), h->nb_pad_for_copy, h->dp_for_copy, h->dp16, h->b_scale, nullptr, h->bp16.p));
     else HIPCHK(nwk_launch_half_copy(h->stream, h->bp.as<float>(), h->nb_pad_for_copy, h->dp_for_copy, h->dp16, NWK_COS_SCALE, h->bn.as<float>(), h->bp16.p));
     ev_end(h, e);
     h->pre_kind = kind;
@@ -409,6 +410,7 @@ static int set_base_common(nwknn_ctx* h, const void* base, const void* const* co
         bool finite = false;
         RCCHK(matrix_finite_f16(h, h->bp.p, rows_pad * (long long)dp, &finite));
         h->f16_finite = finite ? 1 : 0;
+        h->nb_pad_for_copy = rows_pad; h->dp_for_copy = dp; h->dp16 = dp; h->pre_kind = -1;      // cosine builds unit-row copies on demand
     }
     if (pre) {
         bool usable = false;
@@ -449,7 +451,8 @@ extern "C" int nwknn_set_base_columns(nwknn_handle h, const void* const* columns
 struct SearchPlan {
     int cap; long long first, max_chunk, safe; int tile_rows; int granule;
     bool pre;                                   // filtered chunks run the fp16 pre-screen + fp32 rescoring
-    bool native16;                              // exact fp16 mode: the fp16 rows ARE the data (no copies); the dense chunk is rescored too
+    bool native16;                              // exact fp16 mode: the fp16 rows ARE the data; rescoring walks them, the dense chunk is rescored too
+    bool copies16;                              // the tile kernel reads the fp16 COPIES (fp32 data; cosine's unit rows), not the native fp16 rows
     float pre_scale, pre_eps_half, pre_aq, pre_ab, pre_cst;
 };
 
@@ -474,6 +477,7 @@ static int make_plan(nwknn_ctx* h, int k, long long nq, bool pre, SearchPlan* pl
     pl->tile_rows = (h->f16 || pre) ? NWK_F16_TILE_ROWS : (h->opt_tile_rows ? (int)h->opt_tile_rows : (nq >= 2048 ? 256 : 128));
     pl->pre = pre;
     pl->native16 = false;
+    pl->copies16 = pre;
     pl->pre_scale = 1.f; pl->pre_eps_half = pl->pre_aq = pl->pre_ab = pl->pre_cst = 0.f;
     return NWKNN_OK;
 }
@@ -520,7 +524,7 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
     if (qtile_list) { tp.qtile_list = qtile_list; tp.n_qtiles = n_list_tiles; }
     EvPair* e = ev_begin(h, 0);
     if (prescreen) {
-        if (!pl.native16) { tp.qp = h->qp16.as<float>(); tp.bp = h->bp16.as<float>(); tp.dp = h->dp16; }
+        if (pl.copies16) { tp.qp = h->qp16.as<float>(); tp.bp = h->bp16.as<float>(); tp.dp = h->dp16; }
         tp.pre_inv_scale = 1.0f / pl.pre_scale;
         tp.pre_scale = pl.pre_scale; tp.pre_eps_half = pl.pre_eps_half; tp.pre_aq = pl.pre_aq; tp.pre_ab = pl.pre_ab; tp.pre_cst = pl.pre_cst;
         HIPCHK(nwk_launch_tile_prescreen(h->stream, tp, metric, dense));
@@ -635,8 +639,8 @@ static int search_common(nwknn_ctx* h, const void* queries, const void* const* q
     RCCHK(use_device(h));
     bool pre = h->pre_ok && !h->f16;
     // exact fp16 mode (fp16 compute path, option f16_exact): the fp16 MFMA kernel pre-screens, every listed pair is rescored with
-    // the fp32 chain over the fp16 values.  Cosine keeps the raw MFMA sums (its pre-screen wants unit-row copies).
-    bool native16 = h->f16 && h->opt_f16_exact && h->f16_finite && metric != NWKNN_METRIC_COSINE;
+    // the fp32 chain over the fp16 values.  (Cosine pre-screens on unit-row copies of the fp16 rows.)
+    bool native16 = h->f16 && h->opt_f16_exact && h->f16_finite;
     SearchPlan pl;
     RCCHK(make_plan(h, k, nq, pre, &pl));
 
@@ -708,6 +712,20 @@ static int search_common(nwknn_ctx* h, const void* queries, const void* const* q
             pl.pre_scale = 1.0f;
             pl.pre_eps_half = (float)(0.5 * 1.02 * 5.5 * dd * u * (double)h->opt_pre_eps_pct / 100.0);
             pl.pre_aq = pl.pre_ab = pl.pre_cst = 0.0f;
+            pl.copies16 = false;
+            if (metric == NWKNN_METRIC_COSINE) {           // unit-row copies of both sides; the constant bound of the fp32-data cosine path
+                RCCHK(ensure_base_copy(h, 2));
+                RCCHK(h->qp16.ensure((size_t)nq_pad * h->dp16 * 2));
+                EvPair* e = ev_begin(h, 2);
+                HIPCHK(nwk_launch_half_copy16(h->stream, h->qp.p, nq_pad, h->dp16, NWK_COS_SCALE, h->qn.as<float>(), h->qp16.p));
+                ev_end(h, e);
+                const double a = 0x1p-14 / (double)NWK_COS_SCALE, sd = sqrt((double)h->d);
+                pl.copies16 = true;
+                pl.pre_scale = NWK_COS_SCALE * NWK_COS_SCALE;
+                pl.pre_eps_half = 0.f;
+                pl.pre_cst = (float)((1.02 * (0x1p-10 * (1.0 + 0x1p-11) + 7.5 * dd * u + 16.0 * u) + 2.02 * a * sd + (double)h->d * a * a)
+                                     * (double)h->opt_pre_eps_pct / 100.0);
+            }
         } else {
             native16 = false;
         }

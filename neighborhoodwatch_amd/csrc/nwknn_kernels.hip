@@ -1551,6 +1551,27 @@ __global__ __launch_bounds__(256) void nwk_half_copy_kernel(const float* __restr
     }
 }
 
+// fp16 rows -> scaled (cosine: unit-row) fp16 copy, natural k order on both sides (exact fp16 mode, cosine)
+__global__ __launch_bounds__(256) void nwk_half_copy16_kernel(const _Float16* __restrict__ rows16, long long rows_pad, int dp, float scale0,
+                                                               const float* __restrict__ norms, _Float16* __restrict__ out)
+{
+    const int g16 = dp >> 3;
+    const long long total = rows_pad * g16;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / g16;
+        float scale = scale0;
+        if (norms) {
+            const float n = norms[r];
+            scale = cosine_norm_ok(n) ? scale0 * (1.0f / sqrtf(n)) : 0.0f;
+        }
+        const f16x8 v = *(const f16x8*)(rows16 + 8 * i);
+        f16x8 hv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hv[j] = (_Float16)((float)v[j] * scale);
+        *(f16x8*)(out + 8 * i) = hv;
+    }
+}
+
 // One wave per query (blockDim = 64 * waves, dynamic LDS = waves * cap * 8 bytes).  The keys the pre-screen listed carry the
 // fp16 ESTIMATE of the distance; with the error bound e(q,b) the exact value lies in [est - e, est + e].  Phases:
 //   1. bounds of every list entry into LDS (entries of the compacted prefix [0, cnt0) are exact: lb = ub = their distance);
@@ -2024,6 +2045,8 @@ hipError_t nwk_launch_tile_prescreen(hipStream_t st, NwkTileParams p, int metric
             hipLaunchKernelGGL((nwk_tile_kernel_f16s<NWKNN_METRIC_SQEUCLIDEAN, true, 1>), dim3((unsigned)grid), dim3(512), 0, st, p);
         else if (metric == NWKNN_METRIC_ONE_MINUS_DOT)
             hipLaunchKernelGGL((nwk_tile_kernel_f16s<NWKNN_METRIC_ONE_MINUS_DOT, true, 1>), dim3((unsigned)grid), dim3(512), 0, st, p);
+        else if (metric == NWKNN_METRIC_COSINE)
+            hipLaunchKernelGGL((nwk_tile_kernel_f16s<NWKNN_METRIC_COSINE, true, 1>), dim3((unsigned)grid), dim3(512), 0, st, p);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
@@ -2077,6 +2100,16 @@ hipError_t nwk_launch_maxabs(hipStream_t st, const float* x, long long n, unsign
     long long blocks = (n / 4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(nwk_maxabs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n / 4, out_bits);
+    return hipGetLastError();
+}
+
+hipError_t nwk_launch_half_copy16(hipStream_t st, const void* rows16, long long rows_pad, int dp, float scale, const float* norms, void* out16)
+{
+    const long long total = rows_pad * (dp / 8);
+    if (total <= 0) return hipSuccess;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(nwk_half_copy16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const _Float16*)rows16, rows_pad, dp, scale, norms, (_Float16*)out16);
     return hipGetLastError();
 }
 

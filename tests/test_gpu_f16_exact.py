@@ -6,7 +6,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-EXACT = ["sqeuclidean", "one_minus_dot"]
+EXACT = ["sqeuclidean", "one_minus_dot", "cosine"]
 
 
 def _bitwise(a, b):
