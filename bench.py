@@ -200,7 +200,7 @@ def main():
 
     # the same job through the fp16 pre-screen + fp32 rescoring (engine option "prescreen"): results must be the same bits
     pre = None
-    if not maxsim and dtype == "f32" and not args.no_prescreen and not any("prescreen" in o for o in args.opt):
+    if dtype == "f32" and not args.no_prescreen and not any("prescreen" in o for o in args.opt):
         direct = (last[0].clone(), last[1].clone()) if rank == 0 else None
         eng.set_prescreen(True)
         p_elapsed, p_agg, p_flops, p_ms, p_last = measure()
@@ -210,11 +210,12 @@ def main():
             pre = {
                 "what": "same search, same bits out: fp16 MFMA pre-screen over scaled fp16 copies + canonical fp32 rescoring of every listed pair",
                 "value": Q * args.steps / p_elapsed, "unit": "queries/s", "ms_per_step": p_elapsed / args.steps * 1e3,
-                "pairwise_tflops": 2.0 * Q * B * d * args.steps / p_elapsed / 1e12,
+                "pairwise_tflops": 2.0 * Q * B * d * (32 * 64 if maxsim else 1) * args.steps / p_elapsed / 1e12,
                 "identical_to_direct": bool(torch.equal(direct[0], p_last[0])) and bool(torch.equal(direct[1], p_last[1])),
                 "prescreen_searches": p_agg["prescreen"],
                 "roofline": {"bound": "mfma", "achieved": p_ach, "peak": MFMA_PEAK_TFLOPS["f16"], "unit": "TFLOP/s",
-                             "frac": p_ach / MFMA_PEAK_TFLOPS["f16"], "kernel": "nwk_tile_kernel_f16s<metric, false, PRE=1>",
+                             "frac": p_ach / MFMA_PEAK_TFLOPS["f16"],
+                             "kernel": "nwk_maxsim_pre_kernel" if maxsim else "nwk_tile_kernel_f16s<metric, false, PRE=1>",
                              "traffic": recorded_traffic(args.workload + "_prescreen"),
                              "launches": p_agg["tile_launches"], "avg_launch_ms": p_agg["tile_ms"] / max(p_agg["tile_launches"], 1)},
                 "breakdown_ms_per_step": {"tile": p_agg["tile_ms"] / args.steps, "rescore": p_agg["rescore_ms"] / args.steps,

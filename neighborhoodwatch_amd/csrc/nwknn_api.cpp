@@ -82,7 +82,9 @@ struct nwknn_ctx {
     // query side
     DevBuf qraw, qp, qn;
     // fp16 pre-screen of the exact fp32 search (option "prescreen"): scaled fp16 copies of bp / qp
-    DevBuf bp16, qp16, cnt0, scal;
+    DevBuf bp16, qp16, cnt0, scal, ms_rq, ms_cd, ms_surv, ms_nsurv;
+    int ms_pre = 0;                 // MaxSim: the documents have a usable fp16 copy (option "prescreen" at nwknn_maxsim_set_docs)
+    float ms_eps_half = 0.f, ms_aq = 0.f, ms_ab = 0.f, ms_cst = 0.f, ms_scale = 1.f;   // constants of the current MaxSim search
     int pre_ok = 0;                 // the current base can be pre-screened (finite, sane magnitudes); bp16 holds a copy of kind pre_kind
     int f16_finite = 0;             // fp16 compute path: the prepared base holds no Inf/NaN (exact fp16 mode is possible)
     int pre_kind = -1;              // 0: rows scaled by b_scale (sqeuclidean, one_minus_dot); 1: unit rows x 2^14 (cosine); -1: none yet
@@ -191,7 +193,7 @@ extern "C" int nwknn_destroy(nwknn_handle h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->bp, &h->bn, &h->braw, &h->qraw, &h->qp, &h->qn, &h->tau, &h->cnt, &h->buf, &h->ovf, &h->ovf_any, &h->qtiles,
-                      &h->out_d, &h->out_i, &h->mrg_d, &h->mrg_i, &h->bp16, &h->qp16, &h->cnt0, &h->scal})
+                      &h->out_d, &h->out_i, &h->mrg_d, &h->mrg_i, &h->bp16, &h->qp16, &h->cnt0, &h->scal, &h->ms_rq, &h->ms_cd, &h->ms_surv, &h->ms_nsurv})
         b->release();
     for (EvPair& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
@@ -817,10 +819,25 @@ extern "C" int nwknn_maxsim_set_docs(nwknn_handle h, const void* doc_tokens, int
         h->nb_pad = pad;
     }
     h->ms_docs = n_docs;
+    h->ms_pre = 0;
+    if (save_pre) {             // scaled fp16 copy of the doc tokens for the pre-screen (same conditions as for kNN)
+        bool usable = false;
+        RCCHK(matrix_maxabs(h, h->bp.as<float>(), h->nb_pad * (long long)h->dp, &h->b_maxabs, &usable));
+        if (usable) {
+            h->nb_pad_for_copy = h->nb_pad; h->dp_for_copy = h->dp;
+            h->dp16 = (int)round_up(d, NWK_K_ALIGN_F16);
+            h->b_scale = prescreen_scale(h->b_maxabs);
+            h->pre_kind = -1;
+            const int rc2 = ensure_base_copy(h, 0);
+            if (rc2 == NWKNN_OK) h->ms_pre = 1;
+            else if (rc2 != NWKNN_ENOMEM) return rc2;
+        }
+    }
     return NWKNN_OK;
 }
 
-static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq_pad, long long doc_lo, long long docs, bool dense, bool dedupe)
+static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq_pad, long long doc_lo, long long docs, bool dense, bool dedupe,
+                        bool pre)
 {
     NwkTileParams tp;
     memset(&tp, 0, sizeof tp);
@@ -829,9 +846,30 @@ static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq
     tp.nb_valid = h->ms_docs; tp.dense_col0 = doc_lo;
     tp.n_qtiles = (int)(nq_pad / 4); tp.bt0 = (int)(doc_lo / 4); tp.n_btiles = (int)(docs / 4);
     tp.dp = h->dp; tp.cap = cap; tp.sq_shift = (int)h->opt_sq_shift;
+    const bool prescreen = pre && !dense;                // the dense first chunk runs the fp32 kernel (exact keys)
     EvPair* e = ev_begin(h, 0);
-    HIPCHK(nwk_launch_maxsim(h->stream, tp, dense));
+    if (prescreen) {
+        tp.qp = h->qp16.as<float>(); tp.bp = h->bp16.as<float>(); tp.dp = h->dp16;
+        tp.nq_valid = nq; tp.ms_rq = h->ms_rq.as<float>(); tp.ms_cd = h->ms_cd.as<float>();
+        tp.pre_scale = h->ms_scale; tp.pre_inv_scale = 1.0f / h->ms_scale;
+        HIPCHK(nwk_launch_maxsim_pre(h->stream, tp));
+    } else {
+        HIPCHK(nwk_launch_maxsim(h->stream, tp, dense));
+    }
     ev_end(h, e);
+    if (prescreen) {
+        NwkMsRescoreParams rp;
+        rp.qp = h->qp.as<float>(); rp.bp = h->bp.as<float>(); rp.buf = h->buf.as<u64>(); rp.cnt = h->cnt.as<u32>(); rp.cnt0 = h->cnt0.as<u32>();
+        rp.rq = h->ms_rq.as<float>(); rp.cd = h->ms_cd.as<float>();
+        rp.dp = h->dp; rp.cap = cap; rp.k = k; rp.prune = (h->opt_pre_prune && !dedupe) ? 1 : 0;
+        rp.dbg = h->opt_dbg_ptr ? (unsigned long long*)(uintptr_t)h->opt_dbg_ptr : nullptr;
+        rp.surv = h->ms_surv.as<u32>(); rp.nsurv = h->ms_nsurv.as<u32>();
+        // enough (query, slice) waves to fill the chip a few times over
+        const int slices = (int)std::max<long long>(1, std::min<long long>(32, (8ll * h->num_cu * 4 + nq_pad - 1) / nq_pad));
+        e = ev_begin(h, 3);
+        HIPCHK(nwk_launch_maxsim_rescore(h->stream, rp, nq_pad, slices));
+        ev_end(h, e);
+    }
     h->stats.tile_launches += 1;
     const long long real_docs = std::max<long long>(0, std::min<long long>(doc_lo + docs, h->ms_docs) - doc_lo);
     h->stats.tile_flops += 2.0 * (double)nq * NWK_MS_TOKENS_PER_QUERY * (double)real_docs * NWK_MS_TOKENS_PER_DOC * (double)h->d;
@@ -839,6 +877,7 @@ static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq
     memset(&cp, 0, sizeof cp);
     cp.buf = h->buf.as<u64>(); cp.cnt = h->cnt.as<u32>(); cp.tau = h->tau.as<u64>(); cp.ovf = h->ovf.as<u32>(); cp.ovf_any = h->ovf_any.as<u32>();
     cp.cap = cap; cp.k = k; cp.qtile_rows = 4; cp.dense_count = dense ? (int)docs : 0; cp.dedupe = dedupe ? 1 : 0;
+    cp.cnt0 = pre ? h->cnt0.as<u32>() : nullptr;
     e = ev_begin(h, 1);
     HIPCHK(nwk_launch_compact(h->stream, cp, nq_pad));
     ev_end(h, e);
@@ -873,6 +912,40 @@ extern "C" int nwknn_maxsim_search(nwknn_handle h, const void* query_tokens, int
     h->ev_used = 0;
     if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_begin, h->stream));
     RCCHK(stage_and_prep(h, query_tokens, location, 0, 0, qrows, h->d, qrows_pad, h->dp, h->qraw, h->qp.p, h->qn.as<float>()));
+    bool pre = h->ms_pre != 0;
+    if (pre) {
+        float q_maxabs = 0.f;
+        bool usable = false;
+        RCCHK(matrix_maxabs(h, h->qp.as<float>(), qrows_pad * (long long)h->dp, &q_maxabs, &usable));
+        if (!usable) pre = false;
+        else {
+            const float q_scale = prescreen_scale(q_maxabs);
+            const long long docs_all = h->nb_pad / NWK_MS_TOKENS_PER_DOC;
+            RCCHK(h->qp16.ensure((size_t)qrows_pad * h->dp16 * 2));
+            RCCHK(h->cnt0.ensure((size_t)nq_pad * 4));
+            RCCHK(h->ms_rq.ensure((size_t)nq_pad * 4));
+            RCCHK(h->ms_cd.ensure((size_t)docs_all * 4));
+            RCCHK(h->ms_surv.ensure((size_t)nq_pad * cap * 4));
+            RCCHK(h->ms_nsurv.ensure((size_t)nq_pad * 4));
+            const double u = 0x1p-24, dd = (double)h->dp16;
+            const double eps = 1.02 * (0x1p-10 * (1.0 + 0x1p-11) + 5.5 * dd * u);
+            const double a_q = 0x1p-14 / (double)q_scale, a_b = 0x1p-14 / (double)h->b_scale, sd = sqrt((double)h->d);
+            h->ms_scale = q_scale * h->b_scale;
+            h->ms_eps_half = (float)(0.5 * eps);
+            h->ms_aq = (float)(1.01 * a_q * sd);        // times sqrt(|doc token|^2)
+            h->ms_ab = (float)(1.01 * a_b * sd);        // times sqrt(|query token|^2)
+            h->ms_cst = (float)(1.01 * (double)h->d * a_q * a_b);
+            EvPair* e = ev_begin(h, 2);
+            HIPCHK(nwk_launch_half_copy(h->stream, h->qp.as<float>(), qrows_pad, h->dp, h->dp16, q_scale, nullptr, h->qp16.p));
+            HIPCHK(nwk_launch_maxsim_bounds(h->stream, h->qn.as<float>(), nq_pad, NWK_MS_TOKENS_PER_QUERY, h->ms_eps_half, h->ms_ab, h->ms_cst, 0,
+                                            h->ms_rq.as<float>()));
+            HIPCHK(nwk_launch_maxsim_bounds(h->stream, h->bn.as<float>(), docs_all, NWK_MS_TOKENS_PER_DOC, h->ms_eps_half, h->ms_aq, 0.0f, 1,
+                                            h->ms_cd.as<float>()));
+            ev_end(h, e);
+            HIPCHK(hipMemsetAsync(h->cnt0.p, 0, (size_t)nq_pad * 4, h->stream));
+        }
+    }
+    h->stats.prescreen = pre ? 1 : 0;
     HIPCHK(hipMemsetAsync(h->tau.p, 0xFF, (size_t)nq_pad * 8, h->stream));
     HIPCHK(hipMemsetAsync(h->cnt.p, 0, (size_t)nq_pad * 4, h->stream));
     HIPCHK(hipMemsetAsync(h->ovf.p, 0, (size_t)nq_pad * 4, h->stream));
@@ -883,10 +956,10 @@ extern "C" int nwknn_maxsim_search(nwknn_handle h, const void* query_tokens, int
     long long first = h->opt_first_chunk ? round_up(h->opt_first_chunk, 4) : cap / 2;
     first = std::min<long long>(std::max<long long>(first, round_up(k, 4)), cap / 4 * 4);
     long long seen = std::min(docs_pad, first);
-    RCCHK(maxsim_chunk(h, (int)cap, k, nq, nq_pad, 0, seen, true, false));
+    RCCHK(maxsim_chunk(h, (int)cap, k, nq, nq_pad, 0, seen, true, false, pre));
     while (seen < docs_pad) {
         const long long m = std::min(std::min(max_chunk, seen), docs_pad - seen);
-        RCCHK(maxsim_chunk(h, (int)cap, k, nq, nq_pad, seen, m, false, false));
+        RCCHK(maxsim_chunk(h, (int)cap, k, nq, nq_pad, seen, m, false, false, pre));
         seen += m;
     }
     u32 any = 0;
@@ -902,7 +975,7 @@ extern "C" int nwknn_maxsim_search(nwknn_handle h, const void* query_tokens, int
         HIPCHK(hipMemsetAsync(h->ovf.p, 0, (size_t)nq_pad * 4, h->stream));
         HIPCHK(hipMemsetAsync(h->ovf_any.p, 0, 4, h->stream));
         for (long long lo = 0; lo < docs_pad; lo += safe) {
-            RCCHK(maxsim_chunk(h, (int)cap, k, nq, nq_pad, lo, std::min(safe, docs_pad - lo), false, true));
+            RCCHK(maxsim_chunk(h, (int)cap, k, nq, nq_pad, lo, std::min(safe, docs_pad - lo), false, true, pre));
             h->stats.rescan_launches += 1;
         }
         HIPCHK(hipMemcpyAsync(&any, h->ovf_any.p, 4, hipMemcpyDeviceToHost, h->stream));
@@ -926,7 +999,7 @@ extern "C" int nwknn_maxsim_search(nwknn_handle h, const void* query_tokens, int
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, h->ev_begin, h->ev_end));
         h->stats.total_ms = ms;
-        ev_collect(h, &h->stats.tile_ms, &h->stats.compact_ms, &h->stats.prep_ms);
+        ev_collect(h, &h->stats.tile_ms, &h->stats.compact_ms, &h->stats.prep_ms, &h->stats.rescore_ms);
         h->stats.prep_ms += h->base_prep_ms; h->base_prep_ms = 0.0;
     }
     return NWKNN_OK;

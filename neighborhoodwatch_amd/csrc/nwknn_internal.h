@@ -41,6 +41,8 @@ struct NwkTileParams {
     float pre_cst;
     float pre_inv_scale;           // 1 / pre_scale
     int f16_shape;                 // fp16 kernels: 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16, 2 = 4-wave workgroups, two per CU
+    const float* ms_rq;            // MaxSim pre-screen: per-query and per-doc parts of the score bound
+    const float* ms_cd;
     int tiles_per_wg;              // 16x16x32 kernel: consecutive base tiles a workgroup walks (strip); the launcher turns n_btiles into strips
     int n_btiles_real;             // filled in by the launcher: base tiles of this launch
 };
@@ -59,6 +61,21 @@ struct NwkRescoreParams {
     int rows16;                    // 1: qp / bp hold fp16 rows in natural k order (exact fp16 mode); 0: prepared fp32 rows
     int prune;                     // 1: derive bounds from the fp16 estimates and skip pairs that cannot reach the top k
     float eps_half, aq, ab, cst;   // the constants of the pre-screen error bound (as in NwkTileParams)
+};
+
+struct NwkMsRescoreParams {
+    const float* qp;               // prepared fp32 query tokens [nq_pad*32][dp] / doc tokens [docs_pad*64][dp]
+    const float* bp;
+    unsigned long long* buf;
+    const unsigned int* cnt;
+    const unsigned int* cnt0;
+    const float* rq;               // score bound: R(query) + C(doc)
+    const float* cd;
+    int dp, cap, k, prune;
+    unsigned int* surv;            // [nq_pad][cap]: list slots of the pairs to rescore, written by the prune kernel
+    unsigned int* nsurv;           // [nq_pad]
+    unsigned long long* dbg;       // dev: [0] += listed pairs, [1] += rescored pairs
+    int q_in_lds;                  // set by the launcher: the query's token rows fit in LDS next to the list arrays
 };
 
 struct NwkCompactParams {
@@ -97,5 +114,9 @@ hipError_t nwk_launch_finalize(hipStream_t st, const unsigned long long* buf, co
 hipError_t nwk_launch_maxsim(hipStream_t st, NwkTileParams p, bool dense);
 #define NWK_MS_TOKENS_PER_DOC 64
 #define NWK_MS_TOKENS_PER_QUERY 32
+hipError_t nwk_launch_maxsim_pre(hipStream_t st, NwkTileParams p);
+hipError_t nwk_launch_maxsim_bounds(hipStream_t st, const float* norms, long long n_items, int tokens, float eps_half, float a_self, float cst,
+                                    int is_doc, float* out);
+hipError_t nwk_launch_maxsim_rescore(hipStream_t st, NwkMsRescoreParams p, long long nq_pad, int slices);
 hipError_t nwk_launch_merge(hipStream_t st, const float* dists, const long long* idx, int n_lists, long long nq, int k_in, int k_out,
                             float* out_d, long long* out_i);

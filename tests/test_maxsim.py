@@ -55,3 +55,54 @@ def test_hip_maxsim_overflow_repair_and_offsets(oracle):
     rs, ri = oracle.maxsim_canonical(docs, q, 20)
     assert np.array_equal(i, ri + 7_000_000_000) and np.array_equal(s.view(np.uint32), rs.view(np.uint32))
     assert st["overflowed_queries"] > 0 and st["rescan_launches"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(300, 7, 20), (1030, 33, 100), (5000, 9, 1000), (4100, 130, 10), (20000, 64, 50)])
+def test_hip_maxsim_prescreened_matches_oracle_bit_exact(oracle, shape):
+    """Option prescreen before maxsim_set_docs: fp16 MaxSim tile kernel lists (query, doc) pairs under the additive score bound
+    R(query) + C(doc); every survivor is recomputed with the canonical fp32 arithmetic.  Same bits as the fp32 kernel / the oracle."""
+    from neighborhoodwatch_amd import KnnEngine
+    nd, nq, k = shape
+    docs, qs = _tokens(oracle, 0xC3 + nd, nd, 64, 128), _tokens(oracle, 0xC4 + nq, nq, 32, 128)
+    with KnnEngine(0, profile=True) as eng:
+        eng.set_prescreen(True)
+        eng.maxsim_set_docs(docs)
+        s, i = eng.maxsim_search(qs, k)
+        st = eng.stats()
+    rs, ri = oracle.maxsim_canonical(docs, qs, k)
+    assert st["prescreen"] == 1 and (st["rescore_ms"] > 0.0 or nd <= 512)
+    assert np.array_equal(i, ri), f"doc ids differ at {(i != ri).sum()} of {i.size} positions"
+    assert np.array_equal(s.view(np.uint32), rs.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_hip_maxsim_prescreened_overflow_repair_unit_tokens_and_offsets(oracle):
+    from neighborhoodwatch_amd import KnnEngine
+    rng = np.random.default_rng(3)
+    q = rng.standard_normal((9, 32, 128)).astype(np.float32)
+    base = rng.standard_normal((2500, 64, 128)).astype(np.float32)
+    docs = base * np.linspace(0.05, 3.0, 2500, dtype=np.float32)[:, None, None]     # later docs score higher for every query
+    with KnnEngine(0) as eng:
+        eng.set_prescreen(True)
+        eng.set_option("capacity", 256)
+        eng.set_option("first_chunk", 64)
+        eng.maxsim_set_docs(docs)
+        s, i = eng.maxsim_search(q, 20, doc_offset=7_000_000_000)
+        st = eng.stats()
+    rs, ri = oracle.maxsim_canonical(docs, q, 20)
+    assert st["prescreen"] == 1 and st["overflowed_queries"] > 0 and st["rescan_launches"] > 0
+    assert np.array_equal(i, ri + 7_000_000_000) and np.array_equal(s.view(np.uint32), rs.view(np.uint32))
+    # ColBERT-like unit-norm tokens, near-duplicate documents (scores closer than the fp16 bound can separate)
+    d2 = rng.standard_normal((3000, 64, 128)).astype(np.float32)
+    d2[1500:] = d2[:1500] + 1e-4 * rng.standard_normal((1500, 64, 128)).astype(np.float32)
+    d2 /= np.linalg.norm(d2, axis=2, keepdims=True)
+    q2 = rng.standard_normal((40, 32, 128)).astype(np.float32)
+    q2 /= np.linalg.norm(q2, axis=2, keepdims=True)
+    with KnnEngine(0) as eng:
+        eng.set_prescreen(True)
+        eng.maxsim_set_docs(d2)
+        s, i = eng.maxsim_search(q2, 100)
+        assert eng.stats()["prescreen"] == 1
+    rs, ri = oracle.maxsim_canonical(d2, q2, 100)
+    assert np.array_equal(i, ri) and np.array_equal(s.view(np.uint32), rs.view(np.uint32))
