@@ -1690,6 +1690,7 @@ __global__ __launch_bounds__(256) void nwk_maxsim_prune_kernel(const NwkMsRescor
     }
 }
 
+template <bool QLDS>      // the query's token rows are staged in LDS (a generic pointer would make every read a flat_load)
 __global__ __launch_bounds__(256) void nwk_maxsim_rescore_kernel(const NwkMsRescoreParams p)
 {
     extern __shared__ __attribute__((aligned(16))) u32 ms_dyn[];
@@ -1704,12 +1705,11 @@ __global__ __launch_bounds__(256) void nwk_maxsim_rescore_kernel(const NwkMsResc
     // the query's 32 token rows are read by every lane for every survivor: stage them in LDS once (uniform global loads do not
     // become scalar loads here -- the kernel also stores to global memory)
     float* s_q = (float*)ms_dyn + (size_t)wv * NWK_MS_TOKENS_PER_QUERY * p.dp;
-    if (p.q_in_lds) {
+    if (QLDS) {
         const int n4 = NWK_MS_TOKENS_PER_QUERY * p.dp / 4;
         for (int i = lane; i < n4; i += 64) *(f32x4*)(s_q + 4 * i) = *(const f32x4*)(qtok + 4 * i);
         __builtin_amdgcn_wave_barrier();
     }
-    const float* qsrc = p.q_in_lds ? s_q : qtok;
 
     for (u32 i = slice * 2; i < nsurv; i += slices * 2) {                               // survivors i and i+1 (wave-uniform)
         const u32 e0 = surv[i], e1 = (i + 1 < nsurv) ? surv[i + 1] : e0;
@@ -1738,7 +1738,9 @@ __global__ __launch_bounds__(256) void nwk_maxsim_rescore_kernel(const NwkMsResc
             for (int c = 0; c < 4; ++c) { pf[0][c] = pf[1][c]; pf[1][c] = pf[2][c]; }
 #pragma unroll
             for (int t = 0; t < NWK_MS_TOKENS_PER_QUERY; ++t) {
-                const f32x4 qe = *(const f32x4*)(qsrc + t * p.dp + k0), qo = *(const f32x4*)(qsrc + t * p.dp + k0 + 4);
+                f32x4 qe, qo;
+                if (QLDS) { qe = *(const f32x4*)(s_q + t * p.dp + k0); qo = *(const f32x4*)(s_q + t * p.dp + k0 + 4); }
+                else { qe = *(const f32x4*)(qtok + t * p.dp + k0); qo = *(const f32x4*)(qtok + t * p.dp + k0 + 4); }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {                                          // k ascending: k0+2j, k0+2j+1
                     a0[t] = __fmaf_rn(be0[j], qe[j], a0[t]);
@@ -2464,7 +2466,10 @@ hipError_t nwk_launch_maxsim_rescore(hipStream_t st, NwkMsRescoreParams p, long 
     const int waves = 2;
     p.q_in_lds = (waves * qbytes <= 64 * 1024) ? 1 : 0;
     const size_t lds = p.q_in_lds ? waves * qbytes : 16;
-    hipLaunchKernelGGL(nwk_maxsim_rescore_kernel, dim3((unsigned)((nq_pad + waves - 1) / waves), (unsigned)slices), dim3(64 * waves), lds, st, p);
+    if (p.q_in_lds)
+        hipLaunchKernelGGL((nwk_maxsim_rescore_kernel<true>), dim3((unsigned)((nq_pad + waves - 1) / waves), (unsigned)slices), dim3(64 * waves), lds, st, p);
+    else
+        hipLaunchKernelGGL((nwk_maxsim_rescore_kernel<false>), dim3((unsigned)((nq_pad + waves - 1) / waves), (unsigned)slices), dim3(64 * waves), lds, st, p);
     return hipGetLastError();
 }
 
