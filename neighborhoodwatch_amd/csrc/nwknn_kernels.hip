@@ -19,6 +19,10 @@
 //   * a compaction kernel sorts each query's list (bitonic, LDS), keeps k, and tightens tau; the host walks the
 //     base in geometrically growing chunks so that tau is already tight when the big chunks run.
 //   * all integer/key work is exact: 64-bit key order == (distance, index) order, lower index wins ties.
+//   * option "prescreen": the filtered chunks run on the fp16 MFMA kernel (v_mfma_f32_16x16x32_f16) over scaled fp16 copies under a
+//     proven additive error bound, and nwk_rescore_kernel replaces every listed pair by its canonical fp32 key -- the same bits
+//     out, several times faster; fp16 INPUT data takes the same route by default ("exact fp16 mode"), MaxSim has its own
+//     pre-screen / prune / rescore kernels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
