@@ -276,3 +276,18 @@ def test_strips_of_base_tiles_per_workgroup(oracle, strip, d):
             rd, ri = oracle.knn_canonical(base, queries, 20, metric)
             assert eng.stats()["prescreen"] == 1
             assert np.array_equal(idx, ri) and _bitwise(dist, rd), (metric, strip, d)
+
+
+def test_operator_keyword(oracle):
+    """knn(dataset, queries, k, prescreen=True): the pylibraft-shaped operator with the pre-screen switched on for one call."""
+    from neighborhoodwatch_amd import knn
+    from neighborhoodwatch_amd.engine import default_engine
+    base = oracle.gen(0x51, 0, 5000, 96)
+    queries = oracle.gen(0x52, 0, 120, 96)
+    rd, ri = oracle.knn_canonical(base, queries, 15)
+    d1, i1 = knn(base, queries, 15, prescreen=True)
+    assert default_engine(0).stats()["prescreen"] == 1
+    d2, i2 = knn(base, queries, 15)
+    assert default_engine(0).stats()["prescreen"] == 0
+    for d, i in ((d1, i1), (d2, i2)):
+        assert np.array_equal(i, ri) and _bitwise(d, rd)
