@@ -137,7 +137,9 @@ def main(argv=None):
     print(f"(Duration: {time.time() - section:.2f} seconds out of {time.time() - start_time:.2f} seconds)")
     if args.post_validation:
         print("Validating ivec's and fvec's ......")
-        validate_files_v0(data_dir, *files)
+        if validate_files_v0(data_dir, *files) != 0:          # the reference's own identity: 1 - q.b == distance / 2 on unit rows
+            print("post-validation FAILED")
+            return 1
     return 0
 
 

@@ -174,3 +174,12 @@ def test_fp16_file_path(dataset, oracle):
     q16 = synth.gen_unit_rows(0x71, 0, 300, 384).astype(np.float16).astype(np.float32)
     ed, ei = oracle.knn_exact_fp64(b16, q16, 10)
     oracle.check_against_exact(b16, q16, _arr(fd, np.float32), _arr(fi, np.int64), ed)
+
+
+@pytest.mark.parametrize("extra", [[], ["--prescreen"]])
+def test_cli_unit_rows_pass_the_reference_validator(tmp_path, extra):
+    """nw --normalize --post-validation: stage 5's validate_files_v0 (parquet_to_format.py:351-383: 1 - q.b == distance / 2 for every
+    returned neighbour of unit-norm rows) accepts the engine's output, direct and pre-screened."""
+    from neighborhoodwatch_amd.neighborhoodwatch import main
+    assert main(["150", "4000", "-k", "10", "-m", "intfloat/e5-small-v2", "--data-dir", str(tmp_path), "--disable-memory-tuning",
+                 "--normalize", "--post-validation", "--no-gen-hdf5"] + extra) == 0
