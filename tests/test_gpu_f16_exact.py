@@ -101,3 +101,35 @@ def test_non_finite_fp16_inputs_and_the_legacy_switch(oracle):
         assert eng.stats()["prescreen"] == 0
     ed = np.sort(oracle.distances_fp64(base16.astype(np.float32), queries16.astype(np.float32), "sqeuclidean"), axis=1)[:, :10]
     assert np.allclose(dist, ed, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_cases_against_the_oracle(oracle, seed):
+    from neighborhoodwatch_amd import KnnEngine
+    rng = np.random.default_rng(7000 + seed)
+    d = int(rng.choice([1, 5, 31, 64, 100, 129, 200]))
+    B = int(rng.integers(40, 6000))
+    Q = int(rng.integers(1, 300))
+    k = int(min(B, rng.choice([1, 3, 17, 100, 300])))
+    kind = seed % 4
+    if kind == 0:
+        base, queries = rng.standard_normal((B, d)), rng.standard_normal((Q, d))
+    elif kind == 1:
+        base, queries = rng.integers(-3, 4, size=(B, d)), rng.integers(-3, 4, size=(Q, d))          # exact ties
+    elif kind == 2:
+        base = rng.standard_normal((B, d)) * 10.0 ** rng.uniform(-3, 2, size=(B, 1)); queries = rng.standard_normal((Q, d))
+    else:
+        c = rng.standard_normal((6, d)) * 3
+        base = c[rng.integers(0, 6, B)] + 0.02 * rng.standard_normal((B, d)); queries = c[rng.integers(0, 6, Q)] + 0.02 * rng.standard_normal((Q, d))
+    base16, queries16 = base.astype(np.float16), queries.astype(np.float16)
+    bf, qf = base16.astype(np.float32), queries16.astype(np.float32)
+    with KnnEngine(0) as eng:
+        eng.set_base(base16)
+        for metric in EXACT:
+            if metric == "cosine" and kind == 1:
+                continue                                        # integer rows may be all-zero: NaN handling is covered elsewhere
+            dist, idx = eng.search(queries16, k, metric)
+            assert eng.stats()["prescreen"] == 1
+            rd, ri = oracle.knn_canonical(bf, qf, k, metric)
+            assert np.array_equal(idx, ri), f"seed {seed} {metric} Q={Q} B={B} d={d} k={k}: {(idx != ri).sum()} index mismatches"
+            assert _bitwise(dist, rd), f"seed {seed} {metric}"
