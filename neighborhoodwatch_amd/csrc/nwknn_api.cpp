@@ -495,7 +495,7 @@ static NwkTileParams tile_params(nwknn_ctx* h, const SearchPlan& pl, long long n
     p.tau = h->tau.as<u64>(); p.cnt = h->cnt.as<u32>(); p.buf = h->buf.as<u64>();
     p.qtile_list = nullptr;
     p.nb_valid = h->nb;
-    p.nq_valid = h->stats.nq;
+    p.nq_valid = (h->opt_diag == 32) ? 1 : h->stats.nq;   // dev diag 32: only query row 0 may list anything (timing of a filter that never fires)
     p.n_qtiles = (int)(nq_pad / pl.tile_rows);
     p.dp = h->dp; p.cap = pl.cap;
     p.sq_shift = (int)h->opt_sq_shift;
