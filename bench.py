@@ -255,11 +255,11 @@ def main():
         print(json.dumps(out), flush=True)
     if args.verify and rank == 0:
         if maxsim:
-            eng.maxsim_set_docs(eng.generate(SEED_BASE, 0, B * 64, d).view(B, 64, d))
+            eng.maxsim_set_docs(eng.generate(SEED_BASE, 0, B * 64, d, dtype).view(B, 64, d))
             rs, ri = eng.maxsim_search(queries, k)
             rd = -rs
         else:
-            full = eng.generate(SEED_BASE, 0, B, d)
+            full = eng.generate(SEED_BASE, 0, B, d, dtype)      # same dtype as the shards: an fp16 base selects the fp16 path again
             eng.set_base(full)
             rd, ri = eng.search(queries, k, metric)
         dist, idx = last

@@ -1,2 +1,5 @@
+import sys
+
 from neighborhoodwatch_amd.neighborhoodwatch import main
-main()
+
+sys.exit(main())

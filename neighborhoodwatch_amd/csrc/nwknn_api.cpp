@@ -163,6 +163,18 @@ extern "C" int nwknn_mem_info(int device, size_t* free_bytes, size_t* total_byte
     return NWKNN_OK;
 }
 
+static int create_device_objects(nwknn_ctx* h)
+{
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamCreate(&h->own_stream));
+    h->stream = h->own_stream;
+    HIPCHK(hipEventCreate(&h->ev_begin));
+    HIPCHK(hipEventCreate(&h->ev_end));
+    return NWKNN_OK;
+}
+
+extern "C" int nwknn_destroy(nwknn_handle h);
+
 extern "C" int nwknn_create(nwknn_handle* out, int device)
 {
     if (!out) return fail(NWKNN_EINVAL, "nwknn_create: null handle pointer");
@@ -178,11 +190,8 @@ extern "C" int nwknn_create(nwknn_handle* out, int device)
     h->device = device;
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     memset(&h->stats, 0, sizeof h->stats);
-    HIPCHK(hipSetDevice(device));
-    HIPCHK(hipStreamCreate(&h->own_stream));
-    h->stream = h->own_stream;
-    HIPCHK(hipEventCreate(&h->ev_begin));
-    HIPCHK(hipEventCreate(&h->ev_end));
+    const int rc = create_device_objects(h);
+    if (rc != NWKNN_OK) { (void)nwknn_destroy(h); return rc; }      // releases whatever was created; last_error keeps the cause
     *out = h;
     return NWKNN_OK;
 }
@@ -191,7 +200,7 @@ extern "C" int nwknn_destroy(nwknn_handle h)
 {
     if (!h) return NWKNN_OK;
     (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->stream);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->bp, &h->bn, &h->braw, &h->qraw, &h->qp, &h->qn, &h->tau, &h->cnt, &h->buf, &h->ovf, &h->ovf_any, &h->qtiles,
                       &h->out_d, &h->out_i, &h->mrg_d, &h->mrg_i, &h->bp16, &h->qp16, &h->cnt0, &h->scal, &h->ms_rq, &h->ms_cd, &h->ms_surv, &h->ms_nsurv})
         b->release();
@@ -521,7 +530,12 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
 {
     NwkTileParams tp = tile_params(h, pl, nq_pad);
     const bool prescreen = pl.pre && (!dense || pl.native16);   // fp32 data: the dense first chunk runs the fp32 kernel
-    const int btile = ((h->f16 || prescreen) && h->opt_f16_shape != 2) ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS;   // f16_mfma=2: 256 x 128 tiles
+    // rows per base tile of the kernel the launchers below will pick: 128 for the fp32 kernel and for f16_mfma=2 (256 x 128
+    // tiles), 256 for the other fp16 kernels -- and for a dense pre-screened chunk whatever f16_mfma says, because
+    // nwk_launch_tile_prescreen runs those on the 256-row 16x16x32 build only
+    const bool q_shape = h->opt_f16_shape == 2 && !(prescreen && dense);
+    const int btile = ((h->f16 || prescreen) && !q_shape) ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS;
+    if (rows % btile != 0) return fail(NWKNN_EINVAL, "internal: chunk of %lld rows is not a whole number of %d-row tiles", rows, btile);
     tp.bt0 = (int)(lo / btile);
     tp.n_btiles = (int)(rows / btile);
     tp.dense_col0 = lo;
@@ -794,6 +808,19 @@ extern "C" int nwknn_search_columns(nwknn_handle h, const void* const* columns, 
 }
 
 // ---- MaxSim late interaction (new: BASELINE config 5; the reference's `ck` is flat token kNN) ----------------
+// copies the prepared base and its norms into larger zero-filled buffers; the caller owns nb2 / nn2 (and frees them on failure)
+static int grow_padded(nwknn_ctx* h, DevBuf& nb2, DevBuf& nn2, long long pad)
+{
+    RCCHK(nb2.ensure((size_t)pad * h->dp * 4));
+    RCCHK(nn2.ensure((size_t)pad * 4));
+    HIPCHK(hipMemsetAsync(nb2.p, 0, (size_t)pad * h->dp * 4, h->stream));
+    HIPCHK(hipMemcpyAsync(nb2.p, h->bp.p, (size_t)h->nb_pad * h->dp * 4, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(nn2.p, 0, (size_t)pad * 4, h->stream));
+    HIPCHK(hipMemcpyAsync(nn2.p, h->bn.p, (size_t)h->nb_pad * 4, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NWKNN_OK;
+}
+
 extern "C" int nwknn_maxsim_set_docs(nwknn_handle h, const void* doc_tokens, int64_t n_docs, int32_t tokens_per_doc, int32_t d, int dtype,
                                      int location)
 {
@@ -810,12 +837,8 @@ extern "C" int nwknn_maxsim_set_docs(nwknn_handle h, const void* doc_tokens, int
     const long long pad = round_up(h->nb, 256);
     if (pad > h->nb_pad) {      // set_base pads to 128 rows; MaxSim tiles need 256: grow and clear the tail
         DevBuf nb2, nn2;
-        RCCHK(nb2.ensure((size_t)pad * h->dp * 4)); RCCHK(nn2.ensure((size_t)pad * 4));
-        HIPCHK(hipMemsetAsync(nb2.p, 0, (size_t)pad * h->dp * 4, h->stream));
-        HIPCHK(hipMemcpyAsync(nb2.p, h->bp.p, (size_t)h->nb_pad * h->dp * 4, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemsetAsync(nn2.p, 0, (size_t)pad * 4, h->stream));
-        HIPCHK(hipMemcpyAsync(nn2.p, h->bn.p, (size_t)h->nb_pad * 4, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        const int rcg = grow_padded(h, nb2, nn2, pad);
+        if (rcg != NWKNN_OK) { nb2.release(); nn2.release(); return rcg; }
         h->bp.release(); h->bn.release();
         h->bp = nb2; h->bn = nn2;
         h->nb_pad = pad;

@@ -54,10 +54,15 @@ def _as_arrow_table(df) -> pa.Table:
     return pa.Table.from_pandas(df, preserve_index=False)
 
 
-def stream_cudf_to_parquet(filename, df, chunk_size):
+def stream_cudf_to_parquet(filename, df, chunk_size, metadata: Optional[dict] = None):
     """Write a frame as ONE parquet file in ``chunk_size``-row row groups (cu_knn.py:26-51).  ``df`` may be a
-    numpy [rows, k] array (columns get the names "0".."k-1"), a pandas DataFrame or a pyarrow Table."""
+    numpy [rows, k] array (columns get the names "0".."k-1"), a pandas DataFrame or a pyarrow Table.  ``metadata``
+    (str -> str) is added to the file's key-value metadata; readers that do not know the keys ignore them."""
     table = _as_arrow_table(df)
+    if metadata:
+        merged = dict(table.schema.metadata or {})
+        merged.update({str(a).encode(): str(b).encode() for a, b in metadata.items()})
+        table = table.replace_schema_metadata(merged)
     writer = pq.ParquetWriter(filename, table.schema)
     try:
         for start in range(0, max(len(table), 1), chunk_size):
@@ -201,11 +206,30 @@ def compute_knn(data_dir,
                     device=device, devices=devices, resume=resume, prescreen=prescreen)
 
 
-def _partial_pair_exists(data_dir, i, rows) -> bool:
+def _tile_tag(metric: str, dtype: str, batch_offset: int, batch_length: int) -> dict:
+    """What a partial pair was computed with; written into both files, compared by ``resume``.  The directory name pins
+    q, b and k (nw_utils.py:62-73) but not the distance, the arithmetic or the tiling."""
+    return {"nwknn.metric": metric, "nwknn.dtype": "fp16" if dtype in ("fp16", "f16") else "fp32",
+            "nwknn.base_rows": f"{batch_offset}+{batch_length}"}
+
+
+def _partial_pair_exists(data_dir, i, rows, k=None, tag: Optional[dict] = None) -> bool:
+    """A finished pair for base tile ``i``: both files readable, ``rows`` rows and (when given) ``k`` columns each, and --
+    when ``tag`` is given -- written by a run with the same metric, dtype and tile bounds.  Files without the tag (written
+    by the reference or by an older build) do not match a tag, so they are recomputed rather than trusted."""
     fi, fd = get_partial_indices_filename(data_dir, i), get_partial_distances_filename(data_dir, i)
     try:
-        return (os.path.getsize(fi) > 0 and os.path.getsize(fd) > 0 and pq.ParquetFile(fi).metadata.num_rows == rows
-                and pq.ParquetFile(fd).metadata.num_rows == rows)
+        if not (os.path.getsize(fi) > 0 and os.path.getsize(fd) > 0):
+            return False
+        for f in (fi, fd):
+            pf = pq.ParquetFile(f)
+            if pf.metadata.num_rows != rows or (k is not None and pf.metadata.num_columns != k):
+                return False
+            if tag is not None:
+                kv = pf.schema_arrow.metadata or {}
+                if any(kv.get(a.encode()) != b.encode() for a, b in tag.items()):
+                    return False
+        return True
     except (OSError, pa.ArrowInvalid):
         return False
 
@@ -239,8 +263,9 @@ def process_batches(data_dir,
             for start in range(slot, batch_count, len(devices)):
                 batch_offset = start * batch_size
                 batch_length = batch_size if start != batch_count - 1 else len(base_table) - batch_offset
-                if resume and _partial_pair_exists(data_dir, start, len(query_table)):
-                    print(f"-- base tile {start}: partial files present, skipped")
+                tag = _tile_tag(metric, dtype, batch_offset, batch_length)
+                if resume and _partial_pair_exists(data_dir, start, len(query_table), k, tag):
+                    print(f"-- base tile {start}: partial files of the same metric/dtype/tile present, skipped")
                     continue
                 dataset = table_columns(base_table.slice(batch_offset, batch_length))
                 assert (k <= batch_length)                              # cu_knn.py:237
@@ -249,8 +274,8 @@ def process_batches(data_dir,
                 distances, indices = eng.search_columns(queries, k, metric, index_offset=batch_offset)   # + batch_offset, cu_knn.py:273
                 assert (len(distances) == len(query_table))             # cu_knn.py:281-282
                 assert (len(indices) == len(query_table))
-                stream_cudf_to_parquet(get_partial_distances_filename(data_dir, start), distances, PARQUET_ROW_GROUP)
-                stream_cudf_to_parquet(get_partial_indices_filename(data_dir, start), indices, PARQUET_ROW_GROUP)
+                stream_cudf_to_parquet(get_partial_distances_filename(data_dir, start), distances, PARQUET_ROW_GROUP, tag)
+                stream_cudf_to_parquet(get_partial_indices_filename(data_dir, start), indices, PARQUET_ROW_GROUP, tag)
                 cleanup(dataset, distances, indices)
         finally:
             eng.set_compute_dtype('fp32')

@@ -98,6 +98,15 @@ class KnnEngine:
             raise ValueError(f"{what} must be 2-D, got shape {a.shape}")
         return a.ctypes.data, a.shape[0], a.shape[1], (DTYPE_F16 if a.dtype == np.float16 else DTYPE_F32), HOST, a
 
+    def _order_after_torch(self, t, what: str) -> None:
+        """A CUDA tensor handed to the library: it must live on this engine's GPU, and whatever torch queued on its own
+        stream to produce it (``.contiguous()``, ``.to(float32)``, the caller's kernels) must have finished before the
+        engine's stream reads the pointer."""
+        import torch
+        if t.device.index != self.device:
+            raise ValueError(f"{what} lives on {t.device}, this engine drives cuda:{self.device}")
+        torch.cuda.current_stream(t.device).synchronize()
+
     def set_compute_dtype(self, dtype: str) -> None:
         """'f32' (default, bit-exact canonical arithmetic) or 'f16' (fp16 MFMA, fp32 accumulate; BASELINE config 4).
         Takes effect at the next set_base."""
@@ -114,8 +123,7 @@ class KnnEngine:
         if rows == 0 or dim == 0:
             raise ValueError("dataset is empty")
         if loc == DEVICE:
-            import torch
-            torch.cuda.current_stream(keep.device).synchronize()
+            self._order_after_torch(keep, "dataset")
         check(self._L.nwknn_set_base(self._h, ctypes.c_void_p(ptr), rows, dim, dt, loc), "nwknn_set_base")
         if loc == DEVICE:
             self.synchronize()               # the caller may free/overwrite its tensor right after we return
@@ -185,9 +193,11 @@ class KnnEngine:
         if nq == 0:
             raise ValueError("queries are empty")
         want_dev = (loc == DEVICE) if out_device is None else bool(out_device)
+        if loc == DEVICE:
+            self._order_after_torch(keep, "queries")     # also when the results go to host memory
         if want_dev:
             import torch
-            dev = keep.device if loc == DEVICE else torch.device("cuda", self.device)
+            dev = torch.device("cuda", self.device)
             od = torch.empty((nq, k), dtype=torch.float32, device=dev)
             oi = torch.empty((nq, k), dtype=torch.int64, device=dev)
             torch.cuda.current_stream(dev).synchronize()
@@ -236,7 +246,7 @@ class KnnEngine:
             oi = torch.empty((q, k), dtype=torch.int64, device=d.device)
             loc = DEVICE if d.is_cuda else HOST
             if d.is_cuda:
-                torch.cuda.current_stream(d.device).synchronize()
+                self._order_after_torch(d, "merge input")
             check(self._L.nwknn_merge(self._h, ctypes.c_void_p(d.data_ptr()), ctypes.c_void_p(i.data_ptr()), n, q, kin, int(k),
                                       ctypes.c_void_p(od.data_ptr()), ctypes.c_void_p(oi.data_ptr()), loc), "nwknn_merge")
             return od, oi
@@ -256,7 +266,7 @@ class KnnEngine:
                 raise ValueError("doc_tokens must be [n_docs, tokens, d]")
             loc, ptr, shape, keep = (DEVICE if t.is_cuda else HOST), t.data_ptr(), tuple(t.shape), t
             if t.is_cuda:
-                torch.cuda.current_stream(t.device).synchronize()
+                self._order_after_torch(t, "doc_tokens")
         else:
             a = np.ascontiguousarray(doc_tokens, dtype=np.float32)
             if a.ndim != 3:
@@ -275,6 +285,8 @@ class KnnEngine:
             import torch
             t = query_tokens.to(torch.float32).contiguous()
             shape, ptr, keep, loc = tuple(t.shape), t.data_ptr(), t, (DEVICE if t.is_cuda else HOST)
+            if t.is_cuda:
+                self._order_after_torch(t, "query_tokens")
         else:
             a = np.ascontiguousarray(query_tokens, dtype=np.float32)
             shape, ptr, keep, loc = a.shape, a.ctypes.data, a, HOST

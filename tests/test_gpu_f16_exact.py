@@ -133,3 +133,21 @@ def test_random_cases_against_the_oracle(oracle, seed):
             rd, ri = oracle.knn_canonical(bf, qf, k, metric)
             assert np.array_equal(idx, ri), f"seed {seed} {metric} Q={Q} B={B} d={d} k={k}: {(idx != ri).sum()} index mismatches"
             assert _bitwise(dist, rd), f"seed {seed} {metric}"
+
+
+@pytest.mark.parametrize("metric", EXACT)
+def test_two_workgroup_tile_shape_with_exact_mode_walks_the_right_tiles(oracle, metric):
+    """Dev option f16_mfma=2 (256 x 128 tiles) together with exact fp16 mode: the dense first chunk always runs the 256-row
+    16x16x32 build, so its tile count must be in 256-row tiles whatever f16_mfma says (counted in 128-row tiles the kernel
+    walked twice the chunk and past the base allocation)."""
+    from neighborhoodwatch_amd import KnnEngine
+    rng = np.random.default_rng(11)
+    base16 = rng.standard_normal((3000, 96)).astype(np.float16)
+    queries16 = rng.standard_normal((70, 96)).astype(np.float16)
+    with KnnEngine(0) as eng:
+        eng.set_option("f16_mfma", 2)
+        eng.set_base(base16)
+        dist, idx = eng.search(queries16, 20, metric)
+        assert eng.stats()["prescreen"] == 1
+    rd, ri = oracle.knn_canonical(base16.astype(np.float32), queries16.astype(np.float32), 20, metric)
+    assert np.array_equal(idx, ri) and _bitwise(dist, rd)

@@ -156,12 +156,27 @@ def test_resume_skips_finished_tiles_and_two_engines_share_the_work(dataset, ora
     capsys.readouterr()
     cu_knn.compute_knn(data_dir, "intfloat/e5-small-v2", 384, qf, 300, bf, 2600, False, 10, 1000, resume=True)
     out = capsys.readouterr().out
-    assert "base tile 0: partial files present, skipped" in out and "base tile 2: partial files present, skipped" in out
+    assert "base tile 0: partial files of the same metric/dtype/tile present, skipped" in out and "base tile 2: partial files of the same" in out
     assert "base tile 1: partial" not in out
     merge.merge_indices_and_distances(data_dir, k=10)
     fd, fi = _final(data_dir)
     base = synth.gen_unit_rows(0x72, 0, 2600, 384); queries = synth.gen_unit_rows(0x71, 0, 300, 384)
     rd, ri = oracle.knn_canonical(base, queries, 10)
+    assert np.array_equal(_arr(fi, np.int64), ri) and np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
+
+
+def test_resume_does_not_reuse_tiles_of_another_metric(dataset, oracle, capsys):
+    """The directory name pins q, b and k but not the distance: partial pairs written by a sqeuclidean run must not be
+    mixed into a cosine run by --resume (they carry the metric / dtype / tile bounds in their parquet metadata)."""
+    data_dir, qf, bf = dataset
+    cu_knn.compute_knn(data_dir, "intfloat/e5-small-v2", 384, qf, 300, bf, 2600, False, 10, 1000)            # raft: sqeuclidean
+    capsys.readouterr()
+    cu_knn.compute_knn(data_dir, "intfloat/e5-small-v2", 384, qf, 300, bf, 2600, False, 10, 1000, resume=True, engine="cuvs")
+    assert "skipped" not in capsys.readouterr().out
+    merge.merge_indices_and_distances(data_dir, k=10)
+    fd, fi = _final(data_dir)
+    base = synth.gen_unit_rows(0x72, 0, 2600, 384); queries = synth.gen_unit_rows(0x71, 0, 300, 384)
+    rd, ri = oracle.knn_canonical(base, queries, 10, "cosine")
     assert np.array_equal(_arr(fi, np.int64), ri) and np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
 
 

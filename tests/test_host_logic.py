@@ -124,6 +124,37 @@ def test_stream_to_parquet_contract(tmp_path):
     assert all(pa.types.is_int64(x.type) for x in pq.read_table(tmp_path / "i.parquet").schema)
 
 
+def test_resume_accepts_a_partial_pair_only_from_the_same_kind_of_run(tmp_path):
+    """--resume: a pair counts as finished only with the right rows AND columns AND the metric / dtype / tile bounds it was
+    written with (kept in the parquet key-value metadata); untagged files (the reference's, an older build's) do not match."""
+    (tmp_path / "partial").mkdir()
+    d = np.zeros((30, 5), dtype=np.float32); i = np.zeros((30, 5), dtype=np.int64)
+    tag = cu_knn._tile_tag("sqeuclidean", "fp32", 1000, 500)
+
+    def write(t):
+        cu_knn.stream_cudf_to_parquet(nw_utils.get_partial_distances_filename(str(tmp_path), 0), d, 100000, t)
+        cu_knn.stream_cudf_to_parquet(nw_utils.get_partial_indices_filename(str(tmp_path), 0), i, 100000, t)
+
+    write(tag)
+    ok = lambda *a: cu_knn._partial_pair_exists(str(tmp_path), 0, *a)
+    assert ok(30) and ok(30, 5) and ok(30, 5, tag)
+    assert not ok(31, 5, tag) and not ok(30, 6, tag)
+    assert not ok(30, 5, cu_knn._tile_tag("cosine", "fp32", 1000, 500))
+    assert not ok(30, 5, cu_knn._tile_tag("sqeuclidean", "fp16", 1000, 500))
+    assert not ok(30, 5, cu_knn._tile_tag("sqeuclidean", "fp32", 0, 500))
+    assert not cu_knn._partial_pair_exists(str(tmp_path), 1, 30)
+    write(None)
+    assert ok(30, 5) and not ok(30, 5, tag)
+    t = pq.read_table(nw_utils.get_partial_distances_filename(str(tmp_path), 0))       # the tag does not disturb readers
+    assert t.schema.names == [str(j) for j in range(5)]
+
+
+def test_launcher_exits_with_mains_return_code():
+    from pathlib import Path
+    src = (Path(__file__).resolve().parents[1] / "launcher.py").read_text()
+    assert "sys.exit(main())" in src                                                      # launcher.py of the reference discards it
+
+
 def test_prep_table_and_matrix(tmp_path):
     f = synth.write_source_parquet(str(tmp_path / "m_8_base_vector_data_30.parquet"), 5, 30, 8, chunk_rows=16)
     t = cu_knn.prep_table(str(tmp_path), "m", "m_8_base_vector_data_30.parquet", 20, 8)
