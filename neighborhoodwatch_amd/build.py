@@ -1,40 +1,68 @@
 """Builds libnwknn.so in-tree with hipcc for gfx950 (the only target; no other arch, no CPU build).
 
     python -m neighborhoodwatch_amd.build [--force]
+
+Every source file is compiled to its own object (in parallel, only when it or a header is newer than the object) and the
+objects are linked into the shared library, so touching one kernel file rebuilds one object.
 """
 from __future__ import annotations
 
+import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
+OBJ = CSRC / "build"
 OUT = PKG / "libnwknn.so"
-SOURCES = [CSRC / "nwknn_kernels.hip", CSRC / "nwknn_api.cpp"]
-HEADERS = [CSRC / "nwknn_internal.h", PKG.parent / "include" / "nwknn.h"]
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-fhip-fp32-correctly-rounded-divide-sqrt",
-         "-ffp-contract=off", "-x", "hip"]
+SOURCES = [CSRC / n for n in ("nwk_tile_f16.hip", "nwk_maxsim.hip", "nwk_tile_f32.hip", "nwk_select.hip", "nwk_prep.hip", "nwknn_api.cpp")]
+HEADERS = [CSRC / "nwk_device.h", CSRC / "nwknn_internal.h", PKG.parent / "include" / "nwknn.h"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=off", "-x", "hip"]
+
+
+def _obj(src: Path) -> Path:
+    return OBJ / (src.stem + ".o")
+
+
+def _stale(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(p.stat().st_mtime > t for p in deps)
 
 
 def needs_build() -> bool:
-    if not OUT.exists():
-        return True
-    t = OUT.stat().st_mtime
-    return any(p.stat().st_mtime > t for p in SOURCES + HEADERS + [Path(__file__)])
+    return _stale(OUT, SOURCES + HEADERS + [Path(__file__)])
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, *FLAGS, *map(str, SOURCES), "-o", str(OUT)]
+    OBJ.mkdir(exist_ok=True)
+
+    def compile_one(src: Path):
+        obj = _obj(src)
+        if not force and not _stale(obj, [src, *HEADERS, Path(__file__)]):
+            return None
+        cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        return subprocess.run(cmd, capture_output=True, text=True), src
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
+        for res in pool.map(compile_one, SOURCES):
+            if res is not None and res[0].returncode != 0:
+                raise RuntimeError(f"hipcc failed on {res[1].name} ({res[0].returncode}):\n{res[0].stdout}\n{res[0].stderr}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[str(_obj(s)) for s in SOURCES], "-o", str(OUT)]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({r.returncode}):\n{r.stdout}\n{r.stderr}")
+        raise RuntimeError(f"link failed ({r.returncode}):\n{r.stdout}\n{r.stderr}")
     return OUT
 
 

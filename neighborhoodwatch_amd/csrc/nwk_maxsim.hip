@@ -1,0 +1,512 @@
+// nwk_maxsim.hip -- MaxSim late interaction (extension, not in the reference): tile, pre-screen, prune and rescore kernels  (gfx950 only; shared pieces and the overall design: nwk_device.h)
+#include "nwk_device.h"
+
+// ------------------------------------------------------------------------------------------------
+// MaxSim late interaction (BASELINE config 5; NOT in the reference -- its `ck` is flat token-level kNN):
+//     score(query, doc) = sum over the query's TQK tokens of  max over the doc's TDK tokens of  (q_token . d_token)
+// and the k docs with the highest score per query.  One workgroup multiplies 256 doc-token rows (4 docs of 64 tokens)
+// by 128 query-token columns (4 queries of 32 tokens) with the same LDS/DMA/MFMA loop as the kNN tile (d = 128 is
+// 8 slabs of 16).  Orientation matters: doc tokens sit on the accumulator ROWS (registers), query tokens on the lanes,
+// so the max over a doc's 64 tokens is 31 in-lane v_max + one cross-half exchange, and only the final sum over the 32
+// query tokens crosses lanes (5 butterfly steps per (doc, query) pair; the transposed orientation needs 80 per pair).
+// Each wave yields 2 docs x 2 queries = 4 scores per tile.  Scores are ranked through the same 64-bit keys as distances
+// (key = sortable(-score) << 32 | doc), so list filtering, compaction and repair are shared with the kNN path.
+// Canonical arithmetic: dot = ascending-k fmaf chain (fp32 MFMA), max exact, token sum = balanced pairwise tree in
+// natural token order (what the xor-1,2,4,8,16 butterfly computes) -- restated by oracle nwo_maxsim, bit for bit.
+// ------------------------------------------------------------------------------------------------
+#define MS_TDK 64                  // tokens per doc
+#define MS_TQK 32                  // tokens per query
+#define MS_DOCS_PER_TILE 4
+#define MS_QUERIES_PER_TILE 4
+
+template <bool DENSE>
+__global__ __launch_bounds__(256, 2) void nwk_maxsim_kernel(const NwkTileParams p)
+{
+    constexpr int TM = 256, BKT = 16;
+    constexpr int MT = TM / 64, ROWB = BKT * 4, CH = BKT / 4, RSH = 2;
+    constexpr int A_BYTES = TM * ROWB, B_BYTES = TB * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int RPI = 1024 / ROWB, IA = TM / RPI / 4, IB = TB / RPI / 4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const TileCoord tc = tile_from_block(p);         // tc.qt: group of 4 queries, tc.bt: tile of 4 docs
+    if (!tc.ok) return;
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, l = tid & 63;
+    const int wr = w >> 1, wc = w & 1;
+    const int h = l >> 5, c32 = l & 31;
+    const long long drow0 = (long long)tc.bt * TM;   // first doc-token row of the tile   (A operand, from p.bp)
+    const long long qrow0 = (long long)tc.qt * TB;   // first query-token row of the tile (B operand, from p.qp)
+    const int dp = p.dp;
+    const int nk = dp / BKT;
+
+    unsigned voffA[4], voffB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = (w * IA + i) * RPI + (l / CH), rb = (w * IB + i) * RPI + (l / CH);
+        voffA[i] = (unsigned)(ra * dp + (((l % CH) ^ ((ra >> RSH) & (CH - 1))) << 2)) * 4u;
+        voffB[i] = (unsigned)(rb * dp + (((l % CH) ^ ((rb >> RSH) & (CH - 1))) << 2)) * 4u;
+    }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bp + drow0 * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.qp + qrow0 * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const int ldsA = __builtin_amdgcn_readfirstlane(w * IA * 1024);
+    const int ldsB = __builtin_amdgcn_readfirstlane(A_BYTES + w * IB * 1024);
+    auto issue_stage = [&](int stage, int kt) {
+        char* base = smem + stage * STAGE;
+        const int soff = kt * ROWB;
+#pragma unroll
+        for (int i = 0; i < IA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(base + ldsA + i * 1024), 16, voffA[i], soff, 0, 0);
+#pragma unroll
+        for (int i = 0; i < IB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(base + ldsB + i * 1024), 16, voffB[i], soff, 0, 0);
+    };
+
+    int offA[MT], offB[2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int ra = wr * (TM / 2) + m * 32 + c32;
+        offA[m] = ra * ROWB + ((h ^ ((ra >> RSH) & (CH - 1))) << 4);
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int rb = wc * 64 + n * 32 + c32;
+        offB[n] = A_BYTES + rb * ROWB + ((h ^ ((rb >> RSH) & (CH - 1))) << 4);
+    }
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    // thresholds of this wave's two queries (wave-uniform addresses), in flight under the K loop
+    const long long q_first = (long long)tc.qt * MS_QUERIES_PER_TILE + 2 * wc;
+    u64 tauq[2] = {~0ull, ~0ull};
+    if (!DENSE) { tauq[0] = p.tau[q_first]; tauq[1] = p.tau[q_first + 1]; }
+
+    issue_stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            issue_stage(cur ^ 1, kt + 1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const char* sb = smem + cur * STAGE;
+#pragma unroll
+        for (int g = 0; g < BKT / 8; ++g) {
+            f32x4 a[MT], b[2];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[m] = *(const f32x4*)(sb + (offA[m] ^ (g << 5)));
+#pragma unroll
+            for (int n = 0; n < 2; ++n) b[n] = *(const f32x4*)(sb + (offB[n] ^ (g << 5)));
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][t], b[n][t], acc[m][n], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue: 2 docs x 2 queries per wave
+    const int cap = p.cap;
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd) {
+        const long long doc = (long long)tc.bt * MS_DOCS_PER_TILE + 2 * wr + dd;
+        const bool doc_ok = doc < p.nb_valid;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            float v = acc[2 * dd][n][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) v = fmaxf(v, acc[2 * dd][n][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v = fmaxf(v, acc[2 * dd + 1][n][r]);
+            v = fmaxf(v, __shfl_xor(v, 32));                 // the two half-waves hold the other 32 token rows of this doc
+            float sum = v;                                    // lane c32 = query token c32: balanced pairwise tree over tokens
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) sum = __fadd_rn(sum, __shfl_xor(sum, o));
+            const long long q = q_first + n;
+            const u64 key = ((u64)sortable_u32(-sum) << 32) | (u32)doc;
+            if (l == 0) {
+                if (DENSE) {
+                    p.buf[q * cap + (doc - p.dense_col0)] = doc_ok ? key : ~0ull;
+                } else if (doc_ok && key < tauq[n]) {
+                    const u32 pos = atomicAdd(p.cnt + q, 1u);
+                    if (pos < (u32)cap) p.buf[q * cap + pos] = key;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxSim through the fp16 pre-screen (option "prescreen" before nwknn_maxsim_set_docs).  The score is a sum over the query's tokens of
+// a max over the doc's tokens of dot products, so its fp16 estimate is off by at most
+//     sum_i max_j E(q_i, d_j)  <=  R(q) + C(d),   R(q) = sum_i rowerr(q_i),   C(d) = 32 * max_j colerr(d_j)
+// with E = rowerr + colerr the per-dot bound of the kNN pre-screen: additive in (query, doc), so the same test and the same
+// bound-based pruning apply.  nwk_maxsim_pre_kernel is nwk_maxsim_kernel on the scaled fp16 copies (v_mfma_f32_32x32x16_f16: the same
+// accumulator layout, hence the same in-lane max / butterfly sum), 32-half slabs of 64-B LDS rows (image of the f16q kernel), two
+// workgroups per CU; it lists (query, doc) pairs with key = fp16 estimate of -score.  nwk_maxsim_rescore_kernel then recomputes
+// the survivors with the canonical arithmetic of nwk_maxsim_kernel (ascending-k fmaf chains, exact max, pairwise tree sum).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nwk_maxsim_bounds_kernel(const float* __restrict__ norms, long long n_items, int tokens, float eps_half,
+                                                                 float a_self, float cst, int is_doc, float* __restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_items) return;
+    float s = 0.0f, m = 0.0f, ns = 0.0f, nm = 0.0f;
+    for (int j = 0; j < tokens; ++j) {
+        const float n = norms[i * tokens + j];
+        const float e = eps_half * n + a_self * __builtin_amdgcn_sqrtf(n) + cst;
+        s += e; m = fmaxf(m, e); ns += n; nm = fmaxf(nm, n);
+    }
+    // + the two fp32 token sums (canonical and estimate) disagreeing by a few ulps of sum|max dot| <= (sum qn + 32 max bn) / 2
+    out[i] = is_doc ? (float)NWK_MS_TOKENS_PER_QUERY * (m * 1.0001f + 4.0e-6f * nm) : s * 1.0001f + 4.0e-6f * ns + 1.0e-30f;
+}
+
+__global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_kernel(const NwkTileParams p)
+{
+    constexpr int TM = 256, TQ = 128, STAGE = (TM + TQ) * 64;        // 32-half slabs: 64-B rows, 24 KiB per stage
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const TileCoord tc = tile_from_block(p);         // tc.qt: group of 4 queries, tc.bt: tile of 4 docs
+    if (!tc.ok) return;
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, l = tid & 63;
+    const int wr = w >> 1, wc = w & 1;
+    const int h = l >> 5, c32 = l & 31;
+    const long long drow0 = (long long)tc.bt * TM;   // first doc-token row of the tile   (A operand, fp16 copy in p.bp)
+    const long long qrow0 = (long long)tc.qt * TQ;   // first query-token row of the tile (B operand, fp16 copy in p.qp)
+    const int dp = p.dp;                             // halves per row
+    const int nk = dp / 32;
+    const _Float16* docs = (const _Float16*)p.bp;
+    const _Float16* qrys = (const _Float16*)p.qp;
+
+    const unsigned voff = (unsigned)((l >> 2) * dp * 2 + (((l & 3) ^ ((0 - (l >> 4)) & 3)) << 4));
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(docs + drow0 * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(qrys + qrow0 * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int rowsA = wu * 64 * dp * 2, rowsB = wu * 32 * dp * 2, step16 = 16 * dp * 2;
+    auto issue_stage = [&](int stage, int kt) {
+        char* st = smem + stage * STAGE;
+        const int soff = kt * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(st + wu * 4096 + i * 1024), 16, voff, soff + rowsA + i * step16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(st + TM * 64 + wu * 2048 + i * 1024), 16, voff, soff + rowsB + i * step16, 0, 0);
+    };
+
+    const int swz = (0 - (c32 >> 2)) & 3;
+    int offA[4], offB[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) offA[m] = (wr * 128 + m * 32 + c32) * 64 + ((h ^ swz) << 4);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) offB[n] = TM * 64 + (wc * 64 + n * 32 + c32) * 64 + ((h ^ swz) << 4);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    const long long q_first = (long long)tc.qt * MS_QUERIES_PER_TILE + 2 * wc;
+    const u64 tauq[2] = {p.tau[q_first], p.tau[q_first + 1]};
+    const float rq[2] = {p.ms_rq[q_first], p.ms_rq[q_first + 1]};
+
+    issue_stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            issue_stage(cur ^ 1, kt + 1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const char* sb = smem + cur * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 a[4], b[2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] = *(const f16x8*)(sb + (offA[m] ^ (ks << 5)));
+#pragma unroll
+            for (int n = 0; n < 2; ++n) b[n] = *(const f16x8*)(sb + (offB[n] ^ (ks << 5)));
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    const int cap = p.cap;
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd) {
+        const long long doc = (long long)tc.bt * MS_DOCS_PER_TILE + 2 * wr + dd;
+        const bool doc_ok = doc < p.nb_valid;
+        const float cd = doc_ok ? p.ms_cd[doc] : 0.0f;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            float v = acc[2 * dd][n][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) v = fmaxf(v, acc[2 * dd][n][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v = fmaxf(v, acc[2 * dd + 1][n][r]);
+            v = fmaxf(v, __shfl_xor(v, 32));
+            float sum = v;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) sum = __fadd_rn(sum, __shfl_xor(sum, o));
+            if (l == 0 && doc_ok) {
+                const long long q = q_first + n;
+                const float score = sum * p.pre_inv_scale;                         // fp16 estimate of the MaxSim score
+                bool pass = true;
+                if (tauq[n] != ~0ull) {
+                    const float td = unsortable_f32((u32)(tauq[n] >> 32));          // = -(k-th best score so far)
+                    const float err = rq[n] + cd;
+                    pass = !(score < (-td) - err - 2.0e-6f * (fabsf(td) + err));
+                }
+                if (pass && q < p.nq_valid) {
+                    const u32 pos = atomicAdd(p.cnt + q, 1u);
+                    if (pos < (u32)cap) p.buf[q * cap + pos] = ((u64)__float_as_uint(-score) << 32) | (u32)doc;
+                }
+            }
+        }
+    }
+}
+
+// Rescoring in two launches.  (1) nwk_maxsim_prune_kernel, one wave per query: bounds est +- (R(q) + C(doc)) of the listed pairs,
+// k-th smallest upper bound by bisection, pairs that cannot reach the top k become ~0, the slots of the others go to surv[q][.].
+// (2) nwk_maxsim_rescore_kernel, grid (queries, slices): a wave takes every slices-th survivor of its query, two at a time (each
+// query-token value fetched from LDS feeds two docs); lane j owns doc token j (64 lanes = 64 tokens), 32 fmaf chains per lane and doc
+// (one per query token, ascending k over the prepared fp32 rows), max over the lanes by reduce-and-transpose, pairwise tree sum
+// -- the arithmetic of nwk_maxsim_kernel, bit for bit.  Splitting a query's survivors over several waves matters: there are only
+// ~2k queries but ~6k survivors per query, 4096 FMAs per lane each.
+__global__ __launch_bounds__(256) void nwk_maxsim_prune_kernel(const NwkMsRescoreParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 ms_dyn[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const long long q = (long long)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + wv));
+    u32* s_ub = ms_dyn + (size_t)wv * 2 * p.cap;
+    u32* s_lb = s_ub + p.cap;
+    const u32 start = p.cnt0[q];
+    u32 end = p.cnt[q];
+    if (end > (u32)p.cap) end = (u32)p.cap;
+    u32* surv = p.surv + q * p.cap;
+    if (start >= end) { if (lane == 0) p.nsurv[q] = 0; return; }
+    u64* list = p.buf + q * p.cap;
+    u32 nsurv = 0;
+    if (p.prune && end >= (u32)p.k) {
+        const float rq = p.rq[q];
+        for (u32 e0 = 0; e0 < end; e0 += 64) {
+            const u32 e = e0 + lane;
+            if (e < end) {
+                const u64 key = list[e];
+                if (e < start) { s_ub[e] = (u32)(key >> 32); s_lb[e] = 0u; }
+                else {
+                    const float est = __uint_as_float((u32)(key >> 32));             // estimate of -score
+                    const float err = (rq + p.cd[(u32)key]) * 1.0001f + 2.0e-6f * (fabsf(est) + 1.0f);
+                    s_ub[e] = sortable_u32(est + err);
+                    s_lb[e] = sortable_u32(est - err);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        u32 lo = 0u, hi = 0xFFFFFFFFu;
+        while (lo < hi) {
+            const u32 mid = lo + ((hi - lo) >> 1);
+            u32 c = 0;
+            for (u32 e0 = 0; e0 < end; e0 += 64) {
+                const u32 e = e0 + lane;
+                c += (u32)__popcll(__ballot(e < end && s_ub[e] <= mid));
+            }
+            if (c >= (u32)p.k) hi = mid; else lo = mid + 1u;
+        }
+        const u32 U = lo;
+        for (u32 e0 = start; e0 < end; e0 += 64) {
+            const u32 e = e0 + lane;
+            const bool live = e < end;
+            const bool keep = live && s_lb[e] <= U;
+            const u64 mk = __ballot(keep);
+            if (keep) surv[nsurv + (u32)__popcll(mk & ((1ull << lane) - 1ull))] = e;
+            else if (live) list[e] = ~0ull;
+            nsurv += (u32)__popcll(mk);
+        }
+    } else {
+        nsurv = end - start;
+        for (u32 i = lane; i < nsurv; i += 64) surv[i] = start + i;
+    }
+    if (lane == 0) {
+        p.nsurv[q] = nsurv;
+        if (p.dbg) { atomicAdd(p.dbg, (unsigned long long)(end - start)); atomicAdd(p.dbg + 1, (unsigned long long)nsurv); }
+    }
+}
+
+template <bool QLDS>      // the query's token rows are staged in LDS (a generic pointer would make every read a flat_load)
+__global__ __launch_bounds__(256) void nwk_maxsim_rescore_kernel(const NwkMsRescoreParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 ms_dyn[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const long long q = (long long)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + wv));
+    const u32 nsurv = p.nsurv[q];
+    const u32 slice = blockIdx.y, slices = gridDim.y;
+    if (slice * 2 >= nsurv) return;
+    u64* list = p.buf + q * p.cap;
+    const u32* surv = p.surv + q * p.cap;
+    const float* __restrict__ qtok = p.qp + q * NWK_MS_TOKENS_PER_QUERY * p.dp;
+    // the query's 32 token rows are read by every lane for every survivor: stage them in LDS once (uniform global loads do not
+    // become scalar loads here -- the kernel also stores to global memory)
+    float* s_q = (float*)ms_dyn + (size_t)wv * NWK_MS_TOKENS_PER_QUERY * p.dp;
+    if (QLDS) {
+        const int n4 = NWK_MS_TOKENS_PER_QUERY * p.dp / 4;
+        for (int i = lane; i < n4; i += 64) *(f32x4*)(s_q + 4 * i) = *(const f32x4*)(qtok + 4 * i);
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    for (u32 i = slice * 2; i < nsurv; i += slices * 2) {                               // survivors i and i+1 (wave-uniform)
+        const u32 e0 = surv[i], e1 = (i + 1 < nsurv) ? surv[i + 1] : e0;
+        const u32 doc0 = (u32)list[e0], doc1 = (u32)list[e1];
+        const float* __restrict__ br0 = p.bp + ((long long)doc0 * NWK_MS_TOKENS_PER_DOC + lane) * p.dp;
+        const float* __restrict__ br1 = p.bp + ((long long)doc1 * NWK_MS_TOKENS_PER_DOC + lane) * p.dp;
+        float a0[NWK_MS_TOKENS_PER_QUERY], a1[NWK_MS_TOKENS_PER_QUERY];
+#pragma unroll
+        for (int t = 0; t < NWK_MS_TOKENS_PER_QUERY; ++t) { a0[t] = 0.0f; a1[t] = 0.0f; }
+        // the doc rows are gathers from HBM (512-B stride between lanes): keep the loads two 8-k steps ahead of their use
+        f32x4 pf[3][4];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int kk = (s2 * 8 < p.dp) ? s2 * 8 : 0;
+            pf[s2][0] = *(const f32x4*)(br0 + kk); pf[s2][1] = *(const f32x4*)(br0 + kk + 4);
+            pf[s2][2] = *(const f32x4*)(br1 + kk); pf[s2][3] = *(const f32x4*)(br1 + kk + 4);
+        }
+        for (int k0 = 0; k0 < p.dp; k0 += 8) {
+            const f32x4 be0 = pf[0][0], bo0 = pf[0][1], be1 = pf[0][2], bo1 = pf[0][3];
+            {
+                const int kk = (k0 + 16 < p.dp) ? k0 + 16 : 0;                          // (past the end: a harmless reload of step 0)
+                pf[2][0] = *(const f32x4*)(br0 + kk); pf[2][1] = *(const f32x4*)(br0 + kk + 4);
+                pf[2][2] = *(const f32x4*)(br1 + kk); pf[2][3] = *(const f32x4*)(br1 + kk + 4);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { pf[0][c] = pf[1][c]; pf[1][c] = pf[2][c]; }
+#pragma unroll
+            for (int t = 0; t < NWK_MS_TOKENS_PER_QUERY; ++t) {
+                f32x4 qe, qo;
+                if (QLDS) { qe = *(const f32x4*)(s_q + t * p.dp + k0); qo = *(const f32x4*)(s_q + t * p.dp + k0 + 4); }
+                else { qe = *(const f32x4*)(qtok + t * p.dp + k0); qo = *(const f32x4*)(qtok + t * p.dp + k0 + 4); }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                                          // k ascending: k0+2j, k0+2j+1
+                    a0[t] = __fmaf_rn(be0[j], qe[j], a0[t]);
+                    a1[t] = __fmaf_rn(be1[j], qe[j], a1[t]);
+                    a0[t] = __fmaf_rn(bo0[j], qo[j], a0[t]);
+                    a1[t] = __fmaf_rn(bo1[j], qo[j], a1[t]);
+                }
+            }
+        }
+        // max over the doc's 64 tokens (= lanes) for each of the 32 query tokens, as a reduce-and-transpose: at stage s lanes whose
+        // bit s is b keep the tokens whose bit s is b and hand the others to their xor-2^s partner: 16+8+4+2+1 exchanges instead of
+        // 32 x 6, after which lane l holds token l & 31 reduced over its half-wave; one last exchange joins the halves.  (max is exact.)
+#pragma unroll
+        for (int sft = 0; sft < 5; ++sft) {
+            const bool up = (lane >> sft) & 1;
+#pragma unroll
+            for (int j = 0; j < (16 >> sft); ++j) {
+                const float l0 = a0[2 * j], h0 = a0[2 * j + 1], l1 = a1[2 * j], h1 = a1[2 * j + 1];
+                a0[j] = fmaxf(up ? h0 : l0, __shfl_xor(up ? l0 : h0, 1 << sft));
+                a1[j] = fmaxf(up ? h1 : l1, __shfl_xor(up ? l1 : h1, 1 << sft));
+            }
+        }
+        float s0 = fmaxf(a0[0], __shfl_xor(a0[0], 32)), s1 = fmaxf(a1[0], __shfl_xor(a1[0], 32));
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {                                             // lane c = query token c & 31: the kernel's tree
+            s0 = __fadd_rn(s0, __shfl_xor(s0, o));
+            s1 = __fadd_rn(s1, __shfl_xor(s1, o));
+        }
+        if (lane == 0) {
+            list[e0] = ((u64)sortable_u32(-s0) << 32) | doc0;
+            if (e1 != e0) list[e1] = ((u64)sortable_u32(-s1) << 32) | doc1;
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// launchers (host side, called from nwknn_api.cpp)
+// ------------------------------------------------------------------------------------------------
+extern "C++" {
+
+// MaxSim: p.n_qtiles counts groups of 4 queries (128 query-token rows), p.n_btiles tiles of 4 docs (256 doc-token rows)
+hipError_t nwk_launch_maxsim(hipStream_t st, NwkTileParams p, bool dense)
+{
+    if (p.n_qtiles <= 0 || p.n_btiles <= 0) return hipSuccess;
+    if (p.sq_shift < 0 || p.sq_shift > 6) return hipErrorInvalidValue;
+    const int SQ = 1 << p.sq_shift, SB = 64 >> p.sq_shift;
+    const long long n_super_q = (p.n_qtiles + SQ - 1) / SQ;
+    p.n_super_b = (p.n_btiles + SB - 1) / SB;
+    long long supers = n_super_q * p.n_super_b;
+    supers = (supers + 7) / 8 * 8;
+    const long long grid = supers * 64;
+    if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    if (dense) hipLaunchKernelGGL((nwk_maxsim_kernel<true>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((nwk_maxsim_kernel<false>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+// MaxSim pre-screen: p.qp / p.bp are the scaled fp16 copies (dp halves), p.n_qtiles groups of 4 queries, p.n_btiles tiles of 4 docs
+hipError_t nwk_launch_maxsim_pre(hipStream_t st, NwkTileParams p)
+{
+    if (p.n_qtiles <= 0 || p.n_btiles <= 0) return hipSuccess;
+    if (p.sq_shift < 0 || p.sq_shift > 6) return hipErrorInvalidValue;
+    const int SQ = 1 << p.sq_shift, SB = 64 >> p.sq_shift;
+    const long long n_super_q = (p.n_qtiles + SQ - 1) / SQ;
+    p.n_super_b = (p.n_btiles + SB - 1) / SB;
+    long long supers = n_super_q * p.n_super_b;
+    supers = (supers + 7) / 8 * 8;
+    const long long grid = supers * 64;
+    if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(nwk_maxsim_pre_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t nwk_launch_maxsim_bounds(hipStream_t st, const float* norms, long long n_items, int tokens, float eps_half, float a_self, float cst,
+                                    int is_doc, float* out)
+{
+    if (n_items <= 0) return hipSuccess;
+    hipLaunchKernelGGL(nwk_maxsim_bounds_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, st, norms, n_items, tokens, eps_half, a_self,
+                       cst, is_doc, out);
+    return hipGetLastError();
+}
+
+hipError_t nwk_launch_maxsim_rescore(hipStream_t st, NwkMsRescoreParams p, long long nq_pad, int slices)
+{
+    if (nq_pad <= 0) return hipSuccess;
+    {   // (1) prune: one wave per query
+        const int waves = p.cap <= 1024 ? 4 : (p.cap <= 2048 ? 2 : 1);      // nq_pad is a multiple of 8
+        const size_t lds = (size_t)waves * p.cap * 8 + 512;
+        hipLaunchKernelGGL(nwk_maxsim_prune_kernel, dim3((unsigned)((nq_pad + waves - 1) / waves)), dim3(64 * waves), lds, st, p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    // (2) rescore: (query, slice) waves; the query's 32 token rows in LDS when they fit (d = 128: 16 KiB per wave)
+    const size_t qbytes = (size_t)NWK_MS_TOKENS_PER_QUERY * p.dp * 4;
+    const int waves = 2;
+    p.q_in_lds = (waves * qbytes <= 64 * 1024) ? 1 : 0;
+    const size_t lds = p.q_in_lds ? waves * qbytes : 16;
+    if (p.q_in_lds)
+        hipLaunchKernelGGL((nwk_maxsim_rescore_kernel<true>), dim3((unsigned)((nq_pad + waves - 1) / waves), (unsigned)slices), dim3(64 * waves), lds, st, p);
+    else
+        hipLaunchKernelGGL((nwk_maxsim_rescore_kernel<false>), dim3((unsigned)((nq_pad + waves - 1) / waves), (unsigned)slices), dim3(64 * waves), lds, st, p);
+    return hipGetLastError();
+}
+
+}  // extern "C++"

@@ -1,0 +1,325 @@
+// nwk_select.hip -- rescoring of pre-screened pairs, per-query list compaction (K3), finalize, partial-list merge (K5)  (gfx950 only; shared pieces and the overall design: nwk_device.h)
+#include "nwk_device.h"
+
+// One wave per query (blockDim = 64 * waves, dynamic LDS = waves * cap * 8 bytes).  The keys the pre-screen listed carry the
+// fp16 ESTIMATE of the distance; with the error bound e(q,b) the exact value lies in [est - e, est + e].  Phases:
+//   1. bounds of every list entry into LDS (entries of the compacted prefix [0, cnt0) are exact: lb = ub = their distance);
+//   2. U = k-th smallest UPPER bound (bisection over the sortable 32-bit space, ballot counts): at least k entries are <= U,
+//      so the k-th key after this chunk is <= U and every candidate whose LOWER bound is > U can be dropped unrescored;
+//   3. the survivors are packed and rescored 64 at a time: ascending-k fmaf chain over the prepared fp32 rows (the chain the
+//      fp32 MFMA accumulator performs), canonical epilogue, 64-bit key written back in place; dropped entries become ~0
+//      (the sentinel compaction already sorts last).
+template <int METRIC, bool ROWS16>
+__global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 rs_dyn[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const long long q = (long long)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + wv));
+    u32* s_ub = rs_dyn + (size_t)wv * 2 * p.cap;          // later: the packed survivor slots
+    u32* s_lb = s_ub + p.cap;
+    const u32 start = p.cnt0[q];
+    u32 end = p.cnt[q];
+    if (end > (u32)p.cap) end = (u32)p.cap;
+    if (start >= end) return;
+    const float* __restrict__ qrow = ROWS16 ? nullptr : p.qp + q * p.dp;
+    const _Float16* __restrict__ qrow16 = ROWS16 ? (const _Float16*)p.qp + q * p.dp : nullptr;      // exact fp16 mode: the rows ARE the data
+    const float qn = p.qn[q];
+    u64* list = p.buf + q * p.cap;
+
+    u32 nsurv = 0;
+    if (p.prune && end >= (u32)p.k) {
+        const float row_err = p.eps_half * qn + p.ab * __builtin_amdgcn_sqrtf(qn) + p.cst;
+        for (u32 e0 = 0; e0 < end; e0 += 64) {
+            const u32 e = e0 + lane;
+            if (e < end) {
+                const u64 key = list[e];
+                if (e < start) { s_ub[e] = (u32)(key >> 32); s_lb[e] = 0u; }
+                else if (key == ~0ull) { s_ub[e] = 0xFFFFFFFFu; s_lb[e] = 0xFFFFFFFFu; }       // empty slot of a dense chunk
+                else {
+                    const float est = __uint_as_float((u32)(key >> 32));
+                    const float bn = p.bn[(u32)key];
+                    float err = row_err + p.eps_half * bn + p.aq * __builtin_amdgcn_sqrtf(bn);          // >= |dot16 - dot32|
+                    if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) err = 2.0f * err;
+                    if (METRIC == NWKNN_METRIC_COSINE) err = err * 1.0001f + 2.0e-6f * (fabsf(est) + 1.0f);
+                    else err = err * 1.0001f + 2.0e-6f * (fabsf(est) + qn + bn + 1.0f);  // roundings of est and of these lines
+                    float ub = est + err;
+                    if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ub = fmaxf(ub, 0.0f);       // the canonical distance is clamped at 0
+                    u32 sub = sortable_u32(ub), slb = sortable_u32(est - err);
+                    if (METRIC == NWKNN_METRIC_COSINE && !(cosine_norm_ok(qn) && cosine_norm_ok(bn))) {
+                        sub = 0xFFC00000u; slb = 0u;                                   // no estimate for degenerate rows: [-inf, NaN rank]
+                    }
+                    s_ub[e] = sub;
+                    s_lb[e] = slb;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        u32 lo = 0u, hi = 0xFFFFFFFFu;
+        while (lo < hi) {                                   // smallest x with  #{ub <= x} >= k   (wave-uniform)
+            const u32 mid = lo + ((hi - lo) >> 1);
+            u32 c = 0;
+            for (u32 e0 = 0; e0 < end; e0 += 64) {
+                const u32 e = e0 + lane;
+                c += (u32)__popcll(__ballot(e < end && s_ub[e] <= mid));
+            }
+            if (c >= (u32)p.k) hi = mid; else lo = mid + 1u;
+        }
+        const u32 U = lo;
+        __builtin_amdgcn_wave_barrier();
+        for (u32 e0 = start; e0 < end; e0 += 64) {
+            const u32 e = e0 + lane;
+            const bool live = e < end;
+            const bool keep = live && s_lb[e] <= U;
+            const u64 mk = __ballot(keep);
+            const u32 pos = nsurv + (u32)__popcll(mk & ((1ull << lane) - 1ull));
+            __builtin_amdgcn_wave_barrier();
+            if (keep) s_ub[pos] = e;                        // s_ub is free after the bisection: it now holds the packed survivor slots
+            else if (live) list[e] = ~0ull;
+            nsurv += (u32)__popcll(mk);
+        }
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        nsurv = end - start;
+    }
+    const bool packed = p.prune && end >= (u32)p.k;
+
+    for (u32 i0 = 0; i0 < nsurv; i0 += 64) {
+        const u32 i = i0 + lane;
+        const bool live = i < nsurv;
+        const u32 e = live ? (packed ? s_ub[i] : start + i) : start;
+        const u64 old = live ? list[e] : ~0ull;
+        const bool valid = old != ~0ull;                               // dense chunks leave ~0 in the slots of padding columns
+        const u32 col = valid ? (u32)old : 0u;
+        float acc = 0.0f;
+        if (ROWS16) {
+            const _Float16* __restrict__ brow = (const _Float16*)p.bp + (long long)col * p.dp;
+            for (int k0 = 0; k0 < p.dp; k0 += 8) {
+                const f16x8 bv = *(const f16x8*)(brow + k0), qv = *(const f16x8*)(qrow16 + k0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc = __fmaf_rn((float)qv[j], (float)bv[j], acc);       // natural order: ascending k
+            }
+        } else {
+            const float* __restrict__ brow = p.bp + (long long)col * p.dp;
+            for (int k0 = 0; k0 < p.dp; k0 += 8) {
+                const f32x4 be = *(const f32x4*)(brow + k0), bo = *(const f32x4*)(brow + k0 + 4);
+                const f32x4 qe = *(const f32x4*)(qrow + k0), qo = *(const f32x4*)(qrow + k0 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                          // k = k0+2j, then k0+2j+1: ascending
+                    acc = __fmaf_rn(qe[j], be[j], acc);
+                    acc = __fmaf_rn(qo[j], bo[j], acc);
+                }
+            }
+        }
+        const float dist = distance_epilogue<METRIC>(acc, qn, p.bn[col]);
+        if (valid) list[e] = ((u64)sortable_u32(dist) << 32) | col;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// compaction: sort one query's candidate list, (optionally) drop duplicate keys, keep k, tighten tau
+//   dynamic LDS: [cap] u64 keys | [2][cap] u32 scan buffers | 16 B scratch   (one array: keeps the base 16-B aligned)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nwk_compact_kernel(const NwkCompactParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    u64* s = (u64*)dyn;
+    u32* scan0 = (u32*)(dyn + (size_t)p.cap * 8);
+    u32* scan1 = scan0 + p.cap;
+    u32* misc = scan1 + p.cap;
+
+    const int tid = threadIdx.x;
+    long long q;
+    if (p.qtile_list) q = (long long)p.qtile_list[blockIdx.x / p.qtile_rows] * p.qtile_rows + (blockIdx.x % p.qtile_rows);
+    else q = blockIdx.x;
+
+    u32 n = p.dense_count > 0 ? (u32)p.dense_count : p.cnt[q];
+    const bool overflow = n > (u32)p.cap;
+    if (overflow) n = p.cap;
+    // nothing appended since the last compaction: the list is already the sorted top-k
+    if (!overflow && !p.dedupe && p.dense_count == 0 && n <= (u32)p.k && p.tau[q] != ~0ull) return;
+
+    u32 np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    u64* list = p.buf + q * p.cap;
+    for (u32 i = tid; i < np2; i += 256) s[i] = (i < n) ? list[i] : ~0ull;
+    if (tid == 0) misc[0] = 0;
+    __syncthreads();
+    for (u32 k2 = 2; k2 <= np2; k2 <<= 1) {
+        for (u32 j = k2 >> 1; j > 0; j >>= 1) {
+            for (u32 i = tid; i < np2; i += 256) {
+                const u32 ixj = i ^ j;
+                if (ixj > i) {
+                    const u64 a = s[i], b = s[ixj];
+                    const bool up = (i & k2) == 0;
+                    if ((a > b) == up) { s[i] = b; s[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const u32 k = (u32)p.k;
+    if (p.dedupe) {
+        // a rescan can re-find entries that are already listed: keep the first occurrence of every key
+        for (u32 i = tid; i < np2; i += 256) scan0[i] = (s[i] != ~0ull && (i == 0 || s[i] != s[i - 1])) ? 1u : 0u;
+        __syncthreads();
+        u32* src = scan0;
+        u32* dst = scan1;
+        for (u32 off = 1; off < np2; off <<= 1) {                  // inclusive Hillis-Steele scan, ping-pong
+            for (u32 i = tid; i < np2; i += 256) dst[i] = src[i] + (i >= off ? src[i - off] : 0u);
+            __syncthreads();
+            u32* t = src; src = dst; dst = t;
+        }
+        const u32 nvalid = src[np2 - 1];
+        for (u32 i = tid; i < np2; i += 256) {
+            const bool keep = s[i] != ~0ull && (i == 0 || s[i] != s[i - 1]);
+            const u32 at = src[i] - 1;
+            if (keep && at < k) {
+                list[at] = s[i];
+                if (at == k - 1) p.tau[q] = s[i];
+            }
+        }
+        if (tid == 0) {
+            p.cnt[q] = nvalid < k ? nvalid : k;
+            if (p.cnt0) p.cnt0[q] = nvalid < k ? nvalid : k;
+            if (nvalid < k) p.tau[q] = ~0ull;
+        }
+    } else {
+        // sentinels (padding columns of the dense first chunk) sort last: find where they start
+        for (u32 i = tid; i < np2; i += 256)
+            if (s[i] != ~0ull && (i + 1 == np2 || s[i + 1] == ~0ull)) misc[0] = i + 1;
+        __syncthreads();
+        const u32 nvalid = misc[0];
+        const u32 keep = nvalid < k ? nvalid : k;
+        for (u32 i = tid; i < keep; i += 256) list[i] = s[i];
+        if (tid == 0) {
+            p.cnt[q] = keep;
+            if (p.cnt0) p.cnt0[q] = keep;
+            p.tau[q] = (nvalid >= k) ? s[k - 1] : ~0ull;
+        }
+    }
+    if (tid == 0 && overflow) { p.ovf[q] = 1u; atomicOr(p.ovf_any, 1u); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: keys -> (float32 distance, int64 index + offset)   (cu_knn.py:273 adds the tile offset the same way)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nwk_finalize_kernel(const u64* __restrict__ buf, const u32* __restrict__ cnt, int cap, int k,
+                                                            long long nq, long long index_offset, float* __restrict__ out_d,
+                                                            long long* __restrict__ out_i, int negate)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq * k) return;
+    const long long q = i / k;
+    const int j = (int)(i - q * k);
+    if ((u32)j < cnt[q]) {
+        const u64 key = buf[q * cap + j];
+        const float v = unsortable_f32((u32)(key >> 32));
+        out_d[i] = negate ? -v : v;                          // MaxSim ranks -score
+        out_i[i] = (long long)(u32)key + index_offset;
+    } else {
+        out_d[i] = negate ? -__builtin_inff() : __builtin_inff();
+        out_i[i] = -1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge of n_lists partial top-k lists [n_lists][Q][k_in] by (distance, index)   (merge.py:73-101)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nwk_merge_kernel(const float* __restrict__ dists, const long long* __restrict__ idx, int n_lists,
+                                                         long long nq, int k_in, int k_out, float* __restrict__ out_d,
+                                                         long long* __restrict__ out_i, int np2)
+{
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    u32* sd = (u32*)dyn;                            // sortable distance
+    long long* si = (long long*)(dyn + (size_t)np2 * 4);      // np2 is a power of two >= 2: 8-B aligned
+    const int tid = threadIdx.x;
+    const long long q = blockIdx.x;
+    const int w = n_lists * k_in;
+    for (int i = tid; i < np2; i += 256) {
+        if (i < w) {
+            const int lst = i / k_in, j = i - lst * k_in;
+            const long long at = ((long long)lst * nq + q) * k_in + j;
+            const long long id = idx[at];
+            sd[i] = id < 0 ? 0xFFFFFFFFu : sortable_u32(dists[at]);
+            si[i] = id < 0 ? 0x7FFFFFFFFFFFFFFFll : id;
+        } else { sd[i] = 0xFFFFFFFFu; si[i] = 0x7FFFFFFFFFFFFFFFll; }
+    }
+    __syncthreads();
+    for (int k2 = 2; k2 <= np2; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const u32 da = sd[i], db = sd[ixj];
+                    const long long ia = si[i], ib = si[ixj];
+                    const bool gt = (da > db) || (da == db && ia > ib);
+                    const bool up = (i & k2) == 0;
+                    if (gt == up) { sd[i] = db; sd[ixj] = da; si[i] = ib; si[ixj] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = tid; j < k_out; j += 256) {
+        const bool ok = j < np2 && si[j] != 0x7FFFFFFFFFFFFFFFll;
+        out_d[q * k_out + j] = ok ? unsortable_f32(sd[j]) : __builtin_inff();
+        out_i[q * k_out + j] = ok ? si[j] : -1;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// launchers (host side, called from nwknn_api.cpp)
+// ------------------------------------------------------------------------------------------------
+extern "C++" {
+
+hipError_t nwk_launch_rescore(hipStream_t st, const NwkRescoreParams& p, int metric, long long nq_pad)
+{
+    if (nq_pad <= 0) return hipSuccess;
+    const int waves = p.cap <= 1024 ? 4 : (p.cap <= 2048 ? 2 : 1);         // nq_pad is a multiple of 256
+    const unsigned grid = (unsigned)(nq_pad / waves);
+    const size_t lds = (size_t)waves * p.cap * 8 + 512;        // + slack: predicated-off lanes may still address past `end`
+#define NWK_RS(M)                                                                                                        \
+    do {                                                                                                                  \
+        if (p.rows16) hipLaunchKernelGGL((nwk_rescore_kernel<M, true>), dim3(grid), dim3(64 * waves), lds, st, p);        \
+        else hipLaunchKernelGGL((nwk_rescore_kernel<M, false>), dim3(grid), dim3(64 * waves), lds, st, p);                \
+    } while (0)
+    if (metric == NWKNN_METRIC_SQEUCLIDEAN) NWK_RS(NWKNN_METRIC_SQEUCLIDEAN);
+    else if (metric == NWKNN_METRIC_ONE_MINUS_DOT) NWK_RS(NWKNN_METRIC_ONE_MINUS_DOT);
+    else if (metric == NWKNN_METRIC_COSINE) NWK_RS(NWKNN_METRIC_COSINE);
+    else return hipErrorInvalidValue;
+#undef NWK_RS
+    return hipGetLastError();
+}
+
+hipError_t nwk_launch_compact(hipStream_t st, const NwkCompactParams& p, long long n_queries)
+{
+    if (n_queries <= 0) return hipSuccess;
+    const size_t lds = (size_t)p.cap * 16 + 16;
+    hipLaunchKernelGGL(nwk_compact_kernel, dim3((unsigned)n_queries), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t nwk_launch_finalize(hipStream_t st, const u64* buf, const u32* cnt, int cap, int k, long long nq, long long index_offset,
+                               float* out_d, long long* out_i, int negate)
+{
+    const long long total = nq * k;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(nwk_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, buf, cnt, cap, k, nq, index_offset,
+                       out_d, out_i, negate);
+    return hipGetLastError();
+}
+
+hipError_t nwk_launch_merge(hipStream_t st, const float* dists, const long long* idx, int n_lists, long long nq, int k_in, int k_out,
+                            float* out_d, long long* out_i)
+{
+    if (nq <= 0) return hipSuccess;
+    int np2 = 2;
+    while (np2 < n_lists * k_in) np2 <<= 1;
+    const size_t lds = (size_t)np2 * 12;
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(nwk_merge_kernel, dim3((unsigned)nq), dim3(256), lds, st, dists, idx, n_lists, nq, k_in, k_out, out_d, out_i, np2);
+    return hipGetLastError();
+}
+
+}  // extern "C++"

@@ -1,4 +1,4 @@
-// nwknn_internal.h -- shared between nwknn_kernels.hip (device + launchers) and nwknn_api.cpp (C ABI, orchestration).
+// nwknn_internal.h -- shared between the kernel files nwk_*.hip (device code + launchers) and nwknn_api.cpp (C ABI, orchestration).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
