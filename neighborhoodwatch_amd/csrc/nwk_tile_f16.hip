@@ -186,10 +186,35 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16(const NwkTileParam
 // its last phase, as in the 32x32 kernel.
 // Accumulator layout: lane l holds D[4*(l/16) + i][l%16], i = 0..3  ->  column (base row) = l%16, four consecutive query rows.
 // ------------------------------------------------------------------------------------------------
-template <int METRIC, bool DENSE, int PRE>
+// Survivor staging (SC > 0).  A survivor used to cost its quarter-wave a returning global atomic on the query's list length -- a
+// 1-3k cycle round trip, one after the other for every (column block, row) of the wave's tile that had one, with the other
+// seven waves waiting at the next barrier.  At 10M-row scale a 256 x 256 tile holds one or two survivors (3.5 % of the tile
+// kernel); on a 1M-row shard (C2, or one of eight GPUs on C3) it holds a dozen and the round trips were 10-20 %.  Now a survivor
+// goes to a small list in LDS ({key, query row of the tile}; one ds_add_rtn per ballot) and the workgroup moves the list out
+// once per strip, all lanes at once, one round trip in total (flush_survivors).  An entry that finds the LDS list full takes the
+// old direct route, so the capacity is a speed matter only.
+#define H_SC 1024                     // LDS survivor slots per workgroup (12 KiB)
+
+__device__ __forceinline__ void append_direct(const NwkTileParams& p, long long qrow, u64 key)
+{
+    const u32 pos = atomicAdd(p.cnt + qrow, 1u);
+    if (pos < (u32)p.cap) p.buf[qrow * p.cap + pos] = key;
+}
+
+// every lane of the workgroup calls this after a barrier that follows the last append; the caller resets *s_cnt behind another barrier
+__device__ __forceinline__ void flush_survivors(const NwkTileParams& p, LDS_AS const u32* s_cnt, LDS_AS const u64* s_key, LDS_AS const u32* s_row,
+                                                long long q0, int tid, int nthreads)
+{
+    u32 n = *s_cnt;
+    if (n > H_SC) n = H_SC;
+    for (u32 e = (u32)tid; e < n; e += (u32)nthreads) append_direct(p, q0 + s_row[e], s_key[e]);
+}
+
+template <int METRIC, bool DENSE, int PRE, int SC = 0>
 __device__ __forceinline__ void tile_epilogue16(const NwkTileParams& p, const f32x4 (&acc)[8][4], const float* s_qn, const u64* s_tau,
                                                 const float* s_pre, const float (&bnv)[4], const u32 (&colv)[4], const bool (&colok)[4],
-                                                const float (&cpre)[4], long long q0, int wrow0, int g, int c16)
+                                                const float (&cpre)[4], long long q0, int wrow0, int g, int c16,
+                                                LDS_AS u32* s_cnt = nullptr, LDS_AS u64* s_key = nullptr, LDS_AS u32* s_row = nullptr)
 {
     const int cap = p.cap;
 #pragma unroll
@@ -271,6 +296,21 @@ __device__ __forceinline__ void tile_epilogue16(const NwkTileParams& p, const f3
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const u64 mk = __ballot(pass[i]);
+                if (SC > 0) {
+                    if (mk) {                                        // wave-uniform: one LDS atomic for the wave's survivors of this register
+                        const int lane = (g << 4) | c16;
+                        const int leader = __ffsll((long long)mk) - 1;
+                        u32 base = 0;
+                        if (lane == leader) base = __hip_atomic_fetch_add(s_cnt, (u32)__popcll(mk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        base = __shfl(base, leader);
+                        if (pass[i]) {
+                            const u32 pos = base + (u32)__popcll(mk & ((1ull << lane) - 1ull));
+                            if (pos < (u32)SC) { s_key[pos] = key[i]; s_row[pos] = (u32)(rb + i); }
+                            else append_direct(p, q0 + rb + i, key[i]);
+                        }
+                    }
+                    continue;
+                }
                 if (mk) {                                            // wave-uniform
                     const u32 mq = (u32)(mk >> (16 * g)) & 0xFFFFu;   // this quarter-wave's survivors: all for ONE query row
                     const int leader = mq ? (__ffs(mq) - 1) : 0;
@@ -290,8 +330,12 @@ __device__ __forceinline__ void tile_epilogue16(const NwkTileParams& p, const f3
 template <int METRIC, bool DENSE, int PRE = 0>
 __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTileParams p)
 {
-    __shared__ __attribute__((aligned(16))) char smem[2 * H_STAGE + H_TM * 16];
+    constexpr int SC = DENSE ? 0 : H_SC;                        // survivor staging (dense chunks list every key in its own slot)
+    __shared__ __attribute__((aligned(16))) char smem[2 * H_STAGE + H_TM * 16 + SC * 12 + 16];
     char* const epi = smem + 2 * H_STAGE;
+    LDS_AS u64* const s_key = (LDS_AS u64*)(smem + 2 * H_STAGE + H_TM * 16);
+    LDS_AS u32* const s_row = (LDS_AS u32*)(smem + 2 * H_STAGE + H_TM * 16 + SC * 8);
+    LDS_AS u32* const s_cnt = (LDS_AS u32*)(smem + 2 * H_STAGE + H_TM * 16 + SC * 12);
 
     unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;       // dev stamps (p.dbg): see tools/stamps2.py
     if (p.dbg) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
@@ -388,6 +432,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTilePara
     if (nk > 1) issue_stage(1, 1);
     __builtin_amdgcn_sched_barrier(0);
     stage_query_side<METRIC, DENSE, PRE>(epi, H_TM, tid, my_qn, my_tau, p, q0);
+    if (SC > 0 && tid == 0) *s_cnt = 0;                  // published by the first barrier of the K loop, long before any append
     int par = 0;                                         // slab kt of the current tile lives in stage (kt & 1) ^ par
   for (int t = 0; t < n_here; ++t) {
     const long long col0 = b0 + wc * 64 + c16;
@@ -402,6 +447,15 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTilePara
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (p.dbg && t == 0) st1 = __builtin_amdgcn_s_memtime();
+    if (SC > 0 && t > 0) {                               // the staged list is past half full (early, small chunks): empty it now
+        const u32 staged = __builtin_amdgcn_readfirstlane(*s_cnt);
+        if (staged > (u32)(SC / 2)) {
+            flush_survivors(p, s_cnt, s_key, s_row, q0, tid, 512);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tid == 0) *s_cnt = 0;                    // the K loop's barriers order this before the next append
+        }
+    }
     read_A(0, par, 0, 0);
     read_B(0, par, 0);
 
@@ -453,10 +507,14 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTilePara
     asm volatile("" : "+v"(g_here));                     // out of the strip loop and live (spilled) through every K loop
     int c_here = c16;
     asm volatile("" : "+v"(c_here));
-    tile_epilogue16<METRIC, DENSE, PRE>(p, acc, (const float*)epi, (const u64*)(epi + H_TM * 4), (const float*)(epi + H_TM * 12), bnv, colv,
-                                        colok, cpre, q0, wr * 128, g_here, c_here);
+    tile_epilogue16<METRIC, DENSE, PRE, SC>(p, acc, (const float*)epi, (const u64*)(epi + H_TM * 4), (const float*)(epi + H_TM * 12), bnv, colv,
+                                            colok, cpre, q0, wr * 128, g_here, c_here, s_cnt, s_key, s_row);
   }
 #undef NWK_SPHASE
+    if (SC > 0) {                                        // end of the strip: the staged survivors go to the queries' lists
+        __syncthreads();
+        flush_survivors(p, s_cnt, s_key, s_row, q0, tid, 512);
+    }
     if (p.dbg && l == 0) {          // wave 0 writes its own stamps; every wave folds its end times in (the tile ends with its last wave)
         unsigned long long* o = p.dbg + (size_t)blockIdx.x * 8;
         const unsigned long long t3 = __builtin_amdgcn_s_memtime(), r3 = __builtin_amdgcn_s_memrealtime();
