@@ -9,6 +9,8 @@
 //   3. the survivors are packed and rescored 64 at a time: ascending-k fmaf chain over the prepared fp32 rows (the chain the
 //      fp32 MFMA accumulator performs), canonical epilogue, 64-bit key written back in place; dropped entries become ~0
 //      (the sentinel compaction already sorts last).
+#define RS_QC 1024                    // query elements staged in LDS at a time (4 KiB per wave)
+
 template <int METRIC, bool ROWS16>
 __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams p)
 {
@@ -83,6 +85,16 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
     }
     const bool packed = p.prune && end >= (u32)p.k;
 
+    // Phase 3.  A lane owns one pair and runs its chain in ascending k; what matters is how the rows arrive.  The first version
+    // fetched 32 B per lane and iteration and waited for it before its 8 FMAs (128 exposed round trips per pair, hidden only by
+    // occupancy; every 128-B line was visited by eight separate loads while 20 waves thrashed the 32 KiB L1: ~3 TB/s of rows).
+    // Now a lane takes a whole 128-B line of its row at a time (8 x 16 B back to back: one miss, seven L1 hits), the next line is
+    // requested before the current one is consumed (two register sets), and the query row -- the same for all 64 lanes -- is
+    // staged through LDS in chunks of RS_QC elements and read back as broadcasts.
+    const int ES = ROWS16 ? 2 : 4;                                      // bytes per element
+    char* const s_q = (char*)(rs_dyn + (size_t)wpb * 2 * p.cap) + (size_t)wv * RS_QC * 4;
+    const char* const qbytes = ROWS16 ? (const char*)qrow16 : (const char*)qrow;
+    const int line_elems = 128 / ES;                                    // 32 floats or 64 halves; dp is a multiple of it
     for (u32 i0 = 0; i0 < nsurv; i0 += 64) {
         const u32 i = i0 + lane;
         const bool live = i < nsurv;
@@ -90,25 +102,56 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
         const u64 old = live ? list[e] : ~0ull;
         const bool valid = old != ~0ull;                               // dense chunks leave ~0 in the slots of padding columns
         const u32 col = valid ? (u32)old : 0u;
+        const char* __restrict__ brow = (const char*)p.bp + (long long)col * p.dp * ES;
         float acc = 0.0f;
-        if (ROWS16) {
-            const _Float16* __restrict__ brow = (const _Float16*)p.bp + (long long)col * p.dp;
-            for (int k0 = 0; k0 < p.dp; k0 += 8) {
-                const f16x8 bv = *(const f16x8*)(brow + k0), qv = *(const f16x8*)(qrow16 + k0);
+        f32x4 la[8], lb[8];                                             // two lines of this lane's row
+        auto load_line = [&](f32x4 (&dst)[8], int k) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc = __fmaf_rn((float)qv[j], (float)bv[j], acc);       // natural order: ascending k
-            }
-        } else {
-            const float* __restrict__ brow = p.bp + (long long)col * p.dp;
-            for (int k0 = 0; k0 < p.dp; k0 += 8) {
-                const f32x4 be = *(const f32x4*)(brow + k0), bo = *(const f32x4*)(brow + k0 + 4);
-                const f32x4 qe = *(const f32x4*)(qrow + k0), qo = *(const f32x4*)(qrow + k0 + 4);
+            for (int j = 0; j < 8; ++j) dst[j] = *(const f32x4*)(brow + (size_t)k * ES + j * 16);
+        };
+        auto chain_line = [&](const f32x4 (&ln)[8], int kq) {           // kq: element offset inside the staged query chunk
+            if (ROWS16) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {                          // k = k0+2j, then k0+2j+1: ascending
-                    acc = __fmaf_rn(qe[j], be[j], acc);
-                    acc = __fmaf_rn(qo[j], bo[j], acc);
+                for (int j = 0; j < 8; ++j) {
+                    const f16x8 bv = __builtin_bit_cast(f16x8, ln[j]);
+                    const f16x8 qv = *(const f16x8*)(s_q + (size_t)kq * 2 + j * 16);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) acc = __fmaf_rn((float)qv[t], (float)bv[t], acc);      // natural order: ascending k
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                           // prepared layout: [k k+2 k+4 k+6 | k+1 k+3 k+5 k+7]
+                    const f32x4 be = ln[2 * j], bo = ln[2 * j + 1];
+                    const f32x4 qe = *(const f32x4*)(s_q + (size_t)kq * 4 + j * 32), qo = *(const f32x4*)(s_q + (size_t)kq * 4 + j * 32 + 16);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        acc = __fmaf_rn(qe[t], be[t], acc);
+                        acc = __fmaf_rn(qo[t], bo[t], acc);
+                    }
                 }
             }
+        };
+        for (int kc = 0; kc < p.dp; kc += RS_QC) {                      // wave-uniform; one pass for d <= 1024
+            const int n = (p.dp - kc < RS_QC) ? p.dp - kc : RS_QC;
+            const int nl = n / line_elems;                              // n is a multiple of line_elems
+            load_line(la, kc);
+            f32x4 qt[RS_QC * 4 / 1024];                                 // this chunk of the query row: <= 4 x 16 B per lane
+#pragma unroll
+            for (int j = 0; j < RS_QC * 4 / 1024; ++j)
+                if (lane * 16 + j * 1024 < n * ES) qt[j] = *(const f32x4*)(qbytes + (size_t)kc * ES + lane * 16 + j * 1024);
+            __builtin_amdgcn_wave_barrier();                            // the previous chunk has been read by every lane
+#pragma unroll
+            for (int j = 0; j < RS_QC * 4 / 1024; ++j)
+                if (lane * 16 + j * 1024 < n * ES) *(f32x4*)(s_q + lane * 16 + j * 1024) = qt[j];
+            __builtin_amdgcn_wave_barrier();
+            for (int ln = 0; ln + 2 <= nl; ln += 2) {                   // two lines per pass, the loads one line ahead of the chain
+                load_line(lb, kc + (ln + 1) * line_elems);
+                chain_line(la, ln * line_elems);
+                const int nx = (ln + 2 < nl) ? ln + 2 : nl - 1;         // past the end: a line that is there (and is not used)
+                load_line(la, kc + nx * line_elems);
+                chain_line(lb, (ln + 1) * line_elems);
+            }
+            if (nl & 1) chain_line(la, (nl - 1) * line_elems);
         }
         const float dist = distance_epilogue<METRIC>(acc, qn, p.bn[col]);
         if (valid) list[e] = ((u64)sortable_u32(dist) << 32) | col;
@@ -278,7 +321,7 @@ hipError_t nwk_launch_rescore(hipStream_t st, const NwkRescoreParams& p, int met
     if (nq_pad <= 0) return hipSuccess;
     const int waves = p.cap <= 1024 ? 4 : (p.cap <= 2048 ? 2 : 1);         // nq_pad is a multiple of 256
     const unsigned grid = (unsigned)(nq_pad / waves);
-    const size_t lds = (size_t)waves * p.cap * 8 + 512;        // + slack: predicated-off lanes may still address past `end`
+    const size_t lds = (size_t)waves * p.cap * 8 + (size_t)waves * RS_QC * 4 + 512;   // lists + staged query chunks (+ slack: predicated-off lanes may still address past `end`)
 #define NWK_RS(M)                                                                                                        \
     do {                                                                                                                  \
         if (p.rows16) hipLaunchKernelGGL((nwk_rescore_kernel<M, true>), dim3(grid), dim3(64 * waves), lds, st, p);        \
