@@ -1,0 +1,153 @@
+// nwk_f16_common.h -- shared by the fp16 tile kernels (nwk_tile_f16.hip, nwk_tile_f16p.hip): tile geometry, the filter epilogue of
+// the 16x16x32 accumulator layout and the LDS staging of survivors.
+#pragma once
+#include "nwk_device.h"
+
+#define H_TM 256
+#define H_TN 256
+#define H_BK 64                       // halves per slab = 128-B rows
+#define H_STAGE (2 * 256 * 128)       // A 32 KiB + B 32 KiB
+
+// Accumulator layout of v_mfma_f32_16x16x32_f16: lane l holds D[4*(l/16) + i][l%16], i = 0..3  ->  column (base row) = l%16,
+// four consecutive query rows; a wave's 128 x 64 tile is acc[8][4] (16-row blocks x 16-column blocks).
+// Survivor staging (SC > 0).  A survivor used to cost its quarter-wave a returning global atomic on the query's list length -- a
+// 1-3k cycle round trip, one after the other for every (column block, row) of the wave's tile that had one, with the other
+// seven waves waiting at the next barrier.  At 10M-row scale a 256 x 256 tile holds one or two survivors (3.5 % of the tile
+// kernel); on a 1M-row shard (C2, or one of eight GPUs on C3) it holds a dozen and the round trips were 10-20 %.  Now a survivor
+// goes to a small list in LDS ({key, query row of the tile}; one ds_add_rtn per ballot) and the workgroup moves the list out
+// once per strip, all lanes at once, one round trip in total (flush_survivors).  An entry that finds the LDS list full takes the
+// old direct route, so the capacity is a speed matter only.
+#define H_SC 1024                     // LDS survivor slots per workgroup (12 KiB)
+
+__device__ __forceinline__ void append_direct(const NwkTileParams& p, long long qrow, u64 key)
+{
+    const u32 pos = atomicAdd(p.cnt + qrow, 1u);
+    if (pos < (u32)p.cap) p.buf[qrow * p.cap + pos] = key;
+}
+
+// every lane of the workgroup calls this after a barrier that follows the last append; the caller resets *s_cnt behind another barrier
+__device__ __forceinline__ void flush_survivors(const NwkTileParams& p, LDS_AS const u32* s_cnt, LDS_AS const u64* s_key, LDS_AS const u32* s_row,
+                                                long long q0, int tid, int nthreads)
+{
+    u32 n = *s_cnt;
+    if (n > H_SC) n = H_SC;
+    for (u32 e = (u32)tid; e < n; e += (u32)nthreads) append_direct(p, q0 + s_row[e], s_key[e]);
+}
+
+template <int METRIC, bool DENSE, int PRE, int SC = 0>
+__device__ __forceinline__ void tile_epilogue16(const NwkTileParams& p, const f32x4 (&acc)[8][4], const float* s_qn, const u64* s_tau,
+                                                const float* s_pre, const float (&bnv)[4], const u32 (&colv)[4], const bool (&colok)[4],
+                                                const float (&cpre)[4], long long q0, int wrow0, int g, int c16,
+                                                LDS_AS u32* s_cnt = nullptr, LDS_AS u64* s_key = nullptr, LDS_AS u32* s_row = nullptr)
+{
+    const int cap = p.cap;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int rb = wrow0 + m * 16 + 4 * g;                       // this lane's four query rows: rb .. rb+3
+        if (DENSE) {
+            const f32x4 qn4 = *(const f32x4*)(s_qn + rb);
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    u32 hi;
+                    if (PRE) {                                     // exact fp16 mode: every slot carries the estimate and is rescored
+                        const float sdot = acc[m][n][i];
+                        const float est = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? __fmaf_rn(-2.0f * p.pre_inv_scale, sdot, qn4[i] + bnv[n])
+                                                                               : 1.0f - sdot * p.pre_inv_scale;
+                        hi = __float_as_uint(est);
+                    } else {
+                        const float dist = distance_epilogue<METRIC>(acc[m][n][i], qn4[i], bnv[n]);
+                        hi = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? (__float_as_uint(dist) | 0x80000000u) : sortable_u32(dist);
+                    }
+                    const long long slot = (long long)(colv[n] - (u32)p.dense_col0);
+                    p.buf[(q0 + rb + i) * cap + slot] = colok[n] ? (((u64)hi << 32) | colv[n]) : ~0ull;
+                }
+            continue;
+        }
+        const f32x4 pre4 = *(const f32x4*)(s_pre + rb);
+        bool maybe = false;
+        if (METRIC == NWKNN_METRIC_COSINE && !PRE) {
+            const f32x4 qn4 = *(const f32x4*)(s_qn + rb);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                bool mn = false;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mn |= !(distance_epilogue<METRIC>(acc[m][n][i], qn4[i], bnv[n]) > pre4[i]);
+                maybe |= mn & colok[n];
+            }
+        } else if (PRE) {
+            // pre-screen operands are finite by construction, so "some acc >= threshold" can be a running maximum of the
+            // differences (v_max3), with no per-element compare into SGPRs
+            float mx = -__builtin_inff();
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const f32x4 dlt = acc[m][n] - (pre4 + cpre[n]);
+                mx = fmaxf(fmaxf(mx, dlt[0]), dlt[1]);
+                mx = fmaxf(fmaxf(mx, dlt[2]), dlt[3]);
+            }
+            maybe = !(mx < 0.0f);
+        } else {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) maybe |= !(acc[m][n][i] < pre4[i] + cpre[n]);   // NaN falls through
+        }
+        if (!__ballot(maybe)) continue;                            // the common case: nothing in this 16 x 64 strip can survive
+        const f32x4 qn4 = *(const f32x4*)(s_qn + rb);
+        const u64x2 tl = *(const u64x2*)(s_tau + rb);
+        const u64x2 th = *(const u64x2*)(s_tau + rb + 2);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            u64 key[4];
+            bool pass[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (PRE) {                                         // see tile_epilogue: the key carries the fp16 estimate
+                    const float sdot = acc[m][n][i];                 // S * dot16 (this kernel's accumulators start at zero)
+                    const float est = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? __fmaf_rn(-2.0f * p.pre_inv_scale, sdot, qn4[i] + bnv[n])
+                                                                           : 1.0f - sdot * p.pre_inv_scale;
+                    key[i] = ((u64)__float_as_uint(est) << 32) | colv[n];
+                    pass[i] = !(acc[m][n][i] < pre4[i] + cpre[n]) & colok[n];
+                    continue;
+                }
+                const float dist = distance_epilogue<METRIC>(acc[m][n][i], qn4[i], bnv[n]);
+                const u32 sd = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? (__float_as_uint(dist) | 0x80000000u) : sortable_u32(dist);
+                key[i] = ((u64)sd << 32) | colv[n];
+                const u64 tau = (i & 2) ? th[i & 1] : tl[i & 1];
+                pass[i] = (key[i] < tau) & colok[n];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u64 mk = __ballot(pass[i]);
+                if (SC > 0) {
+                    if (mk) {                                        // wave-uniform: one LDS atomic for the wave's survivors of this register
+                        const int lane = (g << 4) | c16;
+                        const int leader = __ffsll((long long)mk) - 1;
+                        u32 base = 0;
+                        if (lane == leader) base = __hip_atomic_fetch_add(s_cnt, (u32)__popcll(mk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        base = __shfl(base, leader);
+                        if (pass[i]) {
+                            const u32 pos = base + (u32)__popcll(mk & ((1ull << lane) - 1ull));
+                            if (pos < (u32)SC) { s_key[pos] = key[i]; s_row[pos] = (u32)(rb + i); }
+                            else append_direct(p, q0 + rb + i, key[i]);
+                        }
+                    }
+                    continue;
+                }
+                if (mk) {                                            // wave-uniform
+                    const u32 mq = (u32)(mk >> (16 * g)) & 0xFFFFu;   // this quarter-wave's survivors: all for ONE query row
+                    const int leader = mq ? (__ffs(mq) - 1) : 0;
+                    u32 base = 0;
+                    if (mq && c16 == leader) base = atomicAdd(p.cnt + q0 + rb + i, (u32)__popc(mq));
+                    base = __shfl(base, leader + (g << 4));
+                    if (pass[i]) {
+                        const u32 pos = base + __popc(mq & ((1u << c16) - 1u));
+                        if (pos < (u32)cap) p.buf[(q0 + rb + i) * cap + pos] = key[i];
+                    }
+                }
+            }
+        }
+    }
+}
+

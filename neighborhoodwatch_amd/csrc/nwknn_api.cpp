@@ -95,7 +95,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = 3, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = 1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = 3, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1, opt_dev_flags = 0;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -174,6 +174,7 @@ static int create_device_objects(nwknn_ctx* h)
 }
 
 extern "C" int nwknn_destroy(nwknn_handle h);
+extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value);
 
 extern "C" int nwknn_create(nwknn_handle* out, int device)
 {
@@ -190,7 +191,23 @@ extern "C" int nwknn_create(nwknn_handle* out, int device)
     h->device = device;
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     memset(&h->stats, 0, sizeof h->stats);
-    const int rc = create_device_objects(h);
+    int rc = create_device_objects(h);
+    // NWKNN_DEFAULT_OPTS="name=value,name=value": options applied to every new handle (developers run the whole test suite against
+    // an alternative kernel build this way, e.g. f16_mfma=3); unset in production
+    if (rc == NWKNN_OK) {
+        if (const char* env = getenv("NWKNN_DEFAULT_OPTS")) {
+            std::string all(env);
+            size_t pos = 0;
+            while (rc == NWKNN_OK && pos < all.size()) {
+                const size_t end = std::min(all.find(',', pos), all.size());
+                const std::string kv = all.substr(pos, end - pos);
+                const size_t eq = kv.find('=');
+                if (eq == std::string::npos) rc = fail(NWKNN_EINVAL, "NWKNN_DEFAULT_OPTS: '%s' is not name=value", kv.c_str());
+                else rc = nwknn_set_option(h, kv.substr(0, eq).c_str(), atoll(kv.c_str() + eq + 1));
+                pos = end + 1;
+            }
+        }
+    }
     if (rc != NWKNN_OK) { (void)nwknn_destroy(h); return rc; }      // releases whatever was created; last_error keeps the cause
     *out = h;
     return NWKNN_OK;
@@ -243,10 +260,12 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
     } else if (!strcmp(name, "f16_strip")) {
         if (value < 1 || value > 64) return fail(NWKNN_EINVAL, "f16_strip must be 1..64");
         h->opt_f16_strip = value;           // base tiles a workgroup of the 16x16x32 fp16 kernel walks in a row (default 4)
+    } else if (!strcmp(name, "dev_flags")) {
+        h->opt_dev_flags = value;           // dev: experiment switches read by the kernels (0 in production)
     } else if (!strcmp(name, "pre_eps_pct")) {
         h->opt_pre_eps_pct = value;         // dev: scales the pre-screen error bound (results are only guaranteed at >= 100)
     } else if (!strcmp(name, "f16_mfma")) {
-        if (value < 0 || value > 2) return fail(NWKNN_EINVAL, "f16_mfma must be 0 (32x32x16), 1 (16x16x32) or 2 (16x16x32, two 4-wave workgroups per CU)");
+        if (value < -1 || value > 3) return fail(NWKNN_EINVAL, "f16_mfma must be -1 (auto), 0 (32x32x16), 1 (16x16x32), 2 (16x16x32, two 4-wave workgroups per CU) or 3 (16x16x32, streaming)");
         h->opt_f16_shape = value;
     } else if (!strcmp(name, "prescreen_prune")) {
         h->opt_pre_prune = value ? 1 : 0;   // dev: 0 rescoring every listed pair (A/B of the bound-based pruning)
@@ -508,8 +527,9 @@ static NwkTileParams tile_params(nwknn_ctx* h, const SearchPlan& pl, long long n
     p.n_qtiles = (int)(nq_pad / pl.tile_rows);
     p.dp = h->dp; p.cap = pl.cap;
     p.sq_shift = (int)h->opt_sq_shift;
-    p.f16_shape = (int)h->opt_f16_shape;
+    p.f16_shape = (int)h->opt_f16_shape;              // -1 (auto) is resolved in run_chunk, once the row length the kernel sees is known
     p.tiles_per_wg = (int)h->opt_f16_strip;
+    p.dev_flags = (int)h->opt_dev_flags;
     p.dbg = h->opt_dbg_ptr ? (unsigned long long*)(uintptr_t)h->opt_dbg_ptr : nullptr;
     return p;
 }
@@ -530,10 +550,15 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
 {
     NwkTileParams tp = tile_params(h, pl, nq_pad);
     const bool prescreen = pl.pre && (!dense || pl.native16);   // fp32 data: the dense first chunk runs the fp32 kernel
+    // fp16 kernel build.  Auto: the streaming form up to 2048 halves per row (+0..4 % over the burst form, it gains at tile
+    // boundaries), the burst form (one barrier per slab) beyond, where the K loop is everything and four barriers per slab cost 1.6 %
+    const int row_halves = (prescreen && pl.copies16) ? h->dp16 : h->dp;
+    const int f16_shape = h->opt_f16_shape >= 0 ? (int)h->opt_f16_shape : (row_halves <= 2048 ? 3 : 1);
+    tp.f16_shape = f16_shape;
     // rows per base tile of the kernel the launchers below will pick: 128 for the fp32 kernel and for f16_mfma=2 (256 x 128
     // tiles), 256 for the other fp16 kernels -- and for a dense pre-screened chunk whatever f16_mfma says, because
     // nwk_launch_tile_prescreen runs those on the 256-row 16x16x32 build only
-    const bool q_shape = h->opt_f16_shape == 2 && !(prescreen && dense);
+    const bool q_shape = f16_shape == 2 && !(prescreen && dense);
     const int btile = ((h->f16 || prescreen) && !q_shape) ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS;
     if (rows % btile != 0) return fail(NWKNN_EINVAL, "internal: chunk of %lld rows is not a whole number of %d-row tiles", rows, btile);
     tp.bt0 = (int)(lo / btile);

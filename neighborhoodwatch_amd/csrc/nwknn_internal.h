@@ -40,9 +40,10 @@ struct NwkTileParams {
     float pre_aq, pre_ab;          // absolute terms: pre_aq * sqrt(|b|^2) and pre_ab * sqrt(|q|^2)
     float pre_cst;
     float pre_inv_scale;           // 1 / pre_scale
-    int f16_shape;                 // fp16 kernels: 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16, 2 = 4-wave workgroups, two per CU
+    int f16_shape;                 // fp16 kernels: 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16, 2 = 4-wave workgroups, two per CU, 3 = 16x16x32 streaming form
     const float* ms_rq;            // MaxSim pre-screen: per-query and per-doc parts of the score bound
     const float* ms_cd;
+    int dev_flags;                 // dev experiments (option "dev_flags"); 0 in production
     int tiles_per_wg;              // 16x16x32 kernel: consecutive base tiles a workgroup walks (strip); the launcher turns n_btiles into strips
     int n_btiles_real;             // filled in by the launcher: base tiles of this launch
 };
@@ -97,6 +98,7 @@ hipError_t nwk_launch_gen(hipStream_t st, uint64_t seed, long long row0, long lo
 hipError_t nwk_launch_gen_f16(hipStream_t st, uint64_t seed, long long row0, long long rows, int d, void* out);
 hipError_t nwk_launch_prep_f16(hipStream_t st, const void* raw, int raw_is_f16, long long rows, int d, long long rows_pad, int dp, void* prepared, float* norms);
 hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool dense, int diag);
+hipError_t nwk_launch_tile_f16p(hipStream_t st, const NwkTileParams& p, int metric, int pre, unsigned grid);   // streaming form (f16_mfma = 3)
 hipError_t nwk_launch_prep_strided(hipStream_t st, const void* raw, int in_dtype, long long rs, long long ks, long long rows, int d,
                                    long long rows_pad, int dp, int out_f16, void* prepared, float* norms);
 hipError_t nwk_launch_prep(hipStream_t st, const float* raw, long long rows, int d, long long rows_pad, int dp, float* prepared, float* norms);

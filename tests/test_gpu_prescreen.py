@@ -172,9 +172,10 @@ def test_k_1000(pre_engine, oracle):
     _check(pre_engine, oracle, base, queries, 1000, "one_minus_dot")
 
 
-@pytest.mark.parametrize("shape_opt", [0, 1, 2])
+@pytest.mark.parametrize("shape_opt", [0, 1, 2, 3])
 def test_both_fp16_mfma_shapes(oracle, shape_opt):
-    """f16_mfma = 0: v_mfma_f32_32x32x16_f16 tiles, 1 (default): v_mfma_f32_16x16x32_f16 -- pre-screened results are the same bits;
+    """f16_mfma = 0: v_mfma_f32_32x32x16_f16 tiles, 1: v_mfma_f32_16x16x32_f16, 2: two 4-wave workgroups per CU, 3: the streaming form
+    (the default up to 2048 halves per row) -- pre-screened results are the same bits;
     on the fp16 compute path the two may differ in the last place of a distance (different summation trees inside the MFMA)."""
     from neighborhoodwatch_amd import KnnEngine
     base = oracle.gen(0x91, 0, 9000, 200)
