@@ -110,15 +110,27 @@ struct TileCoord { int qt, bt, ok; };
 
 __device__ __forceinline__ TileCoord tile_from_block(const NwkTileParams& p)
 {
-    // XCD-aware mapping: blocks b and b+8 share an XCD (and its L2); each XCD works through super-tiles of 64 tiles
-    // (SQ query tiles x SB base tiles, SQ*SB = 64, SQ = 1 << p.sq_shift) so that its co-resident workgroups share operands.
+    // XCD-aware mapping: blocks b and b+8 share an XCD (and its L2; checked: tools/xcd_map.hip); each XCD works through super-tiles
+    // of 64 tiles (SQ query tiles x SB base tiles, SQ*SB = 64, SQ = 1 << p.sq_shift) so that its co-resident workgroups share operands.
+    // In steady state the 64 (fp16: 32) resident blocks of an XCD are consecutive block numbers whose start times -- hence K
+    // positions -- are spread evenly over one tile time, and the L2 holds only the last 2-3 "slab times" of the XCD's operand
+    // stream: a slab fetched by one block is still there for the block started right behind it, not for one started eight later.
+    // So what is shared through L2 is decided by the walk order: sharers must be at most ~2 block numbers apart.  With the base
+    // tile index fastest (8 x 8) the query tile is chained through 8 consecutive blocks and the base tile is not shared at all;
+    // with the query index fastest and 2 x 32, the base tile is shared by a pair (distance 1) and the query tile by 32 blocks
+    // (distance 2): 38 % less fabric traffic on the fp32 kernel (tools/traffic_sweep.sh) -- but 0.27 % slower, and the traffic is
+    // served by the Infinity Cache either way, so 8 x 8 / base fastest stays the default (p.walk_q_fastest selects the other walk).
     const int bid = blockIdx.x;
     const int xcd = bid & 7, local = bid >> 3;
     const long long super = (long long)(local >> 6) * 8 + xcd;
     const int within = local & 63;
     const int sb_shift = 6 - p.sq_shift;
     const int sq = (int)(super / p.n_super_b), sb = (int)(super % p.n_super_b);
-    const int qi = (sq << p.sq_shift) + (within >> sb_shift), bi = (sb << sb_shift) + (within & ((1 << sb_shift) - 1));
+    int qi = (sq << p.sq_shift) + (within >> sb_shift), bi = (sb << sb_shift) + (within & ((1 << sb_shift) - 1));
+    if (p.walk_q_fastest) {
+        qi = (sq << p.sq_shift) + (within & ((1 << p.sq_shift) - 1));
+        bi = (sb << sb_shift) + (within >> p.sq_shift);
+    }
     TileCoord t;
     t.ok = (qi < p.n_qtiles) && (bi < p.n_btiles);
     t.qt = t.ok ? (p.qtile_list ? p.qtile_list[qi] : qi) : 0;

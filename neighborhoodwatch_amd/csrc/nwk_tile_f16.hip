@@ -315,14 +315,10 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16s(const NwkTilePara
     read_A(0, par, 0, 0);
     read_B(0, par, 0);
 
-    const bool xbar = __builtin_amdgcn_readfirstlane(p.dev_flags) & 1;   // dev: three extra barriers per slab (what would 4 per slab cost?)
     for (int kt = 0; kt + 1 < nk; ++kt) {
         const int cur = (kt & 1) ^ par;
-        if (xbar) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
         NWK_SPHASE(0, 0, 0, read_A(1, cur, 0, 1));
-        if (xbar) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
         NWK_SPHASE(1, 0, 1, read_A(0, cur, 1, 0); read_B(1, cur, 1));
-        if (xbar) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
         NWK_SPHASE(0, 1, 0, read_A(1, cur, 1, 1));
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();

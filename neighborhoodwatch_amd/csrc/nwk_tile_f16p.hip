@@ -72,10 +72,8 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16p(const NwkTilePara
     const int wu = __builtin_amdgcn_readfirstlane(w);
     const unsigned voff = (unsigned)((l >> 3) * dp * 2 + (((l & 7) ^ ((4 * (wu & 1) + (l >> 4)) & 7)) << 4));
     const int rowA = 128 * (wu >> 2) + 8 * (wu & 3), rowB = 8 * wu;      // + 32 j / + 64 c
-    // dev_flags & 2 (timing experiment, wrong results): every workgroup streams the SAME rows, so the whole operand stream is L2-resident
-    const bool l2hot = __builtin_amdgcn_readfirstlane(p.dev_flags) & 2;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(qp + (l2hot ? 0 : q0) * dp), 0, 0x7FFFFFFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(bp + (l2hot ? 0 : b_first) * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(qp + q0 * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(bp + b_first * dp), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bn + b_first), 0, 0x7FFFFFFF, 0x00020000);
     // the slab two ahead of the one being computed, clamped to the strip's last slab: (tile, k-slab) and its stage
     int t2 = 0, k2 = 0, st2 = 0;

@@ -95,7 +95,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = 3, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1, opt_dev_flags = 0;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -260,8 +260,9 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
     } else if (!strcmp(name, "f16_strip")) {
         if (value < 1 || value > 64) return fail(NWKNN_EINVAL, "f16_strip must be 1..64");
         h->opt_f16_strip = value;           // base tiles a workgroup of the 16x16x32 fp16 kernel walks in a row (default 4)
-    } else if (!strcmp(name, "dev_flags")) {
-        h->opt_dev_flags = value;           // dev: experiment switches read by the kernels (0 in production)
+    } else if (!strcmp(name, "super_walk_q")) {
+        if (value < -1 || value > 1) return fail(NWKNN_EINVAL, "super_walk_q must be -1 (auto), 0 (base tile index fastest) or 1 (query tile index fastest)");
+        h->opt_walk_q = value;              // walk order inside a super-tile
     } else if (!strcmp(name, "pre_eps_pct")) {
         h->opt_pre_eps_pct = value;         // dev: scales the pre-screen error bound (results are only guaranteed at >= 100)
     } else if (!strcmp(name, "f16_mfma")) {
@@ -270,7 +271,7 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
     } else if (!strcmp(name, "prescreen_prune")) {
         h->opt_pre_prune = value ? 1 : 0;   // dev: 0 rescoring every listed pair (A/B of the bound-based pruning)
     } else if (!strcmp(name, "super_q_shift")) {
-        if (value < 0 || value > 6) return fail(NWKNN_EINVAL, "super_q_shift must be 0..6");
+        if (value < -1 || value > 6) return fail(NWKNN_EINVAL, "super_q_shift must be -1 (auto) or 0..6");
         h->opt_sq_shift = value;         // super-tile of an XCD = 2^v query tiles x 2^(6-v) base tiles
     } else if (!strcmp(name, "tile_rows")) {
         if (value != 0 && value != 128 && value != 256) return fail(NWKNN_EINVAL, "tile_rows must be 0 (auto), 128 or 256");
@@ -526,10 +527,10 @@ static NwkTileParams tile_params(nwknn_ctx* h, const SearchPlan& pl, long long n
     p.nq_valid = (h->opt_diag == 32) ? 1 : h->stats.nq;   // dev diag 32: only query row 0 may list anything (timing of a filter that never fires)
     p.n_qtiles = (int)(nq_pad / pl.tile_rows);
     p.dp = h->dp; p.cap = pl.cap;
-    p.sq_shift = (int)h->opt_sq_shift;
+    p.sq_shift = h->opt_sq_shift >= 0 ? (int)h->opt_sq_shift : 3;      // auto is resolved per kernel in run_chunk
+    p.walk_q_fastest = h->opt_walk_q > 0 ? 1 : 0;
     p.f16_shape = (int)h->opt_f16_shape;              // -1 (auto) is resolved in run_chunk, once the row length the kernel sees is known
     p.tiles_per_wg = (int)h->opt_f16_strip;
-    p.dev_flags = (int)h->opt_dev_flags;
     p.dbg = h->opt_dbg_ptr ? (unsigned long long*)(uintptr_t)h->opt_dbg_ptr : nullptr;
     return p;
 }
@@ -555,6 +556,13 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
     const int row_halves = (prescreen && pl.copies16) ? h->dp16 : h->dp;
     const int f16_shape = h->opt_f16_shape >= 0 ? (int)h->opt_f16_shape : (row_halves <= 2048 ? 3 : 1);
     tp.f16_shape = f16_shape;
+    // super-tile shape and walk order (see tile_from_block).  Auto = 8 x 8 with the base tile index fastest for every kernel: it is
+    // the fastest setting measured (same-box A/B on C3: the fp32 kernel is 0.27 % faster than with 2 x 32 / query fastest, which
+    // moves 38 % fewer bytes over the fabric; the fp16 kernels are 1 % faster than with 4 x 16 / query fastest, -31 % bytes).
+    // Neither kernel is bound by that traffic (it is served by the Infinity Cache), so speed decides; options super_q_shift /
+    // super_walk_q select the lower-traffic walks.
+    if (h->opt_sq_shift < 0) tp.sq_shift = 3;
+    if (h->opt_walk_q < 0) tp.walk_q_fastest = 0;
     // rows per base tile of the kernel the launchers below will pick: 128 for the fp32 kernel and for f16_mfma=2 (256 x 128
     // tiles), 256 for the other fp16 kernels -- and for a dense pre-screened chunk whatever f16_mfma says, because
     // nwk_launch_tile_prescreen runs those on the 256-row 16x16x32 build only
@@ -895,7 +903,7 @@ static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq
     tp.tau = h->tau.as<u64>(); tp.cnt = h->cnt.as<u32>(); tp.buf = h->buf.as<u64>();
     tp.nb_valid = h->ms_docs; tp.dense_col0 = doc_lo;
     tp.n_qtiles = (int)(nq_pad / 4); tp.bt0 = (int)(doc_lo / 4); tp.n_btiles = (int)(docs / 4);
-    tp.dp = h->dp; tp.cap = cap; tp.sq_shift = (int)h->opt_sq_shift;
+    tp.dp = h->dp; tp.cap = cap; tp.sq_shift = h->opt_sq_shift >= 0 ? (int)h->opt_sq_shift : 3; tp.walk_q_fastest = h->opt_walk_q > 0 ? 1 : 0;
     const bool prescreen = pre && !dense;                // the dense first chunk runs the fp32 kernel (exact keys)
     EvPair* e = ev_begin(h, 0);
     if (prescreen) {

@@ -43,7 +43,7 @@ struct NwkTileParams {
     int f16_shape;                 // fp16 kernels: 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16, 2 = 4-wave workgroups, two per CU, 3 = 16x16x32 streaming form
     const float* ms_rq;            // MaxSim pre-screen: per-query and per-doc parts of the score bound
     const float* ms_cd;
-    int dev_flags;                 // dev experiments (option "dev_flags"); 0 in production
+    int walk_q_fastest;            // 1: inside a super-tile the QUERY tile index runs fastest (consecutive blocks share a base tile), 0: the base tile index
     int tiles_per_wg;              // 16x16x32 kernel: consecutive base tiles a workgroup walks (strip); the launcher turns n_btiles into strips
     int n_btiles_real;             // filled in by the launcher: base tiles of this launch
 };
