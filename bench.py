@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--shard", default="base", choices=["base", "queries"],
+                    help="N > 1: 'base' (default, the headline) shards the base rows and merges [Q,k] partials after one all-gather; "
+                         "'queries' replicates the base and shards the query rows (no merge; only when the base fits one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prescreen", action="store_true", help="skip the second measurement (fp16 pre-screen + fp32 rescoring)")
     ap.add_argument("--verify", action="store_true", help="compare the merged result with a single-engine search of the whole base (small workloads)")
@@ -99,10 +102,13 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option (nwknn_set_option), dev use")
     args = ap.parse_args()
 
+    # before anything initialises the HIP runtime: the host driver of this pool only supports dmabuf IPC (RCCL needs it)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     import torch
     import torch.distributed as td
     from neighborhoodwatch_amd import KnnEngine
-    from neighborhoodwatch_amd.distributed import shard_bounds, sharded_search
+    from neighborhoodwatch_amd.distributed import query_sharded_search, shard_bounds, sharded_search
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -117,8 +123,6 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
@@ -130,7 +134,8 @@ def main():
         metric = args.metric
         desc += f" [metric overridden: {metric}]"
     peak = MFMA_PEAK_TFLOPS[dtype]
-    lo, hi = shard_bounds(B, world, rank)
+    by_query = args.shard == "queries" and world > 1
+    lo, hi = (0, B) if by_query else shard_bounds(B, world, rank)
     eng = KnnEngine(dev_index, profile=True)
     for kvs in args.opt:
         for kv in kvs.split(","):
@@ -166,7 +171,10 @@ def main():
         last = None
 
         def step(record):
-            dist, idx = sharded_search(search_shard, eng.merge, queries, k, lo, None)
+            if by_query:
+                dist, idx = query_sharded_search(lambda qs, kk: search_shard(qs, kk, 0), queries, k, None)
+            else:
+                dist, idx = sharded_search(search_shard, eng.merge, queries, k, lo, None)
             if rank == 0:
                 host_d.copy_(dist, non_blocking=True)
                 host_i.copy_(idx, non_blocking=True)
@@ -207,7 +215,7 @@ def main():
         p_elapsed, p_agg, p_flops, p_ms, p_last = measure(p_steps, p_warm)
         eng.set_prescreen(False)
         if rank == 0:
-            p_ach = (p_flops / 1e12) / (p_ms / 1e3) / world if p_ms > 0 else 0.0
+            p_ach = (p_flops / 1e12) / (p_ms / 1e3) if p_ms > 0 else 0.0     # FLOPs summed over ranks / kernel time summed over ranks = per-GPU rate
             pre = {
                 "what": "same search, same bits out: fp16 MFMA pre-screen over scaled fp16 copies + canonical fp32 rescoring of every listed pair",
                 "value": Q * p_steps / p_elapsed, "unit": "queries/s", "steps": p_steps, "warmup": p_warm, "ms_per_step": p_elapsed / p_steps * 1e3,
@@ -217,7 +225,7 @@ def main():
                 "roofline": {"bound": "mfma", "achieved": p_ach, "peak": MFMA_PEAK_TFLOPS["f16"], "unit": "TFLOP/s",
                              "frac": p_ach / MFMA_PEAK_TFLOPS["f16"],
                              "kernel": "nwk_maxsim_pre_kernel" if maxsim else "nwk_tile_kernel_f16p<metric, PRE=1>",
-                             "traffic": recorded_traffic(args.workload + "_prescreen"),
+                             "traffic": recorded_traffic(args.workload + "_prescreen") if world == 1 else None,
                              "launches": max(p_agg["tile_launches"] - p_steps, 1),
                              "avg_launch_ms": p_agg["tile_ms"] / max(p_agg["tile_launches"] - p_steps, 1)},
                 "breakdown_ms_per_step": {"tile": p_agg["tile_ms"] / p_steps, "rescore": p_agg["rescore_ms"] / p_steps,
@@ -228,7 +236,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         qps = Q * args.steps / elapsed
-        achieved = (sum_flops / 1e12) / (sum_ms / 1e3) / world if sum_ms > 0 else 0.0       # per-GPU TFLOP/s of the tile kernel
+        achieved = (sum_flops / 1e12) / (sum_ms / 1e3) if sum_ms > 0 else 0.0       # per-GPU TFLOP/s of the tile kernel: both sums run over the ranks
         out = {
             "metric": "queries/sec + pairwise-dist TFLOP/s, 100k x 10M d=1024 k=100" if args.workload == "c3" else f"queries/sec ({args.workload})",
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -236,9 +244,10 @@ def main():
             "dtype": dtype, "data": "synthetic (seeded counter-based embeddings in [-1,1), generated on device)",
             "pairwise_tflops": 2.0 * Q * B * d * (32 * 64 if maxsim else 1) * args.steps / elapsed / 1e12,
             "config": {"workload": desc, "queries": Q, "base_rows": B, "dim": d, "k": k, "metric": metric,
-                       "parallelism": f"base rows sharded x{world}" + (" + RCCL all-gather of [Q,k] partials + merge" if world > 1 else "")},
+                       "parallelism": (f"query rows sharded x{world}, base replicated + RCCL all-gather of the [Q/N,k] slices" if by_query else
+                                       f"base rows sharded x{world}" + (" + RCCL all-gather of [Q,k] partials + merge" if world > 1 else ""))},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": recorded_traffic(args.workload),
+                         "frac": achieved / peak, "traffic": recorded_traffic(args.workload) if world == 1 else None,   # recorded for the 1-GPU launches only
                          "traffic_note": "bytes per launch, rocprofv3 PMC passes recorded in profiles/ (not sampled live)",
                          # one launch per search is the dense first chunk (cap/2 base rows, a different template instance in the
                          # rocprofv3 stats, ~1 ms): the per-launch figures are over the filtered launches that carry the work

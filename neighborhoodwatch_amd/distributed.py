@@ -53,3 +53,24 @@ def sharded_search(search_shard: Callable, merge: Callable, queries, k: int, sha
         return dist, idx
     gd, gi = allgather_partials(dist, idx, group)
     return merge(gd, gi, k)
+
+
+def query_sharded_search(search_all: Callable, queries, k: int, group=None):
+    """The zero-collective alternative for jobs whose base fits one GPU (C2, C3): every rank holds the WHOLE base and
+    searches its contiguous slice of the query rows (``shard_bounds`` over the queries); the slices are concatenated in rank
+    order by one all-gather -- there is nothing to merge, a query's neighbours all come from one rank.
+    search_all(queries_slice, k) -> (dist [q,k] f32 tensor, idx [q,k] i64 tensor).  Returns ([Q,k], [Q,k]) on every rank."""
+    import torch
+    import torch.distributed as td
+    if not td.is_initialized() or td.get_world_size(group) == 1:
+        return search_all(queries, k)
+    world, rank = td.get_world_size(group), td.get_rank(group)
+    nq = queries.shape[0]
+    lo, hi = shard_bounds(nq, world, rank)
+    rows = -(-nq // world)                                        # slices differ by at most one row: pad to the longest
+    dist, idx = search_all(queries[lo:hi], k)
+    pd_ = torch.zeros((rows, k), dtype=dist.dtype, device=dist.device); pd_[:hi - lo] = dist
+    pi_ = torch.zeros((rows, k), dtype=idx.dtype, device=idx.device); pi_[:hi - lo] = idx
+    gd, gi = allgather_partials(pd_, pi_, group)                  # [world, rows, k]
+    parts = [shard_bounds(nq, world, r) for r in range(world)]
+    return (torch.cat([gd[r, :b - a] for r, (a, b) in enumerate(parts)]), torch.cat([gi[r, :b - a] for r, (a, b) in enumerate(parts)]))

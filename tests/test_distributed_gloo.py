@@ -57,3 +57,37 @@ def test_two_rank_sharded_search_equals_single_shard(tmp_path, oracle):
         g = np.load(tmp_path / f"rank{r}.npz")
         assert np.array_equal(g["idx"], ri), f"rank {r}: merged ids differ from the single-shard result"
         assert np.array_equal(g["dist"].view(np.uint32), rd.view(np.uint32))
+
+
+def _worker_q(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as td
+    from neighborhoodwatch_amd.distributed import query_sharded_search
+    from oracle import cpu_oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    B, Q, d, k = 700, 23, 24, 9                                   # 23 queries over 2 ranks: slices of 11 and 12 rows
+    base = orc.gen(orc.SEED_BASE, 0, B, d)                        # every rank holds the whole base
+    queries = torch.from_numpy(orc.gen(orc.SEED_QUERY, 0, Q, d))
+
+    def search_all(qs, kk):
+        dd, ii = orc.knn_canonical(base, qs.numpy(), kk, "sqeuclidean")
+        return torch.from_numpy(dd), torch.from_numpy(ii)
+
+    dist, idx = query_sharded_search(search_all, queries, k, None)
+    np.savez(Path(out_dir) / f"qrank{rank}.npz", dist=dist.numpy(), idx=idx.numpy())
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_query_sharded_search_equals_single_rank(tmp_path, oracle):
+    world = 2
+    mp.spawn(_worker_q, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    base = oracle.gen(oracle.SEED_BASE, 0, 700, 24)
+    queries = oracle.gen(oracle.SEED_QUERY, 0, 23, 24)
+    rd, ri = oracle.knn_canonical(base, queries, 9, "sqeuclidean")
+    for r in range(world):
+        g = np.load(tmp_path / f"qrank{r}.npz")
+        assert np.array_equal(g["idx"], ri) and np.array_equal(g["dist"].view(np.uint32), rd.view(np.uint32))
