@@ -556,12 +556,13 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
     const int row_halves = (prescreen && pl.copies16) ? h->dp16 : h->dp;
     const int f16_shape = h->opt_f16_shape >= 0 ? (int)h->opt_f16_shape : (row_halves <= 2048 ? 3 : 1);
     tp.f16_shape = f16_shape;
-    // super-tile shape and walk order (see tile_from_block).  Auto = 8 x 8 with the base tile index fastest for every kernel: it is
-    // the fastest setting measured (same-box A/B on C3: the fp32 kernel is 0.27 % faster than with 2 x 32 / query fastest, which
-    // moves 38 % fewer bytes over the fabric; the fp16 kernels are 1 % faster than with 4 x 16 / query fastest, -31 % bytes).
-    // Neither kernel is bound by that traffic (it is served by the Infinity Cache), so speed decides; options super_q_shift /
-    // super_walk_q select the lower-traffic walks.
-    if (h->opt_sq_shift < 0) tp.sq_shift = 3;
+    // super-tile shape and walk order (see tile_from_block).  Auto = the fastest setting measured, base tile index fastest in both:
+    // fp32 kernel 8 x 8 (same-box A/B on C3: 0.27 % faster than 2 x 32 / query fastest, which moves 38 % fewer bytes over the
+    // fabric); fp16 kernels 16 x 4 (C3 pre-screen tile kernel: +1.4 % over 8 x 8, +0.7 % over 32 x 2; 4 x 16 / query fastest moves
+    // 31 % fewer bytes and is 1 % slower).  Neither kernel is bound by that traffic (the Infinity Cache serves it), so speed
+    // decides; options super_q_shift / super_walk_q select the other walks.
+    const bool fp32_kernel = !(h->f16 || prescreen);
+    if (h->opt_sq_shift < 0) tp.sq_shift = fp32_kernel ? 3 : 4;
     if (h->opt_walk_q < 0) tp.walk_q_fastest = 0;
     // rows per base tile of the kernel the launchers below will pick: 128 for the fp32 kernel and for f16_mfma=2 (256 x 128
     // tiles), 256 for the other fp16 kernels -- and for a dense pre-screened chunk whatever f16_mfma says, because

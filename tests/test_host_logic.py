@@ -201,3 +201,16 @@ def test_cli_keeps_the_reference_flags():
     a = build_parser().parse_args(["1", "2", "-m", "x", "--enable-memory-tuning", "--use-dataset-api", "--no-gen-hdf5", "-ods", "256",
                                    "-odt", "int8", "--data-dir", "/tmp/x", "--post-validation"])
     assert a.enable_memory_tuning and a.use_dataset_api and not a.gen_hdf5 and a.output_dimension_size == 256 and a.post_validation
+
+
+def test_engine_refuses_tensors_of_another_gpu():
+    """A CUDA tensor handed to an engine must live on the engine's GPU: the check comes before anything touches a stream, so it
+    can be exercised without a device (the engine object is made without nwknn_create)."""
+    from types import SimpleNamespace
+    from neighborhoodwatch_amd.engine import KnnEngine
+    eng = KnnEngine.__new__(KnnEngine)
+    eng.device = 0
+    eng._h = None
+    other = SimpleNamespace(device=SimpleNamespace(index=1))
+    with pytest.raises(ValueError, match="cuda:0"):
+        eng._order_after_torch(other, "queries")
