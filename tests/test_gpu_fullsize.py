@@ -89,3 +89,43 @@ def test_c3_headline_size_properties_and_sampled_parity(oracle):
     rd, ri = oracle.knn_canonical(hb, hq, k)
     assert np.array_equal(ii, ri)
     assert np.array_equal(di.view(np.uint32), rd.view(np.uint32))
+
+
+@pytest.mark.timeout(1500)
+def test_c4_per_gpu_slice_properties_and_sampled_parity(oracle):
+    """BASELINE.json config 4 as ONE of its eight GPUs sees it: fp16 inputs, 12.5M base rows (a shard of the 100M), d=1536, k=100,
+    a 20k-row slice of the 1M queries.  Exact fp16 mode: the result is the canonical fp32 arithmetic applied to the fp16 values, so
+    the sampled rows must match the CPU oracle bit for bit against the ENTIRE shard; size-independent properties for all rows."""
+    import torch
+    from neighborhoodwatch_amd import KnnEngine
+    Q, B, d, k = 20_000, 12_500_000, 1536, 100
+    offset = 37_500_000                                          # shard 3 of 8: global ids start here (+ batch_offset, cu_knn.py:273)
+    with KnnEngine(0) as eng:
+        base = eng.generate(oracle.SEED_BASE, offset, B, d, "f16")
+        queries = eng.generate(oracle.SEED_QUERY, 0, Q, d, "f16")
+        eng.set_base(base)                                       # fp16 input selects the fp16 compute path
+        dist, idx = eng.search(queries, k, index_offset=offset)
+        st = eng.stats()
+        dist2, idx2 = eng.search(queries, k, index_offset=offset)
+        probe = base[7_654_321:7_654_321 + 16].clone()
+        pd_, pi_ = eng.search(probe, 2, index_offset=offset)
+    assert st["prescreen"] == 1 and st["overflowed_queries"] == 0          # exact fp16 mode ran, no list overflowed
+    assert torch.equal(idx, idx2) and torch.equal(dist, dist2)              # deterministic
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all())                         # ascending (merge.py:104)
+    assert int(idx.min()) >= offset and int(idx.max()) < offset + B          # global ids of this shard
+    srt = torch.sort(idx, dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())                           # no duplicate neighbours
+    assert (pi_[:, 0].cpu().numpy() == offset + np.arange(7_654_321, 7_654_321 + 16)).all() and (pd_[:, 0].cpu().numpy() == 0).all()
+    rows = np.linspace(0, Q - 1, 12).astype(np.int64)
+    sel = torch.from_numpy(rows).cuda()
+    hq = queries[sel].float().cpu().numpy()
+    di, ii = dist[sel].cpu().numpy(), idx[sel].cpu().numpy()
+    del dist, idx, dist2, idx2, queries
+    hb = np.empty((B, d), dtype=np.float32)                                 # the fp16 VALUES as float32, converted on the GPU in slabs
+    step = 1_250_000
+    for s in range(0, B, step):
+        hb[s:s + step] = base[s:s + step].float().cpu().numpy()
+    del base
+    rd, ri = oracle.knn_canonical(hb, hq, k)
+    assert np.array_equal(ii, ri + offset)
+    assert np.array_equal(di.view(np.uint32), rd.view(np.uint32))

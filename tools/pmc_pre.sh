@@ -9,7 +9,7 @@ done
 python3 - <<PY
 import csv, glob, json
 out = {"workload": "$w", "path": "exact search through the fp16 pre-screen (option prescreen=1)"}
-for kern, tag in (("nwk_tile_kernel_f16s", "tile"), ("nwk_rescore_kernel", "rescore")):
+for kern, tag in (("nwk_tile_kernel_f16", "tile"), ("nwk_rescore_kernel", "rescore")):
     rec = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         f = glob.glob(f"gpurun_out/pmcpre_${w}_{c}/*/*_counter_collection.csv")[0]

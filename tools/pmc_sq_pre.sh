@@ -9,7 +9,7 @@ import csv, glob, json, collections
 f = glob.glob("gpurun_out/pmcsq_$w/*/*_counter_collection.csv")[0]
 acc = collections.defaultdict(float); ms = 0.0; n = 0; seen = set()
 for r in csv.DictReader(open(f)):
-    if "nwk_tile_kernel_f16s" in r["Kernel_Name"]:
+    if "nwk_tile_kernel_f16" in r["Kernel_Name"]:
         acc[r["Counter_Name"]] += float(r["Counter_Value"])
         key = (r["Dispatch_Id"] if "Dispatch_Id" in r else r["Start_Timestamp"])
         if key not in seen:
