@@ -1,8 +1,8 @@
 // nwk_tile_f32.hip -- fp32 distance tile + filter kernel (K1)  (gfx950 only; shared pieces and the overall design: nwk_device.h)
 #include "nwk_device.h"
 
-template <int METRIC, bool DENSE, int TM, int BKT, int DIAG = 0>
-__global__ __launch_bounds__(256, 2) void nwk_tile_kernel(const NwkTileParams p)
+template <int METRIC, bool DENSE, int TM, int BKT, int DIAG = 0, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void nwk_tile_kernel(const NwkTileParams p)
 {
     constexpr int MT = TM / 64;                   // 32-row accumulator blocks per wave
     constexpr int ROWB = BKT * 4;                 // bytes per LDS row
@@ -169,8 +169,17 @@ __global__ __launch_bounds__(256, 2) void nwk_tile_kernel(const NwkTileParams p)
 extern "C++" {
 
 template <int METRIC, int TM, int BKT>
-static hipError_t launch_tile_shape(hipStream_t st, const NwkTileParams& p, bool dense, unsigned grid, int diag)
+static hipError_t launch_tile_shape(hipStream_t st, const NwkTileParams& p, bool dense, unsigned grid, int diag, int occ)
 {
+    // <256,16>: 48 KiB of LDS per workgroup, so THREE fit a CU if the kernel stays within 168 VGPRs (it does, with 7 spilled
+    // outside the K loop): the third workgroup's MFMAs fill what the barriers, DMA issue and tile turnarounds of the other two
+    // leave idle -- C3: 144.3 -> 148.6 TF (+3.0 %, same-box A/B).  <128,32> needs 64 KiB: two per CU.
+    if constexpr (TM == 256) {
+        if (!dense && diag == 0 && occ >= 3) {
+            hipLaunchKernelGGL((nwk_tile_kernel<METRIC, false, TM, BKT, 0, 3>), dim3(grid), dim3(256), 0, st, p);
+            return hipGetLastError();
+        }
+    }
     if (dense) { hipLaunchKernelGGL((nwk_tile_kernel<METRIC, true, TM, BKT, 0>), dim3(grid), dim3(256), 0, st, p); return hipGetLastError(); }
     switch (diag) {              // dev-only timing ablations (wrong results by construction)
     case 1: hipLaunchKernelGGL((nwk_tile_kernel<METRIC, false, TM, BKT, 1>), dim3(grid), dim3(256), 0, st, p); break;
@@ -183,14 +192,14 @@ static hipError_t launch_tile_shape(hipStream_t st, const NwkTileParams& p, bool
 }
 
 template <int METRIC>
-static hipError_t launch_tile_metric(hipStream_t st, const NwkTileParams& p, bool dense, unsigned grid, int tile_rows, int diag)
+static hipError_t launch_tile_metric(hipStream_t st, const NwkTileParams& p, bool dense, unsigned grid, int tile_rows, int diag, int occ)
 {
-    if (tile_rows == 256) return launch_tile_shape<METRIC, 256, 16>(st, p, dense, grid, diag);
-    return launch_tile_shape<METRIC, 128, 32>(st, p, dense, grid, diag);
+    if (tile_rows == 256) return launch_tile_shape<METRIC, 256, 16>(st, p, dense, grid, diag, occ);
+    return launch_tile_shape<METRIC, 128, 32>(st, p, dense, grid, diag, occ);
 }
 
 // p.n_qtiles counts query tiles of `tile_rows` (128 or 256) rows; p.n_btiles counts 128-row base tiles.
-hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool dense, int tile_rows, int diag)
+hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool dense, int tile_rows, int diag, int occ)
 {
     if (p.n_qtiles <= 0 || p.n_btiles <= 0) return hipSuccess;
     if (tile_rows != 128 && tile_rows != 256) return hipErrorInvalidValue;
@@ -203,9 +212,9 @@ hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool den
     const long long grid = supers * 64;
     if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
     switch (metric) {
-    case NWKNN_METRIC_SQEUCLIDEAN: return launch_tile_metric<NWKNN_METRIC_SQEUCLIDEAN>(st, p, dense, (unsigned)grid, tile_rows, diag);
-    case NWKNN_METRIC_ONE_MINUS_DOT: return launch_tile_metric<NWKNN_METRIC_ONE_MINUS_DOT>(st, p, dense, (unsigned)grid, tile_rows, diag);
-    case NWKNN_METRIC_COSINE: return launch_tile_metric<NWKNN_METRIC_COSINE>(st, p, dense, (unsigned)grid, tile_rows, diag);
+    case NWKNN_METRIC_SQEUCLIDEAN: return launch_tile_metric<NWKNN_METRIC_SQEUCLIDEAN>(st, p, dense, (unsigned)grid, tile_rows, diag, occ);
+    case NWKNN_METRIC_ONE_MINUS_DOT: return launch_tile_metric<NWKNN_METRIC_ONE_MINUS_DOT>(st, p, dense, (unsigned)grid, tile_rows, diag, occ);
+    case NWKNN_METRIC_COSINE: return launch_tile_metric<NWKNN_METRIC_COSINE>(st, p, dense, (unsigned)grid, tile_rows, diag, occ);
     default: return hipErrorInvalidValue;
     }
 }

@@ -95,7 +95,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1, opt_tile_occ = 3;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -260,6 +260,9 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
     } else if (!strcmp(name, "f16_strip")) {
         if (value < 1 || value > 64) return fail(NWKNN_EINVAL, "f16_strip must be 1..64");
         h->opt_f16_strip = value;           // base tiles a workgroup of the 16x16x32 fp16 kernel walks in a row (default 4)
+    } else if (!strcmp(name, "tile_occ")) {
+        if (value != 2 && value != 3) return fail(NWKNN_EINVAL, "tile_occ must be 2 or 3");
+        h->opt_tile_occ = value;            // workgroups per CU of the fp32 tile kernel's 256-row shape (3: default)
     } else if (!strcmp(name, "super_walk_q")) {
         if (value < -1 || value > 1) return fail(NWKNN_EINVAL, "super_walk_q must be -1 (auto), 0 (base tile index fastest) or 1 (query tile index fastest)");
         h->opt_walk_q = value;              // walk order inside a super-tile
@@ -581,7 +584,7 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         tp.pre_scale = pl.pre_scale; tp.pre_eps_half = pl.pre_eps_half; tp.pre_aq = pl.pre_aq; tp.pre_ab = pl.pre_ab; tp.pre_cst = pl.pre_cst;
         HIPCHK(nwk_launch_tile_prescreen(h->stream, tp, metric, dense));
     } else if (h->f16) HIPCHK(nwk_launch_tile_f16(h->stream, tp, metric, dense, (int)h->opt_diag));
-    else HIPCHK(nwk_launch_tile(h->stream, tp, metric, dense, pl.tile_rows, (int)h->opt_diag));
+    else HIPCHK(nwk_launch_tile(h->stream, tp, metric, dense, pl.tile_rows, (int)h->opt_diag, (int)h->opt_tile_occ));
     ev_end(h, e);
     if (prescreen) {                                       // listed pairs -> canonical fp32 keys, in place
         if (dense) {                                       // (exact fp16 mode) every slot of the dense chunk is a candidate: [0, rows)

@@ -1,6 +1,8 @@
 """Exact fp16 mode (default on the fp16 compute path): the fp16 MFMA kernel only pre-screens; every listed pair, the dense first
 chunk included, is rescored with the fp32 ascending-k fmaf chain over the fp16 VALUES.  The result is therefore the canonical one of
 the fp32 oracle applied to the fp16-rounded inputs -- bit for bit, indices and distances -- instead of "whatever order the MFMA sums in"."""
+import os
+
 import numpy as np
 import pytest
 
@@ -103,7 +105,11 @@ def test_non_finite_fp16_inputs_and_the_legacy_switch(oracle):
     assert np.allclose(dist, ed, rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("seed", range(40))
+F16_SEED0 = int(os.environ.get("NWKNN_FUZZ_SEED0", "0"))       # one-off soaks: NWKNN_FUZZ_SEED0=1000 NWKNN_FUZZ_CASES=2000 pytest ...
+F16_CASES = int(os.environ.get("NWKNN_FUZZ_CASES", "40"))
+
+
+@pytest.mark.parametrize("seed", range(F16_SEED0, F16_SEED0 + F16_CASES))
 def test_random_cases_against_the_oracle(oracle, seed):
     from neighborhoodwatch_amd import KnnEngine
     rng = np.random.default_rng(7000 + seed)
