@@ -127,6 +127,14 @@ int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int dtype, int
 /* Same with COLUMN-major host queries (cu_knn.py:229-235 converts the query tile the same way as the base tile). */
 int nwknn_search_columns(nwknn_handle h, const void* const* columns, int64_t nq, int dtype, int32_t k, int metric,
                          int64_t index_offset, float* out_dist, int64_t* out_idx, int out_location);
+/* The same two with CHUNKED columns, as pq.read_table hands them over (cu_knn.py:112-114: a ChunkedArray per dimension, one
+ * chunk per parquet row group): chunk c of column j at chunks[c * d + j], chunk_rows[c] rows each, the same chunking for every
+ * column, sum(chunk_rows) == rows.  Nothing is concatenated on the host: the upload pipeline gathers straight from the chunks. */
+int nwknn_set_base_column_chunks(nwknn_handle h, const void* const* chunks, const int64_t* chunk_rows, int32_t n_chunks,
+                                 int64_t rows, int32_t d, int dtype);
+int nwknn_search_column_chunks(nwknn_handle h, const void* const* chunks, const int64_t* chunk_rows, int32_t n_chunks, int64_t nq,
+                               int dtype, int32_t k, int metric, int64_t index_offset, float* out_dist, int64_t* out_idx,
+                               int out_location);
 
 /* ---- merge of partial top-k lists: merge_indices_and_distances(), merge.py:56-101 ----------------------- */
 /* dists/idx: [n_lists][nq][k_in] (partial list l of query q at ((l*nq)+q)*k_in); idx < 0 marks an empty

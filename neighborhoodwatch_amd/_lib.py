@@ -27,6 +27,7 @@ EXPORTS = [
     "nwknn_version", "nwknn_last_error", "nwknn_device_count", "nwknn_mem_info", "nwknn_create", "nwknn_destroy",
     "nwknn_set_stream", "nwknn_set_option", "nwknn_get_stats", "nwknn_synchronize", "nwknn_set_base", "nwknn_search",
     "nwknn_merge", "nwknn_generate", "nwknn_set_base_columns", "nwknn_search_columns",
+    "nwknn_set_base_column_chunks", "nwknn_search_column_chunks",
     "nwknn_maxsim_set_docs", "nwknn_maxsim_search",
 ]
 
@@ -99,6 +100,9 @@ def load() -> ctypes.CDLL:
     L.nwknn_merge.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int]
     L.nwknn_set_base_columns.argtypes = [c_void_p, POINTER(c_void_p), c_int64, c_int32, c_int]
     L.nwknn_search_columns.argtypes = [c_void_p, POINTER(c_void_p), c_int64, c_int, c_int32, c_int, c_int64, c_void_p, c_void_p, c_int]
+    L.nwknn_set_base_column_chunks.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_int64), c_int32, c_int64, c_int32, c_int]
+    L.nwknn_search_column_chunks.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_int64), c_int32, c_int64, c_int, c_int32, c_int, c_int64,
+                                             c_void_p, c_void_p, c_int]
     L.nwknn_maxsim_set_docs.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int, c_int]
     L.nwknn_maxsim_search.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int, c_int, c_int32, c_int64, c_void_p, c_void_p, c_int]
     L.nwknn_generate.argtypes = [c_void_p, c_uint64, c_int64, c_int64, c_int32, c_int, c_void_p]

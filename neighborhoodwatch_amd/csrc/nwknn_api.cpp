@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "nwknn_internal.h"
@@ -68,11 +69,18 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+#define NWK_UPLOAD_THREADS 8
+
 struct EvPair { hipEvent_t a, b; int kind; };   // kind: 0 tile, 1 compact, 2 prep, 3 rescore
 
 struct nwknn_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // column upload pipeline (nwknn_set_base_columns / nwknn_search_columns): two pinned host slabs, a copy stream, four events
+    hipStream_t copy_stream = nullptr;
+    void* pin[2] = {nullptr, nullptr};
+    size_t pin_bytes = 0;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_prepped[2] = {nullptr, nullptr};
     // base shard
     DevBuf bp, bn, braw;
     long long nb = 0, nb_pad = 0;
@@ -95,7 +103,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -222,6 +230,12 @@ extern "C" int nwknn_destroy(nwknn_handle h)
                       &h->out_d, &h->out_i, &h->mrg_d, &h->mrg_i, &h->bp16, &h->qp16, &h->cnt0, &h->scal, &h->ms_rq, &h->ms_cd, &h->ms_surv, &h->ms_nsurv})
         b->release();
     for (EvPair& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (int i = 0; i < 2; ++i) {
+        if (h->pin[i]) (void)hipHostFree(h->pin[i]);
+        if (h->ev_h2d[i]) (void)hipEventDestroy(h->ev_h2d[i]);
+        if (h->ev_prepped[i]) (void)hipEventDestroy(h->ev_prepped[i]);
+    }
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -263,6 +277,9 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
     } else if (!strcmp(name, "chunk_growth")) {
         if (value < 0 || value > 7) return fail(NWKNN_EINVAL, "chunk_growth must be 0 (auto) or 1..7");
         h->opt_chunk_growth = value;        // a filtered chunk holds up to chunk_growth x the rows seen so far (1: chunks double)
+    } else if (!strcmp(name, "upload_threads")) {
+        if (value < 1 || value > 64) return fail(NWKNN_EINVAL, "upload_threads must be 1..64");
+        h->opt_upload_threads = value;      // host threads that gather column slabs into the pinned upload buffers
     } else if (!strcmp(name, "tile_occ")) {
         if (value != 2 && value != 3) return fail(NWKNN_EINVAL, "tile_occ must be 2 or 3");
         h->opt_tile_occ = value;            // workgroups per CU of the fp32 tile kernel's 256-row shape (3: default)
@@ -343,31 +360,112 @@ static int stage_and_prep(nwknn_ctx* h, const void* src, int location, int in_f1
 
 // Column-major host input (one pointer per dimension, as parquet/arrow hold embeddings): each slab of rows is staged as
 // [d][slab_rows] by d plain copies (no host-side transpose) and the strided prep kernel writes the prepared layout.
-static int stage_and_prep_columns(nwknn_ctx* h, const void* const* columns, int in_dtype, int out_f16, long long rows, int d, long long rows_pad,
+// Column-major host data as the caller holds it: chunk c of column j at chunks[c * d + j], chunk_rows[c] rows each, the same chunking
+// for every column (a pyarrow ChunkedArray per dimension has one chunk per parquet row group; a plain array is one chunk).
+struct ColumnSource {
+    const void* const* chunks;
+    const int64_t* chunk_rows;
+    int n_chunks;
+};
+
+// Column-major host data (one array per dimension: what parquet / arrow hold) -> prepared layout, as a three-stage pipeline:
+//   host threads copy a slab of every column into a PINNED buffer (the arrow buffers are pageable: a plain hipMemcpy of them
+//   stages through the driver's own bounce buffers at ~11 GB/s)  ->  one H2D copy of the whole slab on a copy stream
+//   ->  the strided layout kernel on the compute stream.  Two pinned slabs and two device slabs: slab s+1 is gathered and copied
+//   while slab s is laid out.  C2's base (1M x 768 float32 columns = 3.07 GB): 0.28 s -> see DESIGN.md section 6.
+#define NWK_UPLOAD_SLAB_BYTES (128ull << 20)
+
+static int ensure_upload_pipeline(nwknn_ctx* h, size_t slab_bytes)
+{
+    if (!h->copy_stream) HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        if (!h->ev_h2d[i]) HIPCHK(hipEventCreateWithFlags(&h->ev_h2d[i], hipEventDisableTiming));
+        if (!h->ev_prepped[i]) HIPCHK(hipEventCreateWithFlags(&h->ev_prepped[i], hipEventDisableTiming));
+    }
+    if (h->pin_bytes < slab_bytes) {
+        for (int i = 0; i < 2; ++i) {
+            if (h->pin[i]) { (void)hipHostFree(h->pin[i]); h->pin[i] = nullptr; }
+            hipError_t e = hipHostMalloc(&h->pin[i], slab_bytes, hipHostMallocDefault);
+            if (e != hipSuccess) { h->pin[i] = nullptr; h->pin_bytes = 0; return fail(NWKNN_ENOMEM, "hipHostMalloc(%zu bytes) failed: %s", slab_bytes, hipGetErrorString(e)); }
+        }
+        h->pin_bytes = slab_bytes;
+    }
+    return NWKNN_OK;
+}
+
+static int stage_and_prep_columns(nwknn_ctx* h, const ColumnSource& src, int in_dtype, int out_f16, long long rows, int d, long long rows_pad,
                                   int dp, DevBuf& raw, void* dst, float* norms)
 {
     const size_t in_es = in_dtype == NWKNN_DTYPE_F64 ? 8 : (in_dtype == NWKNN_DTYPE_F16 ? 2 : 4), out_es = out_f16 ? 2 : 4;
     if (in_dtype == NWKNN_DTYPE_F16 && !out_f16) return fail(NWKNN_EINVAL, "fp16 columns need the fp16 compute path");
-    for (int j = 0; j < d; ++j)
-        if (!columns[j]) return fail(NWKNN_EINVAL, "column %d is a null pointer", j);
-    // 1 GiB staging slabs: one plain copy per dimension and slab, so bigger slabs mean fewer, larger copies (C2: 2 304 copies of 1.3 MB
-    // instead of 9 216 of 0.34 MB: the per-call cost was a third of the upload time)
-    const long long slab_rows = std::max<long long>(256, ((1024ll << 20) / ((long long)d * (long long)in_es)) / 256 * 256);
-    const long long stage_rows = std::min(slab_rows, std::max<long long>(rows, 1));
-    RCCHK(raw.ensure((size_t)stage_rows * d * in_es));
-    for (long long r0 = 0; r0 < rows_pad; r0 += slab_rows) {
+    if (src.n_chunks <= 0 || !src.chunks || !src.chunk_rows) return fail(NWKNN_EINVAL, "column table: no chunks");
+    std::vector<long long> chunk_start((size_t)src.n_chunks + 1, 0);
+    for (int c = 0; c < src.n_chunks; ++c) {
+        if (src.chunk_rows[c] < 0) return fail(NWKNN_EINVAL, "column chunk %d has %lld rows", c, (long long)src.chunk_rows[c]);
+        chunk_start[c + 1] = chunk_start[c] + src.chunk_rows[c];
+        for (int j = 0; j < d; ++j)
+            if (src.chunk_rows[c] > 0 && !src.chunks[(size_t)c * d + j]) return fail(NWKNN_EINVAL, "column %d, chunk %d is a null pointer", j, c);
+    }
+    if (chunk_start[src.n_chunks] != rows) return fail(NWKNN_EINVAL, "column chunks hold %lld rows, expected %lld", chunk_start[src.n_chunks], rows);
+    // slab = as many rows (a multiple of 256) as fit NWK_UPLOAD_SLAB_BYTES with all d columns
+    const long long slab_rows = std::max<long long>(256, (long long)(NWK_UPLOAD_SLAB_BYTES / ((size_t)d * in_es)) / 256 * 256);
+    const long long stage_rows = std::min(slab_rows, round_up(std::max<long long>(rows, 1), 256));
+    const size_t slab_bytes = (size_t)stage_rows * d * in_es;
+    RCCHK(raw.ensure(2 * slab_bytes));
+    RCCHK(ensure_upload_pipeline(h, slab_bytes));
+    // whatever the compute stream still does with the device slabs (a previous call's layout kernel) must finish first
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int s = 0;
+    for (long long r0 = 0; r0 < rows_pad; r0 += slab_rows, ++s) {
+        const int b = s & 1;
         const long long pad_here = std::min(slab_rows, rows_pad - r0);
         const long long real_here = std::max<long long>(0, std::min(slab_rows, rows - r0));
-        if (real_here > 0)
-            for (int j = 0; j < d; ++j)
-                HIPCHK(hipMemcpyAsync((char*)raw.p + (size_t)j * stage_rows * in_es, (const char*)columns[j] + (size_t)r0 * in_es,
-                                      (size_t)real_here * in_es, hipMemcpyHostToDevice, h->stream));
+        char* dev_slab = (char*)raw.p + (size_t)b * slab_bytes;
+        if (real_here > 0) {
+            if (s >= 2) HIPCHK(hipEventSynchronize(h->ev_h2d[b]));            // the copy of slab s-2 has left this pinned buffer
+            {   // gather: column j of the slab at offset j * stage_rows (the layout kernel's row stride 1, column stride stage_rows)
+                char* pin = (char*)h->pin[b];
+                const size_t seg = (size_t)real_here * in_es;
+                const int nt = (int)std::min<long long>(h->opt_upload_threads, std::max<long long>(1, (long long)((size_t)d * seg >> 22)));   // >= 4 MiB per thread
+                // rows [r0, r0 + real_here) of column j: the pieces of the chunks that overlap the slab, in row order
+                int c0 = 0;
+                while (chunk_start[c0 + 1] <= r0) ++c0;
+                auto work = [&](int t) {
+                    for (int j = t; j < d; j += nt) {
+                        char* out = pin + (size_t)j * stage_rows * in_es;
+                        long long r = r0;
+                        for (int c = c0; r < r0 + real_here; ++c) {
+                            const long long take = std::min(chunk_start[c + 1], r0 + real_here) - r;
+                            if (take > 0) {
+                                memcpy(out + (size_t)(r - r0) * in_es, (const char*)src.chunks[(size_t)c * d + j] + (size_t)(r - chunk_start[c]) * in_es,
+                                       (size_t)take * in_es);
+                                r += take;
+                            }
+                        }
+                    }
+                };
+                (void)seg;
+                if (nt <= 1) work(0);
+                else {
+                    std::vector<std::thread> pool;
+                    pool.reserve(nt - 1);
+                    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+                    work(0);
+                    for (auto& th : pool) th.join();
+                }
+            }
+            if (s >= 2) HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_prepped[b], 0));   // the layout kernel of slab s-2 has read this device slab
+            HIPCHK(hipMemcpyAsync(dev_slab, h->pin[b], slab_bytes, hipMemcpyHostToDevice, h->copy_stream));
+            HIPCHK(hipEventRecord(h->ev_h2d[b], h->copy_stream));
+            HIPCHK(hipStreamWaitEvent(h->stream, h->ev_h2d[b], 0));
+        }
         EvPair* e = ev_begin(h, 2);
-        HIPCHK(nwk_launch_prep_strided(h->stream, raw.p, in_dtype, 1, stage_rows, real_here, d, pad_here, dp, out_f16,
+        HIPCHK(nwk_launch_prep_strided(h->stream, dev_slab, in_dtype, 1, stage_rows, real_here, d, pad_here, dp, out_f16,
                                        (char*)dst + (size_t)r0 * dp * out_es, norms + r0));
         ev_end(h, e);
-        HIPCHK(hipStreamSynchronize(h->stream));    // the staging slab is reused by the next copies
+        HIPCHK(hipEventRecord(h->ev_prepped[b], h->stream));
     }
+    HIPCHK(hipStreamSynchronize(h->stream));        // the caller may reuse its columns, and the device slabs, right away
     return NWKNN_OK;
 }
 
@@ -423,7 +521,7 @@ static int ensure_base_copy(nwknn_ctx* h, int kind)
     return NWKNN_OK;
 }
 
-static int set_base_common(nwknn_ctx* h, const void* base, const void* const* columns, int64_t rows, int32_t d, int dtype, int location)
+static int set_base_common(nwknn_ctx* h, const void* base, const ColumnSource* columns, int64_t rows, int32_t d, int dtype, int location)
 {
     if (!h || (!base && !columns)) return fail(NWKNN_EINVAL, "nwknn_set_base: null handle or base pointer");
     const bool cols = columns != nullptr;
@@ -440,7 +538,7 @@ static int set_base_common(nwknn_ctx* h, const void* base, const void* const* co
     RCCHK(h->bp.ensure((size_t)rows_pad * dp * (f16 ? 2 : 4)));
     RCCHK(h->bn.ensure((size_t)rows_pad * 4));
     h->ev_used = 0;
-    if (cols) RCCHK(stage_and_prep_columns(h, columns, dtype, f16, rows, d, rows_pad, dp, h->braw, h->bp.p, h->bn.as<float>()));
+    if (cols) RCCHK(stage_and_prep_columns(h, *columns, dtype, f16, rows, d, rows_pad, dp, h->braw, h->bp.p, h->bn.as<float>()));
     else RCCHK(stage_and_prep(h, base, location, dtype == NWKNN_DTYPE_F16, f16, rows, d, rows_pad, dp, h->braw, h->bp.p, h->bn.as<float>()));
     h->nb = rows; h->nb_pad = rows_pad; h->d = d; h->dp = dp; h->f16 = f16; h->ms_docs = 0;
     h->pre_ok = 0;
@@ -483,7 +581,17 @@ extern "C" int nwknn_set_base(nwknn_handle h, const void* base, int64_t rows, in
 extern "C" int nwknn_set_base_columns(nwknn_handle h, const void* const* columns, int64_t rows, int32_t d, int dtype)
 {
     if (!columns) return fail(NWKNN_EINVAL, "nwknn_set_base_columns: null column table");
-    return set_base_common(h, nullptr, columns, rows, d, dtype, NWKNN_HOST);
+    const int64_t one = rows;
+    const ColumnSource src{columns, &one, 1};
+    return set_base_common(h, nullptr, &src, rows, d, dtype, NWKNN_HOST);
+}
+
+extern "C" int nwknn_set_base_column_chunks(nwknn_handle h, const void* const* chunks, const int64_t* chunk_rows, int32_t n_chunks, int64_t rows,
+                                            int32_t d, int dtype)
+{
+    if (!chunks || !chunk_rows || n_chunks <= 0) return fail(NWKNN_EINVAL, "nwknn_set_base_column_chunks: null or empty chunk table");
+    const ColumnSource src{chunks, chunk_rows, n_chunks};
+    return set_base_common(h, nullptr, &src, rows, d, dtype, NWKNN_HOST);
 }
 
 // ---- search -----------------------------------------------------------------------------------------
@@ -680,7 +788,7 @@ static int repair(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long lo
     return NWKNN_OK;
 }
 
-static int search_common(nwknn_ctx* h, const void* queries, const void* const* qcolumns, int64_t nq, int dtype, int location, int32_t k, int metric,
+static int search_common(nwknn_ctx* h, const void* queries, const ColumnSource* qcolumns, int64_t nq, int dtype, int location, int32_t k, int metric,
                          int64_t index_offset, float* out_dist, int64_t* out_idx, int out_location)
 {
     if (!h || (!queries && !qcolumns) || !out_dist || !out_idx) return fail(NWKNN_EINVAL, "nwknn_search: null argument");
@@ -716,7 +824,7 @@ static int search_common(nwknn_ctx* h, const void* queries, const void* const* q
     h->ev_used = 0;
     if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_begin, h->stream));
 
-    if (qcolumns) RCCHK(stage_and_prep_columns(h, qcolumns, dtype, h->f16, nq, h->d, nq_pad, h->dp, h->qraw, h->qp.p, h->qn.as<float>()));
+    if (qcolumns) RCCHK(stage_and_prep_columns(h, *qcolumns, dtype, h->f16, nq, h->d, nq_pad, h->dp, h->qraw, h->qp.p, h->qn.as<float>()));
     else RCCHK(stage_and_prep(h, queries, location, dtype == NWKNN_DTYPE_F16, h->f16, nq, h->d, nq_pad, h->dp, h->qraw, h->qp.p, h->qn.as<float>()));
     if (pre) {
         // scaled fp16 copy of the prepared queries and the constants of the error bound (DESIGN.md "pre-screen bound")
@@ -849,7 +957,17 @@ extern "C" int nwknn_search_columns(nwknn_handle h, const void* const* columns, 
                                     float* out_dist, int64_t* out_idx, int out_location)
 {
     if (!columns) return fail(NWKNN_EINVAL, "nwknn_search_columns: null column table");
-    return search_common(h, nullptr, columns, nq, dtype, NWKNN_HOST, k, metric, index_offset, out_dist, out_idx, out_location);
+    const int64_t one = nq;
+    const ColumnSource src{columns, &one, 1};
+    return search_common(h, nullptr, &src, nq, dtype, NWKNN_HOST, k, metric, index_offset, out_dist, out_idx, out_location);
+}
+
+extern "C" int nwknn_search_column_chunks(nwknn_handle h, const void* const* chunks, const int64_t* chunk_rows, int32_t n_chunks, int64_t nq, int dtype,
+                                          int32_t k, int metric, int64_t index_offset, float* out_dist, int64_t* out_idx, int out_location)
+{
+    if (!chunks || !chunk_rows || n_chunks <= 0) return fail(NWKNN_EINVAL, "nwknn_search_column_chunks: null or empty chunk table");
+    const ColumnSource src{chunks, chunk_rows, n_chunks};
+    return search_common(h, nullptr, &src, nq, dtype, NWKNN_HOST, k, metric, index_offset, out_dist, out_idx, out_location);
 }
 
 // ---- MaxSim late interaction (new: BASELINE config 5; the reference's `ck` is flat token kNN) ----------------

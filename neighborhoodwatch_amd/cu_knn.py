@@ -113,17 +113,23 @@ def table_to_matrix(table) -> np.ndarray:
 
 
 def table_columns(table):
-    """The float columns of an arrow table as a list of 1-D numpy arrays, zero-copy where arrow allows it (a sliced,
-    single-chunk column).  This is all the host does to a tile: the column -> row-major conversion the reference performs
-    on the GPU per tile (cu_knn.py:205-211,229-235) happens inside the engine's layout kernel, which reads the columns."""
+    """The float columns of an arrow table as zero-copy numpy views: a 1-D array per column, or -- when the table is chunked
+    (pq.read_table yields one chunk per parquet row group) -- a list of 1-D arrays per column, which the engine's upload
+    pipeline gathers from directly.  This is all the host does to a tile: nothing is concatenated or transposed; the column ->
+    row-major conversion the reference performs on the GPU per tile (cu_knn.py:205-211,229-235) happens inside the engine's
+    layout kernel, which reads the columns."""
     fields = [f for f in table.schema if pa.types.is_float32(f.type) or pa.types.is_float64(f.type) or pa.types.is_float16(f.type)]
     kinds = {str(f.type) for f in fields}
     cols = []
     for f in fields:
         col = table.column(f.name)
-        arr = col.chunk(0) if col.num_chunks == 1 else col.combine_chunks()
-        a = arr.to_numpy(zero_copy_only=False)
-        cols.append(a if len(kinds) == 1 else a.astype(np.float32))
+        chunks = [ch.to_numpy(zero_copy_only=False) for ch in col.chunks if len(ch) > 0]
+        if len(kinds) != 1:
+            chunks = [a.astype(np.float32) for a in chunks]
+        cols.append(chunks[0] if len(chunks) == 1 else chunks)
+    shapes = {tuple(len(a) for a in c) if isinstance(c, list) else (len(c),) for c in cols}
+    if len(shapes) > 1:                                          # columns chunked differently (concatenated tables): one array each
+        cols = [np.concatenate(c) if isinstance(c, list) else c for c in cols]
     return cols
 
 

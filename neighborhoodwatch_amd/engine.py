@@ -133,38 +133,41 @@ class KnnEngine:
     # -- column-major input (what parquet / arrow hold: one array per dimension) ------------------------------
     @staticmethod
     def _columns(columns, what: str):
-        """-> (ctypes pointer table, rows, dim, dtype id, keepalive list).  Every column: 1-D, contiguous, same length and
-        dtype (float32 | float64 | float16)."""
-        cols = [np.asarray(c) for c in columns]
+        """-> (ctypes pointer table [chunk][dim], ctypes int64 rows per chunk, n_chunks, rows, dim, dtype id, keepalive list).
+        Every column is a 1-D array, or a list of 1-D arrays (the chunks of a pyarrow ChunkedArray: one per parquet row group);
+        all columns share one dtype (float32 | float64 | float16) and one chunking.  Nothing is concatenated here."""
+        cols = [[np.asarray(x) for x in c] if isinstance(c, (list, tuple)) else [np.asarray(c)] for c in columns]
         if not cols:
             raise ValueError(f"{what}: no columns")
-        dt = cols[0].dtype
+        dt = cols[0][0].dtype if cols[0] else np.dtype(np.float32)
         if dt not in (np.float32, np.float64, np.float16):
-            cols = [c.astype(np.float32) for c in cols]
+            cols = [[x.astype(np.float32) for x in c] for c in cols]
             dt = np.dtype(np.float32)
-        rows = cols[0].shape[0]
+        chunk_rows = [x.shape[0] for x in cols[0]]
         keep = []
         for j, c in enumerate(cols):
-            if c.ndim != 1 or c.shape[0] != rows or c.dtype != dt:
-                raise ValueError(f"{what}: column {j} has shape {c.shape} / dtype {c.dtype}, expected ({rows},) / {dt}")
-            keep.append(np.ascontiguousarray(c))
-        table = (ctypes.c_void_p * len(keep))(*[c.ctypes.data for c in keep])
+            if [x.shape[0] for x in c] != chunk_rows or any(x.ndim != 1 or x.dtype != dt for x in c):
+                raise ValueError(f"{what}: column {j} has chunks {[(x.shape, str(x.dtype)) for x in c]}, expected rows {chunk_rows} of {dt}")
+            keep.append([np.ascontiguousarray(x) for x in c])
+        n_chunks, dim = len(chunk_rows), len(keep)
+        table = (ctypes.c_void_p * (n_chunks * dim))(*[keep[j][c].ctypes.data for c in range(n_chunks) for j in range(dim)])
+        rows_arr = (ctypes.c_int64 * n_chunks)(*chunk_rows)
         ident = {np.dtype(np.float32): DTYPE_F32, np.dtype(np.float64): DTYPE_F64, np.dtype(np.float16): DTYPE_F16}[np.dtype(dt)]
-        return table, rows, len(keep), ident, keep
+        return table, rows_arr, n_chunks, int(sum(chunk_rows)), dim, ident, keep
 
     def set_base_columns(self, columns) -> None:
-        """Base shard from per-dimension host arrays: no row-major copy is made on the host or the device
-        (the job of ``cp.from_dlpack(df.to_dlpack()).copy(order='C')``, cu_knn.py:211)."""
-        table, rows, dim, dt, keep = self._columns(columns, "dataset")
+        """Base shard from per-dimension host arrays (or lists of chunks): no row-major copy and no concatenation is made on the
+        host or the device (the job of ``cp.from_dlpack(df.to_dlpack()).copy(order='C')``, cu_knn.py:211)."""
+        table, rows_arr, n_chunks, rows, dim, dt, keep = self._columns(columns, "dataset")
         if rows == 0:
             raise ValueError("dataset is empty")
-        check(self._L.nwknn_set_base_columns(self._h, table, rows, dim, dt), "nwknn_set_base_columns")
+        check(self._L.nwknn_set_base_column_chunks(self._h, table, rows_arr, n_chunks, rows, dim, dt), "nwknn_set_base_column_chunks")
         self.rows, self.dim = rows, dim
         del keep
 
     def search_columns(self, columns, k: int, metric: str = "sqeuclidean", index_offset: int = 0):
         metric = resolve_metric(metric)
-        table, nq, dim, dt, keep = self._columns(columns, "queries")
+        table, rows_arr, n_chunks, nq, dim, dt, keep = self._columns(columns, "queries")
         if self.rows == 0:
             raise _lib.NwknnError("search before set_base")
         if dim != self.dim:
@@ -175,8 +178,8 @@ class KnnEngine:
             raise ValueError("queries are empty")
         od = np.empty((nq, k), dtype=np.float32)
         oi = np.empty((nq, k), dtype=np.int64)
-        check(self._L.nwknn_search_columns(self._h, table, nq, dt, int(k), METRIC_IDS[metric], int(index_offset),
-                                           ctypes.c_void_p(od.ctypes.data), ctypes.c_void_p(oi.ctypes.data), HOST), "nwknn_search_columns")
+        check(self._L.nwknn_search_column_chunks(self._h, table, rows_arr, n_chunks, nq, dt, int(k), METRIC_IDS[metric], int(index_offset),
+                                                 ctypes.c_void_p(od.ctypes.data), ctypes.c_void_p(oi.ctypes.data), HOST), "nwknn_search_column_chunks")
         del keep
         return od, oi
 

@@ -269,6 +269,23 @@ def test_column_major_input_equals_row_major(engine, oracle):
         engine.set_base_columns([base[:, 0], base[:10, 1]])
 
 
+def test_chunked_columns_equal_plain_columns(engine, oracle):
+    """Columns handed over as lists of chunks (pq.read_table: one chunk per row group) go through the upload pipeline without
+    being concatenated; upload slabs straddle chunk boundaries (128 MiB slabs of 600 float64 columns hold 27 904 rows, the
+    chunks here 20 000 / 1 / 15 000 / 7 / 4 992) and the result is that of the plain arrays, bit for bit."""
+    B, Q, d, k = 40_000, 300, 600, 10
+    base, queries = oracle.gen(0xC1, 0, B, d), oracle.gen(0xC2, 0, Q, d)
+    cuts = [0, 20_000, 20_001, 35_001, 35_008, B]
+    bcols = [[base[a:b, j].astype(np.float64) for a, b in zip(cuts[:-1], cuts[1:])] for j in range(d)]
+    qcols = [[np.ascontiguousarray(queries[:100, j]), np.ascontiguousarray(queries[100:, j])] for j in range(d)]
+    engine.set_base_columns(bcols)
+    dist, idx = engine.search_columns(qcols, k)
+    rd, ri = oracle.knn_canonical(base, queries, k)
+    assert np.array_equal(idx, ri) and _same_bits(dist, rd)
+    with pytest.raises(ValueError):
+        engine.set_base_columns([[base[:10, 0], base[10:30, 0]], [base[:15, 1], base[15:30, 1]]])     # different chunking per column
+
+
 def test_merge_folds_more_than_4096_entries(engine, oracle):
     """8 shards x k=1000 (BASELINE config 5 on 8 GPUs) exceeds one LDS sort: folded in groups, same result; torch and numpy."""
     import torch

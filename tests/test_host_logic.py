@@ -214,3 +214,21 @@ def test_engine_refuses_tensors_of_another_gpu():
     other = SimpleNamespace(device=SimpleNamespace(index=1))
     with pytest.raises(ValueError, match="cuda:0"):
         eng._order_after_torch(other, "queries")
+
+
+def test_table_columns_hands_over_chunks_without_copying(tmp_path):
+    """pq.read_table yields one chunk per parquet row group: table_columns returns the chunks as zero-copy views (a list per
+    column), not a concatenation; a single-chunk table gives plain arrays; differently chunked columns are concatenated."""
+    f = synth.write_source_parquet(str(tmp_path / "m_8_base_vector_data_50.parquet"), 5, 50, 8, chunk_rows=16)
+    t = cu_knn.prep_table(str(tmp_path), "m", "m_8_base_vector_data_50.parquet", 50, 8)
+    cols = cu_knn.table_columns(t)
+    assert len(cols) == 8 and all(isinstance(c, list) and [len(a) for a in c] == [16, 16, 16, 2] for c in cols)
+    ref = synth.gen_rows(5, 0, 50, 8)
+    assert all(np.array_equal(np.concatenate(cols[j]), ref[:, j]) for j in range(8))
+    assert not cols[0][0].flags["OWNDATA"]                                   # a view of the arrow buffer
+    one = cu_knn.table_columns(t.slice(3, 9))                                # inside the first row group: one chunk
+    assert all(isinstance(c, np.ndarray) and np.array_equal(c, ref[3:12, j]) for j, c in enumerate(one))
+    mixed = pa.table({"embedding_0": pa.chunked_array([[1.0, 2.0], [3.0]], type=pa.float32()),
+                      "embedding_1": pa.chunked_array([[4.0], [5.0, 6.0]], type=pa.float32())})
+    m = cu_knn.table_columns(mixed)
+    assert all(isinstance(c, np.ndarray) for c in m) and m[1].tolist() == [4.0, 5.0, 6.0]
