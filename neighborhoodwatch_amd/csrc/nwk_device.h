@@ -9,13 +9,14 @@
 //   neighborhoodwatch/merge.py:73-101     [Q,2k] argsort fold of partial lists  (merge kernel)
 //
 // Design (DESIGN.md has the full story):
-//   * distance tile = f32 MFMA GEMM (v_mfma_f32_32x32x2_f32): 128 queries x 128 base rows per workgroup,
-//     K streamed in 32-wide slabs through double-buffered LDS filled by LDS-DMA (global_load_lds_dwordx4).
-//     One accumulator carries the whole K loop in ascending k, so every dot product is bit-for-bit the
-//     k-ordered fmaf chain of oracle/nwknn_oracle.c.
+//   * distance tile = f32 MFMA GEMM (v_mfma_f32_32x32x2_f32): 256 (or 128) queries x 128 base rows per workgroup, three (two)
+//     workgroups per CU, K streamed in 16- (32-)float slabs through double-buffered LDS filled by LDS-DMA
+//     (buffer_load_dwordx4 ... lds).  One accumulator carries the whole K loop in ascending k, so every dot product is
+//     bit-for-bit the k-ordered fmaf chain of oracle/nwknn_oracle.c.
 //   * the Q x B distance matrix never exists: the epilogue turns each accumulator into a 64-bit key
 //     (sortable(distance) << 32 | base row) and keeps only keys below the query's current k-th key (tau);
-//     survivors are appended to a per-query candidate list with half-wave aggregated atomics.
+//     survivors are appended to a per-query candidate list (fp32 kernel: half-wave aggregated atomics; fp16 kernels: staged in an
+//     LDS list and moved out once per strip).
 //   * a compaction kernel sorts each query's list (bitonic, LDS), keeps k, and tightens tau; the host walks the
 //     base in geometrically growing chunks so that tau is already tight when the big chunks run.
 //   * all integer/key work is exact: 64-bit key order == (distance, index) order, lower index wins ties.
@@ -28,7 +29,8 @@
 // XCD-aware block -> tile mapping, and the filter epilogue of the 32x32-accumulator kernels.  The kernels live in
 //   nwk_prep.hip       seeded generator, layout/norm preparation, max|x| and the scaled fp16 copies of the pre-screen
 //   nwk_tile_f32.hip   fp32 distance tile (v_mfma_f32_32x32x2_f32) fused with the running top-k filter
-//   nwk_tile_f16.hip   fp16 distance tiles (32x32x16, 16x16x32, two-workgroup form), direct and pre-screen (PRE = 1)
+//   nwk_tile_f16p.hip  fp16 distance tile, streaming form (v_mfma_f32_16x16x32_f16): the default up to 2048 halves per row
+//   nwk_tile_f16.hip   fp16 distance tiles, burst forms (32x32x16, 16x16x32, two-workgroup form), direct and pre-screen (PRE = 1)
 //   nwk_select.hip     rescoring of pre-screened pairs, list compaction, finalize, partial-list merge
 //   nwk_maxsim.hip     MaxSim late interaction (extension)
 // each with its host-side launchers (declared in nwknn_internal.h, called from nwknn_api.cpp).
