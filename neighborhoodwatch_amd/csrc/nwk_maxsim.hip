@@ -286,6 +286,156 @@ __global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_kernel(const NwkTilePar
     }
 }
 
+// The same pre-screen for d <= 128 (ColBERT: 128), "strip" form.  At 87 FLOP per operand byte the kernel above lives off its
+// operand stream, and a third of that stream is the query-token tile, re-fetched for every document tile.  Here a workgroup walks a
+// strip of p.tiles_per_wg consecutive document tiles for ONE group of 4 queries: the query tokens go through LDS once, their
+// fragments (8 k-steps x 2 column blocks = 64 VGPRs) then stay in registers for the whole strip, and only document tokens stream
+// (16 KiB per slab instead of 24; two 16 KiB stages instead of two of 24).  The next tile's first slab is requested before the
+// current tile's epilogue.  Same accumulators, same epilogue, same keys.
+__global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_strip_kernel(const NwkTileParams p)
+{
+    constexpr int TM = 256, TQ = 128, NK = 4, A_STAGE = TM * 64, B_SLAB = TQ * 64;      // 32-half slabs of 64-B rows
+    static_assert(NK * B_SLAB <= 2 * A_STAGE, "the query tile is staged through the document stages");
+    __shared__ __attribute__((aligned(16))) char smem[2 * A_STAGE];
+
+    const TileCoord tc = tile_from_block(p);         // tc.qt: group of 4 queries, tc.bt: STRIP of document tiles
+    if (!tc.ok) return;
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, l = tid & 63;
+    const int wr = w >> 1, wc = w & 1;
+    const int h = l >> 5, c32 = l & 31;
+    const int T = p.tiles_per_wg > 1 ? p.tiles_per_wg : 1;
+    const int bt_first = p.bt0 + (tc.bt - p.bt0) * T;
+    int n_here = p.bt0 + p.n_btiles_real - bt_first;
+    if (n_here > T) n_here = T;
+    const long long qrow0 = (long long)tc.qt * TQ;
+    const int dp = p.dp;                             // halves per row: 32 * nk, nk <= NK
+    const int nk = dp / 32;
+    const _Float16* docs = (const _Float16*)p.bp;
+    const _Float16* qrys = (const _Float16*)p.qp;
+
+    const unsigned voff = (unsigned)((l >> 2) * dp * 2 + (((l & 3) ^ ((0 - (l >> 4)) & 3)) << 4));
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(qrys + qrow0 * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int rowsA = wu * 64 * dp * 2, rowsB = wu * 32 * dp * 2, step16 = 16 * dp * 2;
+    const int swz = (0 - (c32 >> 2)) & 3;
+    int offA[4], offB[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) offA[m] = (wr * 128 + m * 32 + c32) * 64 + ((h ^ swz) << 4);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) offB[n] = (wc * 64 + n * 32 + c32) * 64 + ((h ^ swz) << 4);
+
+    // ---- the query-token tile: all of its slabs through LDS once, then 8 x 2 fragments in registers for the whole strip
+    for (int kt = 0; kt < nk; ++kt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(smem + kt * B_SLAB + wu * 2048 + i * 1024), 16, voff,
+                                                     kt * 64 + rowsB + i * step16, 0, 0);
+    const long long q_first = (long long)tc.qt * MS_QUERIES_PER_TILE + 2 * wc;
+    const u64 tauq[2] = {p.tau[q_first], p.tau[q_first + 1]};
+    const float rq[2] = {p.ms_rq[q_first], p.ms_rq[q_first + 1]};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    f16x8 bq[2 * NK][2];
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                bq[2 * kt + ks][n] = (kt < nk) ? *(const f16x8*)(smem + kt * B_SLAB + (offB[n] ^ (ks << 5))) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // every wave holds its fragments: the stages now belong to the document stream
+
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(docs + (long long)bt_first * TM * dp), 0, 0x7FFFFFFF, 0x00020000);
+    auto issue_A = [&](int stage, int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(smem + stage * A_STAGE + wu * 4096 + i * 1024), 16, voff,
+                                                     kt * 64 + rowsA + i * step16, 0, 0);
+    };
+    const int cap = p.cap;
+    issue_A(0, 0);
+    for (int t = 0; t < n_here; ++t) {
+        const int bt = bt_first + t;
+        float cdv[2];                                // per-document part of the score bound: requested now, used in the epilogue
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+            const long long doc = (long long)bt * MS_DOCS_PER_TILE + 2 * wr + dd;
+            cdv[dd] = doc < p.nb_valid ? p.ms_cd[doc] : 0.0f;
+        }
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+            if (kt >= nk) break;
+            const int cur = kt & 1;
+            if (kt + 1 < nk) {
+                issue_A(cur ^ 1, kt + 1);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            const char* sb = smem + cur * A_STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 a[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) a[m] = *(const f16x8*)(sb + (offA[m] ^ (ks << 5)));
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], bq[2 * kt + ks][n], acc[m][n], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (t + 1 < n_here) {                        // the next tile's first slab goes out before this tile's epilogue
+            rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(docs + (long long)(bt + 1) * TM * dp), 0, 0x7FFFFFFF, 0x00020000);
+            issue_A(0, 0);
+        }
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+            const long long doc = (long long)bt * MS_DOCS_PER_TILE + 2 * wr + dd;
+            const bool doc_ok = doc < p.nb_valid;
+            const float cd = cdv[dd];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                float v = acc[2 * dd][n][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) v = fmaxf(v, acc[2 * dd][n][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v = fmaxf(v, acc[2 * dd + 1][n][r]);
+                v = fmaxf(v, __shfl_xor(v, 32));
+                float sum = v;
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) sum = __fadd_rn(sum, __shfl_xor(sum, o));
+                if (l == 0 && doc_ok) {
+                    const long long q = q_first + n;
+                    const float score = sum * p.pre_inv_scale;                         // fp16 estimate of the MaxSim score
+                    bool pass = true;
+                    if (tauq[n] != ~0ull) {
+                        const float td = unsortable_f32((u32)(tauq[n] >> 32));          // = -(k-th best score so far)
+                        const float err = rq[n] + cd;
+                        pass = !(score < (-td) - err - 2.0e-6f * (fabsf(td) + err));
+                    }
+                    if (pass && q < p.nq_valid) {
+                        const u32 pos = atomicAdd(p.cnt + q, 1u);
+                        if (pos < (u32)cap) p.buf[q * cap + pos] = ((u64)__float_as_uint(-score) << 32) | (u32)doc;
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the workgroup leaves
+}
+
 // Rescoring in two launches.  (1) nwk_maxsim_prune_kernel, one wave per query: bounds est +- (R(q) + C(doc)) of the listed pairs,
 // k-th smallest upper bound by bisection, pairs that cannot reach the top k become ~0, the slots of the others go to surv[q][.].
 // (2) nwk_maxsim_rescore_kernel, grid (queries, slices): a wave takes every slices-th survivor of its query, two at a time (each
@@ -467,6 +617,12 @@ hipError_t nwk_launch_maxsim_pre(hipStream_t st, NwkTileParams p)
 {
     if (p.n_qtiles <= 0 || p.n_btiles <= 0) return hipSuccess;
     if (p.sq_shift < 0 || p.sq_shift > 6) return hipErrorInvalidValue;
+    const bool strip = p.dp <= 128 && p.tiles_per_wg != 1;      // d <= 128: query fragments fit the registers (tiles_per_wg = 1: the plain kernel)
+    if (strip) {
+        if (p.tiles_per_wg < 1) p.tiles_per_wg = 8;
+        p.n_btiles_real = p.n_btiles;
+        p.n_btiles = (p.n_btiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
+    }
     const int SQ = 1 << p.sq_shift, SB = 64 >> p.sq_shift;
     const long long n_super_q = (p.n_qtiles + SQ - 1) / SQ;
     p.n_super_b = (p.n_btiles + SB - 1) / SB;
@@ -474,7 +630,8 @@ hipError_t nwk_launch_maxsim_pre(hipStream_t st, NwkTileParams p)
     supers = (supers + 7) / 8 * 8;
     const long long grid = supers * 64;
     if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(nwk_maxsim_pre_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
+    if (strip) hipLaunchKernelGGL(nwk_maxsim_pre_strip_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(nwk_maxsim_pre_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
