@@ -450,10 +450,14 @@ static int stage_and_prep_columns(nwknn_ctx* h, const ColumnSource& src, int in_
                 (void)seg;
                 if (nt <= 1) work(0);
                 else {
+                    // no C++ exception may cross the C ABI: if a thread cannot be started, this thread does that share itself
                     std::vector<std::thread> pool;
+                    std::vector<int> mine{0};
                     pool.reserve(nt - 1);
-                    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
-                    work(0);
+                    for (int t = 1; t < nt; ++t) {
+                        try { pool.emplace_back(work, t); } catch (...) { mine.push_back(t); }
+                    }
+                    for (int t : mine) work(t);
                     for (auto& th : pool) th.join();
                 }
             }
