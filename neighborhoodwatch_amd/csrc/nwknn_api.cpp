@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -52,6 +53,16 @@ static int fail(int code, const char* fmt, ...)
     } while (0)
 
 static inline long long round_up(long long x, long long m) { return (x + m - 1) / m * m; }
+
+// No C++ exception crosses the C ABI (include/nwknn.h): entry points that reach code which allocates host memory run through this.
+template <class F>
+static int guarded(F&& f)
+{
+    try { return f(); }
+    catch (const std::bad_alloc&) { return fail(NWKNN_ENOMEM, "out of host memory"); }
+    catch (const std::exception& e) { return fail(NWKNN_EHIP, "internal error: %s", e.what()); }
+    catch (...) { return fail(NWKNN_EHIP, "internal error (unknown C++ exception)"); }
+}
 
 struct DevBuf {
     void* p = nullptr;
@@ -582,7 +593,7 @@ static int set_base_common(nwknn_ctx* h, const void* base, const ColumnSource* c
 extern "C" int nwknn_set_base(nwknn_handle h, const void* base, int64_t rows, int32_t d, int dtype, int location)
 {
     if (!base) return fail(NWKNN_EINVAL, "nwknn_set_base: null handle or base pointer");
-    return set_base_common(h, base, nullptr, rows, d, dtype, location);
+    return guarded([&] { return set_base_common(h, base, nullptr, rows, d, dtype, location); });
 }
 
 extern "C" int nwknn_set_base_columns(nwknn_handle h, const void* const* columns, int64_t rows, int32_t d, int dtype)
@@ -590,7 +601,7 @@ extern "C" int nwknn_set_base_columns(nwknn_handle h, const void* const* columns
     if (!columns) return fail(NWKNN_EINVAL, "nwknn_set_base_columns: null column table");
     const int64_t one = rows;
     const ColumnSource src{columns, &one, 1};
-    return set_base_common(h, nullptr, &src, rows, d, dtype, NWKNN_HOST);
+    return guarded([&] { return set_base_common(h, nullptr, &src, rows, d, dtype, NWKNN_HOST); });
 }
 
 extern "C" int nwknn_set_base_column_chunks(nwknn_handle h, const void* const* chunks, const int64_t* chunk_rows, int32_t n_chunks, int64_t rows,
@@ -598,7 +609,7 @@ extern "C" int nwknn_set_base_column_chunks(nwknn_handle h, const void* const* c
 {
     if (!chunks || !chunk_rows || n_chunks <= 0) return fail(NWKNN_EINVAL, "nwknn_set_base_column_chunks: null or empty chunk table");
     const ColumnSource src{chunks, chunk_rows, n_chunks};
-    return set_base_common(h, nullptr, &src, rows, d, dtype, NWKNN_HOST);
+    return guarded([&] { return set_base_common(h, nullptr, &src, rows, d, dtype, NWKNN_HOST); });
 }
 
 // ---- search -----------------------------------------------------------------------------------------
@@ -957,7 +968,7 @@ extern "C" int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int
                             float* out_dist, int64_t* out_idx, int out_location)
 {
     if (!queries) return fail(NWKNN_EINVAL, "nwknn_search: null argument");
-    return search_common(h, queries, nullptr, nq, dtype, location, k, metric, index_offset, out_dist, out_idx, out_location);
+    return guarded([&] { return search_common(h, queries, nullptr, nq, dtype, location, k, metric, index_offset, out_dist, out_idx, out_location); });
 }
 
 extern "C" int nwknn_search_columns(nwknn_handle h, const void* const* columns, int64_t nq, int dtype, int32_t k, int metric, int64_t index_offset,
@@ -966,7 +977,7 @@ extern "C" int nwknn_search_columns(nwknn_handle h, const void* const* columns, 
     if (!columns) return fail(NWKNN_EINVAL, "nwknn_search_columns: null column table");
     const int64_t one = nq;
     const ColumnSource src{columns, &one, 1};
-    return search_common(h, nullptr, &src, nq, dtype, NWKNN_HOST, k, metric, index_offset, out_dist, out_idx, out_location);
+    return guarded([&] { return search_common(h, nullptr, &src, nq, dtype, NWKNN_HOST, k, metric, index_offset, out_dist, out_idx, out_location); });
 }
 
 extern "C" int nwknn_search_column_chunks(nwknn_handle h, const void* const* chunks, const int64_t* chunk_rows, int32_t n_chunks, int64_t nq, int dtype,
@@ -974,7 +985,7 @@ extern "C" int nwknn_search_column_chunks(nwknn_handle h, const void* const* chu
 {
     if (!chunks || !chunk_rows || n_chunks <= 0) return fail(NWKNN_EINVAL, "nwknn_search_column_chunks: null or empty chunk table");
     const ColumnSource src{chunks, chunk_rows, n_chunks};
-    return search_common(h, nullptr, &src, nq, dtype, NWKNN_HOST, k, metric, index_offset, out_dist, out_idx, out_location);
+    return guarded([&] { return search_common(h, nullptr, &src, nq, dtype, NWKNN_HOST, k, metric, index_offset, out_dist, out_idx, out_location); });
 }
 
 // ---- MaxSim late interaction (new: BASELINE config 5; the reference's `ck` is flat token kNN) ----------------
@@ -991,7 +1002,7 @@ static int grow_padded(nwknn_ctx* h, DevBuf& nb2, DevBuf& nn2, long long pad)
     return NWKNN_OK;
 }
 
-extern "C" int nwknn_maxsim_set_docs(nwknn_handle h, const void* doc_tokens, int64_t n_docs, int32_t tokens_per_doc, int32_t d, int dtype,
+static int nwknn_maxsim_set_docs_impl(nwknn_handle h, const void* doc_tokens, int64_t n_docs, int32_t tokens_per_doc, int32_t d, int dtype,
                                      int location)
 {
     if (!h || !doc_tokens) return fail(NWKNN_EINVAL, "nwknn_maxsim_set_docs: null argument");
@@ -1029,6 +1040,11 @@ extern "C" int nwknn_maxsim_set_docs(nwknn_handle h, const void* doc_tokens, int
         }
     }
     return NWKNN_OK;
+}
+
+extern "C" int nwknn_maxsim_set_docs(nwknn_handle h, const void* doc_tokens, int64_t n_docs, int32_t tokens_per_doc, int32_t d, int dtype, int location)
+{
+    return guarded([&] { return nwknn_maxsim_set_docs_impl(h, doc_tokens, n_docs, tokens_per_doc, d, dtype, location); });
 }
 
 static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq_pad, long long doc_lo, long long docs, bool dense, bool dedupe,
@@ -1081,8 +1097,8 @@ static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq
     return NWKNN_OK;
 }
 
-extern "C" int nwknn_maxsim_search(nwknn_handle h, const void* query_tokens, int64_t n_queries, int32_t tokens_per_query, int dtype, int location,
-                                   int32_t k, int64_t doc_offset, float* out_score, int64_t* out_doc, int out_location)
+static int maxsim_search_impl(nwknn_handle h, const void* query_tokens, int64_t n_queries, int32_t tokens_per_query, int dtype, int location,
+                              int32_t k, int64_t doc_offset, float* out_score, int64_t* out_doc, int out_location)
 {
     if (!h || !query_tokens || !out_score || !out_doc) return fail(NWKNN_EINVAL, "nwknn_maxsim_search: null argument");
     if (h->ms_docs <= 0) return fail(NWKNN_ESTATE, "nwknn_maxsim_search: call nwknn_maxsim_set_docs first");
@@ -1199,6 +1215,13 @@ extern "C" int nwknn_maxsim_search(nwknn_handle h, const void* query_tokens, int
         h->stats.prep_ms += h->base_prep_ms; h->base_prep_ms = 0.0;
     }
     return NWKNN_OK;
+}
+
+extern "C" int nwknn_maxsim_search(nwknn_handle h, const void* query_tokens, int64_t n_queries, int32_t tokens_per_query, int dtype, int location,
+                                   int32_t k, int64_t doc_offset, float* out_score, int64_t* out_doc, int out_location)
+{
+    return guarded([&] { return maxsim_search_impl(h, query_tokens, n_queries, tokens_per_query, dtype, location, k, doc_offset, out_score, out_doc,
+                                                   out_location); });
 }
 
 // ---- merge ------------------------------------------------------------------------------------------
