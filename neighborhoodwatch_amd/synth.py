@@ -53,8 +53,9 @@ def gen_unit_rows(seed: int, row0: int, rows: int, d: int) -> np.ndarray:
 
 
 def write_source_parquet(filename: str, seed: int, rows: int, d: int, normalize: bool = False, chunk_rows: int = 50000,
-                         column_prefix: str = "embedding_") -> str:
-    """One parquet file, metadata columns first then ``<prefix>0..d-1`` as float32, written in row groups."""
+                         column_prefix: str = "embedding_", metadata_columns: bool = True) -> str:
+    """One parquet file, metadata columns first (unless ``metadata_columns=False``: the ``ck`` source files hold the token
+    columns only, colbert_knn.py:229-233) then ``<prefix>0..d-1`` as float32, written in row groups."""
     os.makedirs(os.path.dirname(os.path.abspath(filename)), exist_ok=True)
     writer = None
     try:
@@ -66,7 +67,7 @@ def write_source_parquet(filename: str, seed: int, rows: int, d: int, normalize:
                 "text": pa.array(["synthetic"] * n),
                 "title": pa.array(["synthetic"] * n),
                 "document_id": pa.array(np.arange(r0, r0 + n, dtype=np.int64)),
-            }
+            } if metadata_columns else {}
             for j in range(d):
                 cols[f"{column_prefix}{j}"] = pa.array(np.ascontiguousarray(x[:, j]))
             table = pa.table(cols)

@@ -198,3 +198,19 @@ def test_cli_unit_rows_pass_the_reference_validator(tmp_path, extra):
     from neighborhoodwatch_amd.neighborhoodwatch import main
     assert main(["150", "4000", "-k", "10", "-m", "intfloat/e5-small-v2", "--data-dir", str(tmp_path), "--disable-memory-tuning",
                  "--normalize", "--post-validation", "--no-gen-hdf5"] + extra) == 0
+
+
+def test_ck_cli_end_to_end(tmp_path, oracle):
+    """`ck` with synthetic token embeddings: same flags and stage order as the reference (colbert_knn.py:146-341), token
+    source files with token_embedding_<i> columns only, 9000-row tiles, 1 - dot, merge, fvec/ivec -- checked against the oracle."""
+    from neighborhoodwatch_amd import parquet_to_format as p2f
+    from neighborhoodwatch_amd.colbert_knn import main
+    assert main(["140", "21000", "-k", "10", "--data-dir", str(tmp_path), "--no-gen-hdf5", "--disable-memory-tuning", "--synthetic-seed", "0x40"]) == 0
+    data_dir = f"{tmp_path}/colbertv2.0/q140_b21000_k10"
+    assert merge.get_file_count(f"{data_dir}/partial") == 3                     # engine torch: 9000-row base tiles (colbert_knn.py:95-98)
+    base = synth.gen_unit_rows(0x40, 0, 21000, 128); queries = synth.gen_unit_rows(0x41, 0, 140, 128)
+    rd, ri = oracle.knn_canonical(base, queries, 10, "one_minus_dot")
+    fd, fi = _final(data_dir)
+    assert np.array_equal(_arr(fi, np.int64), ri) and np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
+    qf, bf, iif, df_ = p2f.get_ivec_fvec_filenames(data_dir, "colbertv2.0", 128, 21000, 140, 10, None)
+    assert p2f.count_vectors(data_dir, iif) == 140 and p2f.count_vectors(data_dir, bf) == 21000

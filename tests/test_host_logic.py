@@ -203,6 +203,15 @@ def test_cli_keeps_the_reference_flags():
     assert a.enable_memory_tuning and a.use_dataset_api and not a.gen_hdf5 and a.output_dimension_size == 256 and a.post_validation
 
 
+def test_ck_cli_keeps_the_reference_flags():
+    from neighborhoodwatch_amd.colbert_knn import build_parser                       # colbert_knn.py:149-172
+    a = build_parser().parse_args(["100000", "1000000", "-k", "100", "--disable-memory-tuning"])
+    assert (a.query_token_count, a.base_token_count, a.k, a.model_name, a.engine) == (100000, 1000000, 100, "colbertv2.0", "torch")
+    assert a.embedding_scale == "medium" and a.data_dir == "knn_dataset" and a.gen_hdf5 is True and a.use_dataset_api is False
+    a = build_parser().parse_args(["1", "2", "-es", "small", "--engine", "raft", "--enable-memory-tuning", "--no-gen-hdf5", "--data-dir", "/tmp/x"])
+    assert a.embedding_scale == "small" and a.engine == "raft" and a.enable_memory_tuning and not a.gen_hdf5
+
+
 def test_engine_refuses_tensors_of_another_gpu():
     """A CUDA tensor handed to an engine must live on the engine's GPU: the check comes before anything touches a stream, so it
     can be exercised without a device (the engine object is made without nwknn_create)."""
