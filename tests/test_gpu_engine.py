@@ -322,3 +322,18 @@ def test_non_finite_inputs_do_not_break_parity(engine, oracle):
         rd, ri = oracle.knn_canonical(base, queries, 25, metric)
         assert np.array_equal(idx, ri)
         assert np.array_equal(dist.view(np.uint32), rd.view(np.uint32))
+
+
+def test_default_opts_environment_hook(monkeypatch):
+    """NWKNN_DEFAULT_OPTS applies options to every new handle (how the whole suite is run against an alternative kernel build);
+    a malformed entry or an unknown option makes nwknn_create fail loudly instead of being ignored."""
+    from neighborhoodwatch_amd import KnnEngine
+    from neighborhoodwatch_amd._lib import NwknnError
+    monkeypatch.setenv("NWKNN_DEFAULT_OPTS", "f16_mfma=1,tile_occ=2")
+    KnnEngine(0).close()
+    monkeypatch.setenv("NWKNN_DEFAULT_OPTS", "f16_mfma")
+    with pytest.raises(NwknnError, match="name=value"):
+        KnnEngine(0)
+    monkeypatch.setenv("NWKNN_DEFAULT_OPTS", "no_such_option=1")
+    with pytest.raises(NwknnError):
+        KnnEngine(0)
