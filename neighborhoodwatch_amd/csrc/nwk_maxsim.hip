@@ -1,5 +1,6 @@
 // nwk_maxsim.hip -- MaxSim late interaction (extension, not in the reference): tile, pre-screen, prune and rescore kernels  (gfx950 only; shared pieces and the overall design: nwk_device.h)
 #include "nwk_device.h"
+#include <algorithm>
 
 // ------------------------------------------------------------------------------------------------
 // MaxSim late interaction (BASELINE config 5; NOT in the reference -- its `ck` is flat token-level kNN):
@@ -590,6 +591,79 @@ __global__ __launch_bounds__(256) void nwk_maxsim_rescore_kernel(const NwkMsResc
 }
 
 
+// The same rescoring on the matrix pipes.  Recomputing one (query, document) score is a 64 x 32 x d fp32 product -- the shape of
+// v_mfma_f32_32x32x2_f32, whose result is the k-ordered fmaf chain, i.e. the very arithmetic nwk_maxsim_kernel defines as
+// canonical (document tokens on the accumulator rows, query tokens on the lanes: the in-lane max and the butterfly sum below are
+// that kernel's).  A workgroup = 4 waves on ONE query (its 32 token rows staged once in LDS, 528-B pitch: conflict-free
+// ds_read_b128), each wave takes every (4 x slices)-th survivor; the document's token rows come straight from global memory in
+// fragment shape (lane = row, 16 B = four k-steps of its half), four 8-k groups ahead of the MFMAs (two register sets).
+// 128 MFMAs per pair instead of 4096 FMAs per lane: the kernel becomes a gather of 32 KiB per document.
+__global__ __launch_bounds__(256) void nwk_maxsim_rescore_mfma_kernel(const NwkMsRescoreParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char msq_dyn[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long q = blockIdx.x;
+    const u32 nsurv = p.nsurv[q];
+    if (blockIdx.y * 4 >= nsurv) return;                             // workgroup-uniform
+    const int dp = p.dp;                                             // multiple of 32
+    const int pitch = dp * 4 + 16;
+    const float* __restrict__ qtok = p.qp + q * NWK_MS_TOKENS_PER_QUERY * dp;
+    const int per_row = dp / 4;
+    for (int i = threadIdx.x; i < NWK_MS_TOKENS_PER_QUERY * per_row; i += 256) {
+        const int row = i / per_row, c = i - row * per_row;
+        *(f32x4*)(msq_dyn + row * pitch + c * 16) = *(const f32x4*)(qtok + row * dp + c * 4);
+    }
+    __syncthreads();
+    const int h = lane >> 5, c32 = lane & 31;
+    const char* sb = msq_dyn + c32 * pitch + h * 16;                 // + 32 g: chunk 2g + h of query token c32
+    u64* list = p.buf + q * p.cap;
+    const u32* surv = p.surv + q * p.cap;
+    const int ngroups = dp / 8;                                      // multiple of 4
+    for (u32 i = blockIdx.y * 4 + wv; i < nsurv; i += gridDim.y * 4) {                   // wave-uniform
+        const u32 e = surv[i];
+        const u32 doc = (u32)list[e];
+        const float* __restrict__ a0p = p.bp + ((long long)doc * NWK_MS_TOKENS_PER_DOC + c32) * dp + 4 * h;   // token rows 0..31
+        const float* __restrict__ a1p = a0p + 32 * dp;                                                      // token rows 32..63
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+        f32x4 xa[4][2], xb[4][2];                                    // two sets of four groups x two row blocks
+        auto load4 = [&](f32x4 (&dst)[4][2], int g0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dst[j][0] = *(const f32x4*)(a0p + 8 * (g0 + j)); dst[j][1] = *(const f32x4*)(a1p + 8 * (g0 + j)); }
+        };
+        auto mma4 = [&](const f32x4 (&src)[4][2], int g0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 b = *(const f32x4*)(sb + 32 * (g0 + j));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {                          // k = 8 (g0 + j) + 2 t + h: ascending over the whole loop
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(src[j][0][t], b[t], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(src[j][1][t], b[t], acc1, 0, 0, 0);
+                }
+            }
+        };
+        load4(xa, 0);
+        for (int g0 = 0; g0 < ngroups; g0 += 8) {
+            if (g0 + 4 < ngroups) load4(xb, g0 + 4);
+            mma4(xa, g0);
+            if (g0 + 4 >= ngroups) break;
+            if (g0 + 8 < ngroups) load4(xa, g0 + 8);
+            mma4(xb, g0 + 4);
+        }
+        float v = acc0[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) v = fmaxf(v, acc0[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v = fmaxf(v, acc1[r]);
+        v = fmaxf(v, __shfl_xor(v, 32));                             // the other half-wave holds the other 32 token rows of the doc
+        float sum = v;                                               // lane c32 = query token c32: the kernel's pairwise tree
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) sum = __fadd_rn(sum, __shfl_xor(sum, o));
+        if (lane == 0) list[e] = ((u64)sortable_u32(-sum) << 32) | doc;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers (host side, called from nwknn_api.cpp)
 // ------------------------------------------------------------------------------------------------
@@ -654,7 +728,15 @@ hipError_t nwk_launch_maxsim_rescore(hipStream_t st, NwkMsRescoreParams p, long 
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    // (2) rescore: (query, slice) waves; the query's 32 token rows in LDS when they fit (d = 128: 16 KiB per wave)
+    // (2) rescore.  On the matrix pipes when the query's padded token rows fit LDS comfortably (d <= 256): workgroups of four
+    //     waves per (query, slice)
+    const size_t mfma_lds = (size_t)NWK_MS_TOKENS_PER_QUERY * ((size_t)p.dp * 4 + 16);
+    if (mfma_lds <= 40 * 1024 && !p.rescore_valu) {
+        const int s4 = std::max(1, (slices + 3) / 4);
+        hipLaunchKernelGGL(nwk_maxsim_rescore_mfma_kernel, dim3((unsigned)nq_pad, (unsigned)s4), dim3(256), mfma_lds, st, p);
+        return hipGetLastError();
+    }
+    //     else on the vector pipes: (query, slice) waves; the query's 32 token rows in LDS when they fit (d = 128: 16 KiB per wave)
     const size_t qbytes = (size_t)NWK_MS_TOKENS_PER_QUERY * p.dp * 4;
     const int waves = 2;
     p.q_in_lds = (waves * qbytes <= 64 * 1024) ? 1 : 0;

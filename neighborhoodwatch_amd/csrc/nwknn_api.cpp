@@ -114,7 +114,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 8;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 8, opt_ms_rescore_valu = 0;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -288,6 +288,8 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
     } else if (!strcmp(name, "chunk_growth")) {
         if (value < 0 || value > 7) return fail(NWKNN_EINVAL, "chunk_growth must be 0 (auto) or 1..7");
         h->opt_chunk_growth = value;        // a filtered chunk holds up to chunk_growth x the rows seen so far (1: chunks double)
+    } else if (!strcmp(name, "ms_rescore_valu")) {
+        h->opt_ms_rescore_valu = value ? 1 : 0;   // MaxSim rescoring on the vector pipes (round-1 kernel) instead of the matrix pipes
     } else if (!strcmp(name, "ms_strip")) {
         if (value < 1 || value > 64) return fail(NWKNN_EINVAL, "ms_strip must be 1..64");
         h->opt_ms_strip = value;            // MaxSim pre-screen, d <= 128: document tiles a workgroup walks per query group (1: the plain kernel)
@@ -1075,7 +1077,7 @@ static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq
         rp.rq = h->ms_rq.as<float>(); rp.cd = h->ms_cd.as<float>();
         rp.dp = h->dp; rp.cap = cap; rp.k = k; rp.prune = (h->opt_pre_prune && !dedupe) ? 1 : 0;
         rp.dbg = h->opt_dbg_ptr ? (unsigned long long*)(uintptr_t)h->opt_dbg_ptr : nullptr;
-        rp.surv = h->ms_surv.as<u32>(); rp.nsurv = h->ms_nsurv.as<u32>();
+        rp.surv = h->ms_surv.as<u32>(); rp.nsurv = h->ms_nsurv.as<u32>(); rp.rescore_valu = (int)h->opt_ms_rescore_valu;
         // enough (query, slice) waves to fill the chip a few times over
         const int slices = (int)std::max<long long>(1, std::min<long long>(32, (8ll * h->num_cu * 4 + nq_pad - 1) / nq_pad));
         e = ev_begin(h, 3);

@@ -77,6 +77,7 @@ struct NwkMsRescoreParams {
     unsigned int* nsurv;           // [nq_pad]
     unsigned long long* dbg;       // dev: [0] += listed pairs, [1] += rescored pairs
     int q_in_lds;                  // set by the launcher: the query's token rows fit in LDS next to the list arrays
+    int rescore_valu;              // 1: the vector-pipe rescoring kernel even where the MFMA one applies (option "ms_rescore_valu")
 };
 
 struct NwkCompactParams {
