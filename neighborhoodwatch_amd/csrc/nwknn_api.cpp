@@ -213,20 +213,20 @@ extern "C" int nwknn_create(nwknn_handle* out, int device)
     int rc = create_device_objects(h);
     // NWKNN_DEFAULT_OPTS="name=value,name=value": options applied to every new handle (developers run the whole test suite against
     // an alternative kernel build this way, e.g. f16_mfma=3); unset in production
-    if (rc == NWKNN_OK) {
-        if (const char* env = getenv("NWKNN_DEFAULT_OPTS")) {
-            std::string all(env);
-            size_t pos = 0;
-            while (rc == NWKNN_OK && pos < all.size()) {
-                const size_t end = std::min(all.find(',', pos), all.size());
-                const std::string kv = all.substr(pos, end - pos);
-                const size_t eq = kv.find('=');
-                if (eq == std::string::npos) rc = fail(NWKNN_EINVAL, "NWKNN_DEFAULT_OPTS: '%s' is not name=value", kv.c_str());
-                else rc = nwknn_set_option(h, kv.substr(0, eq).c_str(), atoll(kv.c_str() + eq + 1));
-                pos = end + 1;
-            }
+    if (rc == NWKNN_OK) rc = guarded([&] {
+        const char* env = getenv("NWKNN_DEFAULT_OPTS");
+        if (!env) return (int)NWKNN_OK;
+        const std::string all(env);
+        for (size_t pos = 0; pos < all.size();) {
+            const size_t end = std::min(all.find(',', pos), all.size());
+            const std::string kv = all.substr(pos, end - pos);
+            const size_t eq = kv.find('=');
+            if (eq == std::string::npos) return fail(NWKNN_EINVAL, "NWKNN_DEFAULT_OPTS: '%s' is not name=value", kv.c_str());
+            RCCHK(nwknn_set_option(h, kv.substr(0, eq).c_str(), atoll(kv.c_str() + eq + 1)));
+            pos = end + 1;
         }
-    }
+        return (int)NWKNN_OK;
+    });
     if (rc != NWKNN_OK) { (void)nwknn_destroy(h); return rc; }      // releases whatever was created; last_error keeps the cause
     *out = h;
     return NWKNN_OK;
@@ -465,7 +465,9 @@ static int stage_and_prep_columns(nwknn_ctx* h, const ColumnSource& src, int in_
                 else {
                     // no C++ exception may cross the C ABI: if a thread cannot be started, this thread does that share itself
                     std::vector<std::thread> pool;
-                    std::vector<int> mine{0};
+                    std::vector<int> mine;
+                    mine.reserve(nt);               // nothing below may throw once a thread runs
+                    mine.push_back(0);
                     pool.reserve(nt - 1);
                     for (int t = 1; t < nt; ++t) {
                         try { pool.emplace_back(work, t); } catch (...) { mine.push_back(t); }
