@@ -437,6 +437,196 @@ __global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_strip_kernel(const NwkT
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the workgroup leaves
 }
 
+// "Ring" form of the strip kernel (option ms_ring, the default for d <= 128).  Two things held the strip kernel at 37 % of the fp16
+// MFMA rate although a tile is only 64 MFMAs per wave:
+//   * its two 16 KiB stages let a document slab be requested ONE slab (16 MFMAs per wave, ~0.25 us) before it is waited for, with two
+//     barriers per slab -- the LDS-DMA round trip is several times that, so every slab began with a stall;
+//   * its epilogue ran 4 x 6 ds_bpermute exchanges one after the other, each behind an s_waitcnt lgkmcnt(0) (the butterfly sum over
+//     the query's tokens, once per (doc, query) pair of the wave): 24 LDS round trips per tile, as long as the tile's MFMAs.
+// Here the document stream runs through a ring of FOUR 16 KiB stages (a whole d = 128 tile ahead; 64 KiB per workgroup, still two
+// workgroups per CU): slab S+3 is requested at the top of slab S into the stage slab S-1 just released, ONE barrier per slab,
+// one counted wait (vmcnt(8): the requests of slabs S+1 and S+2 may still be in flight; requests past the end of the strip are
+// still issued, source clamped to the last slab, so the count is a constant), and the stream runs on across the tiles of the strip.
+// The first k-step of a tile takes a zero C operand instead of cleared accumulators; the per-document bounds of the strip are
+// staged in LDS once (no register-destination load, hence no vmcnt(0), inside the loop).  The epilogue exchanges nothing through
+// LDS: the cross-half max is one v_permlane32_swap, the sum over the 32 query tokens four DPP adds (quad_perm [1,0,3,2], [2,3,0,1],
+// row_half_mirror, row_mirror: lane for lane the values of the xor-1,2,4,8 butterfly, fp32 addition being commutative) and two
+// v_readlane for the last level, the four pairs of a wave interleaved.  Same estimates, same keys as the strip kernel.
+template <int CTRL>
+__device__ __forceinline__ float ms_dpp(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+
+// v: a lane's max over its 32 accumulator rows of one (doc, query-token column); lanes l and l ^ 32 hold the two halves of the doc's
+// 64 tokens.  Returns the sum over the 32 query tokens (lanes 0..31) of the max over the doc's tokens, wave-uniform.
+__device__ __forceinline__ float ms_token_sum(float v)
+{
+    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    float s = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));     // [lo, lo] vs [hi, hi]: every lane holds max(lo, hi)
+    s = __fadd_rn(s, ms_dpp<0xB1>(s));       // quad_perm [1,0,3,2]  == xor 1
+    s = __fadd_rn(s, ms_dpp<0x4E>(s));       // quad_perm [2,3,0,1]  == xor 2
+    s = __fadd_rn(s, ms_dpp<0x141>(s));      // row_half_mirror      == xor 4 (quads are uniform by now)
+    s = __fadd_rn(s, ms_dpp<0x140>(s));      // row_mirror           == xor 8
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 16));
+    return __fadd_rn(r0, r1);                // == xor 16 as lane 0 sees it
+}
+
+#define MS_RING_MAX_STRIP 64
+
+__global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_ring_kernel(const NwkTileParams p)
+{
+    constexpr int TM = 256, TQ = 128, NK = 4, SLAB = TM * 64, RING = 4, B_SLAB = TQ * 64;      // 32-half slabs of 64-B rows
+    constexpr int OFF_CD = RING * SLAB;
+    static_assert(NK * B_SLAB <= RING * SLAB, "the query tile is staged through the document stages");
+    static_assert(MS_RING_MAX_STRIP * MS_DOCS_PER_TILE == 256, "one thread stages one document bound");
+    __shared__ __attribute__((aligned(16))) char smem[OFF_CD + MS_RING_MAX_STRIP * MS_DOCS_PER_TILE * 4];
+
+    const TileCoord tc = tile_from_block(p);         // tc.qt: group of 4 queries, tc.bt: STRIP of document tiles
+    if (!tc.ok) return;
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, l = tid & 63;
+    const int wr = w >> 1, wc = w & 1;
+    const int h = l >> 5, c32 = l & 31;
+    const int T = p.tiles_per_wg > 1 ? p.tiles_per_wg : 1;         // <= MS_RING_MAX_STRIP (launcher)
+    const int bt_first = p.bt0 + (tc.bt - p.bt0) * T;
+    int n_here = p.bt0 + p.n_btiles_real - bt_first;
+    if (n_here > T) n_here = T;
+    const long long qrow0 = (long long)tc.qt * TQ;
+    const int dp = p.dp;                             // halves per row: 32 * nk, nk <= NK
+    const int nk = dp / 32;
+    const _Float16* docs = (const _Float16*)p.bp;
+    const _Float16* qrys = (const _Float16*)p.qp;
+
+    const unsigned voff = (unsigned)((l >> 2) * dp * 2 + (((l & 3) ^ ((0 - (l >> 4)) & 3)) << 4));
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(qrys + qrow0 * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int rowsA = wu * 64 * dp * 2, rowsB = wu * 32 * dp * 2, step16 = 16 * dp * 2;
+    const int swz = (0 - (c32 >> 2)) & 3;
+    int offA[4], offB[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) offA[m] = (wr * 128 + m * 32 + c32) * 64 + ((h ^ swz) << 4);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) offB[n] = (wc * 64 + n * 32 + c32) * 64 + ((h ^ swz) << 4);
+
+    // ---- once per strip: the query-token tile through LDS into 8 x 2 register fragments; the strip's per-document bounds into LDS
+    for (int kt = 0; kt < nk; ++kt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(smem + kt * B_SLAB + wu * 2048 + i * 1024), 16, voff,
+                                                     kt * 64 + rowsB + i * step16, 0, 0);
+    const long long q_first = (long long)tc.qt * MS_QUERIES_PER_TILE + 2 * wc;
+    const u64 tauq[2] = {p.tau[q_first], p.tau[q_first + 1]};
+    const float rq[2] = {p.ms_rq[q_first], p.ms_rq[q_first + 1]};
+    float cd_mine = 0.0f;
+    {
+        const long long doc = (long long)bt_first * MS_DOCS_PER_TILE + tid;
+        if (tid < n_here * MS_DOCS_PER_TILE && doc < p.nb_valid) cd_mine = p.ms_cd[doc];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ((float*)(smem + OFF_CD))[tid] = cd_mine;
+    __builtin_amdgcn_s_barrier();
+    f16x8 bq[2 * NK][2];
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                bq[2 * kt + ks][n] = (kt < nk) ? *(const f16x8*)(smem + kt * B_SLAB + (offB[n] ^ (ks << 5))) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    // per (query, .) constants of the filter:  pass  <=>  !(score < lim),  lim = -td - err - 2e-6 (|td| + err),  err = rq + cd
+    float ntd[2], atd[2];
+    bool open_[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        open_[n] = tauq[n] == ~0ull;                                  // fewer than k docs seen: everything is listed
+        const float td = unsortable_f32((u32)(tauq[n] >> 32));       // = -(k-th best score so far)
+        ntd[n] = -td; atd[n] = fabsf(td);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // every wave holds its fragments: the stages now belong to the document stream
+
+    // ---- the document stream: slab X (tile X / nk, k-slab X % nk, clamped to the strip's last slab) goes to stage X & 3
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(docs + (long long)bt_first * TM * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const int NS = n_here * nk;
+    const int tile_bytes = TM * dp * 2;
+    int it = 0, ik = 0, ist = 0;
+    auto issue_next = [&]() {
+        const int soff = it * tile_bytes + ik * 64 + rowsA;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(smem + ist * SLAB + wu * 4096 + i * 1024), 16, voff, soff + i * step16, 0, 0);
+        ist = (ist + 1) & (RING - 1);
+        if (it * nk + ik + 1 < NS) { if (++ik == nk) { ik = 0; ++it; } }
+    };
+    issue_next(); issue_next(); issue_next();
+
+    const int cap = p.cap;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int st = 0;                                      // stage of the slab being multiplied
+    for (int t = 0; t < n_here; ++t) {
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+            if (kt >= nk) break;
+            // this wave's requests for the slab have landed (behind them: the 4 + 4 of the next two slabs) and its fragment reads of
+            // the previous slab are done; behind the barrier that holds for every wave, so the previous slab's stage can be refilled
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue_next();
+            const char* sb = smem + st * SLAB;
+            st = (st + 1) & (RING - 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 a[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) a[m] = *(const f16x8*)(sb + (offA[m] ^ (ks << 5)));
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], bq[2 * kt + ks][n], (kt == 0 && ks == 0) ? zero16 : acc[m][n], 0, 0, 0);
+            }
+        }
+        // ---- epilogue of tile t (the requests of the next three slabs are in flight): 2 docs x 2 queries per wave
+        const float* cd_s = (const float*)(smem + OFF_CD) + t * MS_DOCS_PER_TILE + 2 * wr;
+        float score[2][2];
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                float v = acc[2 * dd][n][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) v = fmaxf(v, acc[2 * dd][n][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v = fmaxf(v, acc[2 * dd + 1][n][r]);
+                score[dd][n] = v;
+            }
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) score[dd][n] = ms_token_sum(score[dd][n]) * p.pre_inv_scale;     // fp16 estimate of the MaxSim score
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+            const long long doc = (long long)(bt_first + t) * MS_DOCS_PER_TILE + 2 * wr + dd;
+            const bool doc_ok = doc < p.nb_valid;
+            const float cd = cd_s[dd];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const long long q = q_first + n;
+                const float err = rq[n] + cd;
+                const bool pass = open_[n] || !(score[dd][n] < ntd[n] - err - 2.0e-6f * (atd[n] + err));
+                if (pass && doc_ok && q < p.nq_valid && l == 0) {
+                    const u32 pos = atomicAdd(p.cnt + q, 1u);
+                    if (pos < (u32)cap) p.buf[q * cap + pos] = ((u64)__float_as_uint(-score[dd][n]) << 32) | (u32)doc;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the workgroup leaves
+}
+
 // Rescoring in two launches.  (1) nwk_maxsim_prune_kernel, one wave per query: bounds est +- (R(q) + C(doc)) of the listed pairs,
 // k-th smallest upper bound by bisection, pairs that cannot reach the top k become ~0, the slots of the others go to surv[q][.].
 // (2) nwk_maxsim_rescore_kernel, grid (queries, slices): a wave takes every slices-th survivor of its query, two at a time (each
@@ -692,8 +882,10 @@ hipError_t nwk_launch_maxsim_pre(hipStream_t st, NwkTileParams p)
     if (p.n_qtiles <= 0 || p.n_btiles <= 0) return hipSuccess;
     if (p.sq_shift < 0 || p.sq_shift > 6) return hipErrorInvalidValue;
     const bool strip = p.dp <= 128 && p.tiles_per_wg != 1;      // d <= 128: query fragments fit the registers (tiles_per_wg = 1: the plain kernel)
+    const bool ring = strip && p.ms_ring;                       // four-stage document ring, one barrier per slab, DPP epilogue (the default)
     if (strip) {
         if (p.tiles_per_wg < 1) p.tiles_per_wg = 8;
+        if (ring && p.tiles_per_wg > MS_RING_MAX_STRIP) p.tiles_per_wg = MS_RING_MAX_STRIP;
         p.n_btiles_real = p.n_btiles;
         p.n_btiles = (p.n_btiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
     }
@@ -704,7 +896,8 @@ hipError_t nwk_launch_maxsim_pre(hipStream_t st, NwkTileParams p)
     supers = (supers + 7) / 8 * 8;
     const long long grid = supers * 64;
     if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    if (strip) hipLaunchKernelGGL(nwk_maxsim_pre_strip_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
+    if (ring) hipLaunchKernelGGL(nwk_maxsim_pre_ring_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
+    else if (strip) hipLaunchKernelGGL(nwk_maxsim_pre_strip_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(nwk_maxsim_pre_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
     return hipGetLastError();
 }

@@ -46,6 +46,7 @@ struct NwkTileParams {
     int walk_q_fastest;            // 1: inside a super-tile the QUERY tile index runs fastest (consecutive blocks share a base tile), 0: the base tile index
     int tiles_per_wg;              // 16x16x32 kernel: consecutive base tiles a workgroup walks (strip); the launcher turns n_btiles into strips
     int n_btiles_real;             // filled in by the launcher: base tiles of this launch
+    int ms_ring;                   // MaxSim pre-screen, d <= 128: 1 = nwk_maxsim_pre_ring_kernel, 0 = nwk_maxsim_pre_strip_kernel (option "ms_ring")
 };
 
 struct NwkRescoreParams {
