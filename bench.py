@@ -224,7 +224,7 @@ def main():
                 "prescreen_searches": p_agg["prescreen"],
                 "roofline": {"bound": "mfma", "achieved": p_ach, "peak": MFMA_PEAK_TFLOPS["f16"], "unit": "TFLOP/s",
                              "frac": p_ach / MFMA_PEAK_TFLOPS["f16"],
-                             "kernel": "nwk_maxsim_pre_kernel" if maxsim else "nwk_tile_kernel_f16p<metric, PRE=1>",
+                             "kernel": "nwk_maxsim_pre_ring_kernel" if maxsim else "nwk_tile_kernel_f16p<metric, PRE=1>",
                              "traffic": recorded_traffic(args.workload + "_prescreen") if world == 1 else None,
                              "launches": max(p_agg["tile_launches"] - p_steps, 1),
                              "avg_launch_ms": p_agg["tile_ms"] / max(p_agg["tile_launches"] - p_steps, 1)},

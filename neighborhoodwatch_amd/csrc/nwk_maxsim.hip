@@ -20,6 +20,34 @@
 #define MS_DOCS_PER_TILE 4
 #define MS_QUERIES_PER_TILE 4
 
+// The token sum without LDS exchanges (round 2).  __shfl_xor is a ds_bpermute round trip; six of them in a row per (doc, query) pair,
+// four pairs per wave and tile, were as long as the fp16 tile's MFMAs.  One v_permlane32_swap gives every lane the max of the two
+// half-waves, four DPP adds (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror) produce lane for lane the values of the
+// xor-1,2,4,8 butterfly (fp32 addition is commutative, and after each level the groups being mirrored are uniform), and the last
+// level is lane 0's view of xor 16: row 0 + row 1.  The balanced pairwise tree of the canonical arithmetic, bit for bit.
+template <int CTRL>
+__device__ __forceinline__ float ms_dpp(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+
+// v: a lane's max over its 32 accumulator rows of one (doc, query-token column); lanes l and l ^ 32 hold the two halves of the doc's
+// 64 tokens.  Returns the sum over the 32 query tokens (lanes 0..31) of the max over the doc's tokens, wave-uniform.
+__device__ __forceinline__ float ms_token_sum(float v)
+{
+    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    // (elements copied to scalars first: __builtin_bit_cast(float, sw[1]) on the vector element reads element 0 with this clang)
+    const unsigned sw_lo = sw[0], sw_hi = sw[1];
+    float s = fmaxf(__builtin_bit_cast(float, sw_lo), __builtin_bit_cast(float, sw_hi));     // [lo, lo] vs [hi, hi]: every lane holds max(lo, hi)
+    s = __fadd_rn(s, ms_dpp<0xB1>(s));       // quad_perm [1,0,3,2]  == xor 1
+    s = __fadd_rn(s, ms_dpp<0x4E>(s));       // quad_perm [2,3,0,1]  == xor 2
+    s = __fadd_rn(s, ms_dpp<0x141>(s));      // row_half_mirror      == xor 4 (quads are uniform by now)
+    s = __fadd_rn(s, ms_dpp<0x140>(s));      // row_mirror           == xor 8
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 16));
+    return __fadd_rn(r0, r1);                // == xor 16 as lane 0 sees it
+}
+
 template <bool DENSE>
 __global__ __launch_bounds__(256, 2) void nwk_maxsim_kernel(const NwkTileParams p)
 {
@@ -116,12 +144,11 @@ __global__ __launch_bounds__(256, 2) void nwk_maxsim_kernel(const NwkTileParams 
         __builtin_amdgcn_s_barrier();
     }
 
-    // ---- epilogue: 2 docs x 2 queries per wave
+    // ---- epilogue: 2 docs x 2 queries per wave (the four max trees, then the four token sums, interleaved by the scheduler)
     const int cap = p.cap;
+    float tsum[2][2];
 #pragma unroll
-    for (int dd = 0; dd < 2; ++dd) {
-        const long long doc = (long long)tc.bt * MS_DOCS_PER_TILE + 2 * wr + dd;
-        const bool doc_ok = doc < p.nb_valid;
+    for (int dd = 0; dd < 2; ++dd)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             float v = acc[2 * dd][n][0];
@@ -129,12 +156,20 @@ __global__ __launch_bounds__(256, 2) void nwk_maxsim_kernel(const NwkTileParams 
             for (int r = 1; r < 16; ++r) v = fmaxf(v, acc[2 * dd][n][r]);
 #pragma unroll
             for (int r = 0; r < 16; ++r) v = fmaxf(v, acc[2 * dd + 1][n][r]);
-            v = fmaxf(v, __shfl_xor(v, 32));                 // the two half-waves hold the other 32 token rows of this doc
-            float sum = v;                                    // lane c32 = query token c32: balanced pairwise tree over tokens
+            tsum[dd][n] = v;                                  // the two half-waves hold the two halves of this doc's 64 token rows
+        }
 #pragma unroll
-            for (int o = 1; o < 32; o <<= 1) sum = __fadd_rn(sum, __shfl_xor(sum, o));
+    for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) tsum[dd][n] = ms_token_sum(tsum[dd][n]);     // balanced pairwise tree over the query's tokens
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd) {
+        const long long doc = (long long)tc.bt * MS_DOCS_PER_TILE + 2 * wr + dd;
+        const bool doc_ok = doc < p.nb_valid;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
             const long long q = q_first + n;
-            const u64 key = ((u64)sortable_u32(-sum) << 32) | (u32)doc;
+            const u64 key = ((u64)sortable_u32(-tsum[dd][n]) << 32) | (u32)doc;
             if (l == 0) {
                 if (DENSE) {
                     p.buf[q * cap + (doc - p.dense_col0)] = doc_ok ? key : ~0ull;
@@ -452,27 +487,6 @@ __global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_strip_kernel(const NwkT
 // LDS: the cross-half max is one v_permlane32_swap, the sum over the 32 query tokens four DPP adds (quad_perm [1,0,3,2], [2,3,0,1],
 // row_half_mirror, row_mirror: lane for lane the values of the xor-1,2,4,8 butterfly, fp32 addition being commutative) and two
 // v_readlane for the last level, the four pairs of a wave interleaved.  Same estimates, same keys as the strip kernel.
-template <int CTRL>
-__device__ __forceinline__ float ms_dpp(float x)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
-}
-
-// v: a lane's max over its 32 accumulator rows of one (doc, query-token column); lanes l and l ^ 32 hold the two halves of the doc's
-// 64 tokens.  Returns the sum over the 32 query tokens (lanes 0..31) of the max over the doc's tokens, wave-uniform.
-__device__ __forceinline__ float ms_token_sum(float v)
-{
-    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    float s = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));     // [lo, lo] vs [hi, hi]: every lane holds max(lo, hi)
-    s = __fadd_rn(s, ms_dpp<0xB1>(s));       // quad_perm [1,0,3,2]  == xor 1
-    s = __fadd_rn(s, ms_dpp<0x4E>(s));       // quad_perm [2,3,0,1]  == xor 2
-    s = __fadd_rn(s, ms_dpp<0x141>(s));      // row_half_mirror      == xor 4 (quads are uniform by now)
-    s = __fadd_rn(s, ms_dpp<0x140>(s));      // row_mirror           == xor 8
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 0));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 16));
-    return __fadd_rn(r0, r1);                // == xor 16 as lane 0 sees it
-}
-
 #define MS_RING_MAX_STRIP 64
 
 __global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_ring_kernel(const NwkTileParams p)
@@ -574,7 +588,7 @@ __global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_ring_kernel(const NwkTi
             // the previous slab are done; behind the barrier that holds for every wave, so the previous slab's stage can be refilled
             asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            issue_next();
+            if (!(p.ms_ring & 2)) issue_next();      // dev ablation (ms_ring = 3): no document stream inside the loop, timing only
             const char* sb = smem + st * SLAB;
             st = (st + 1) & (RING - 1);
 #pragma unroll
@@ -590,6 +604,7 @@ __global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_ring_kernel(const NwkTi
             }
         }
         // ---- epilogue of tile t (the requests of the next three slabs are in flight): 2 docs x 2 queries per wave
+        if ((p.ms_ring & 4) && t + 1 < n_here) continue;      // dev ablation (ms_ring = 5): only the strip's last tile has an epilogue, timing only
         const float* cd_s = (const float*)(smem + OFF_CD) + t * MS_DOCS_PER_TILE + 2 * wr;
         float score[2][2];
 #pragma unroll
@@ -846,10 +861,7 @@ __global__ __launch_bounds__(256) void nwk_maxsim_rescore_mfma_kernel(const NwkM
         for (int r = 1; r < 16; ++r) v = fmaxf(v, acc0[r]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) v = fmaxf(v, acc1[r]);
-        v = fmaxf(v, __shfl_xor(v, 32));                             // the other half-wave holds the other 32 token rows of the doc
-        float sum = v;                                               // lane c32 = query token c32: the kernel's pairwise tree
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) sum = __fadd_rn(sum, __shfl_xor(sum, o));
+        const float sum = ms_token_sum(v);                           // max over the two half-waves, then the kernel's pairwise tree over the 32 query tokens
         if (lane == 0) list[e] = ((u64)sortable_u32(-sum) << 32) | doc;
     }
 }
@@ -884,7 +896,10 @@ hipError_t nwk_launch_maxsim_pre(hipStream_t st, NwkTileParams p)
     const bool strip = p.dp <= 128 && p.tiles_per_wg != 1;      // d <= 128: query fragments fit the registers (tiles_per_wg = 1: the plain kernel)
     const bool ring = strip && p.ms_ring;                       // four-stage document ring, one barrier per slab, DPP epilogue (the default)
     if (strip) {
-        if (p.tiles_per_wg < 1) p.tiles_per_wg = 8;
+        if (p.tiles_per_wg < 1) {                               // auto (option ms_strip = 0): the ring form likes long strips (64: +3 % over 8 on
+            p.tiles_per_wg = ring ? MS_RING_MAX_STRIP : 8;      // C5) as long as the launch still has a few workgroups for each of the 512 slots
+            while (ring && p.tiles_per_wg > 8 && (long long)((p.n_btiles + p.tiles_per_wg - 1) / p.tiles_per_wg) * p.n_qtiles < 2048) p.tiles_per_wg >>= 1;
+        }
         if (ring && p.tiles_per_wg > MS_RING_MAX_STRIP) p.tiles_per_wg = MS_RING_MAX_STRIP;
         p.n_btiles_real = p.n_btiles;
         p.n_btiles = (p.n_btiles + p.tiles_per_wg - 1) / p.tiles_per_wg;

@@ -114,7 +114,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 8, opt_ms_rescore_valu = 0, opt_ms_ring = 1;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_rescore_valu = 0, opt_ms_ring = 1;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -291,10 +291,11 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
     } else if (!strcmp(name, "ms_rescore_valu")) {
         h->opt_ms_rescore_valu = value ? 1 : 0;   // MaxSim rescoring on the vector pipes (round-1 kernel) instead of the matrix pipes
     } else if (!strcmp(name, "ms_ring")) {
-        h->opt_ms_ring = value ? 1 : 0;     // MaxSim pre-screen, d <= 128: the ring form of the strip kernel (default) or the round-2a strip kernel
+        if (value < 0 || value > 7) return fail(NWKNN_EINVAL, "ms_ring must be 0..7");
+        h->opt_ms_ring = value;             // MaxSim pre-screen, d <= 128: 1 the ring form of the strip kernel (default), 0 the round-2a strip kernel; dev: +2 / +4 = timing ablations of the ring kernel without its document stream / its epilogues (wrong results)
     } else if (!strcmp(name, "ms_strip")) {
-        if (value < 1 || value > 64) return fail(NWKNN_EINVAL, "ms_strip must be 1..64");
-        h->opt_ms_strip = value;            // MaxSim pre-screen, d <= 128: document tiles a workgroup walks per query group (1: the plain kernel)
+        if (value < 0 || value > 64) return fail(NWKNN_EINVAL, "ms_strip must be 0..64");
+        h->opt_ms_strip = value;            // MaxSim pre-screen, d <= 128: document tiles a workgroup walks per query group (0: auto, 1: the plain kernel)
     } else if (!strcmp(name, "upload_threads")) {
         if (value < 1 || value > 64) return fail(NWKNN_EINVAL, "upload_threads must be 1..64");
         h->opt_upload_threads = value;      // host threads that gather column slabs into the pinned upload buffers
