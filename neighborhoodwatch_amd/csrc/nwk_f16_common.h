@@ -34,15 +34,42 @@ __device__ __forceinline__ void flush_survivors(const NwkTileParams& p, LDS_AS c
     for (u32 e = (u32)tid; e < n; e += (u32)nthreads) append_direct(p, q0 + s_row[e], s_key[e]);
 }
 
+// Pre-screen, first pass over a finished tile (round 2): which of the wave's eight 16-row blocks can hold a survivor at all?
+// The exact test of a block (below) costs an LDS round trip for its four row terms, ~33 VALU and a branch, eight times in a row with
+// nothing to hide them behind -- ~3.4k cycles per tile while the matrix pipes idle.  A pair passes when acc >= row(q) + col(b); with
+// pmin[m] = min of the block's four row terms (the query tile is the same for the whole strip: eight registers, loaded once) and
+// cmin = min of the lane's four column terms,  fl(pmin + cmin) <= fl(row + col)  for every element of the block (rounded addition
+// is monotone), so "max of the block's 16 accumulators >= pmin + cmin" holds whenever any of them passes: 8 v_max3, one add and
+// one compare per block, no LDS, no branch.  The blocks it flags (a few percent) go through the exact test as before.
+__device__ __forceinline__ u32 prescreen_block_mask(const f32x4 (&acc)[8][4], const float (&pmin)[8], float cmin)
+{
+    u32 fired = 0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        float mx = fmaxf(acc[m][0][0], acc[m][0][1]);
+        mx = fmaxf(fmaxf(mx, acc[m][0][2]), acc[m][0][3]);
+#pragma unroll
+        for (int n = 1; n < 4; ++n) {
+            mx = fmaxf(fmaxf(mx, acc[m][n][0]), acc[m][n][1]);
+            mx = fmaxf(fmaxf(mx, acc[m][n][2]), acc[m][n][3]);
+        }
+        const bool f = !(mx < pmin[m] + cmin);                       // NaN (an infinite row term meeting an infinite column term) flags the block
+        if (__ballot(f)) fired |= 1u << m;
+    }
+    return fired;
+}
+
 template <int METRIC, bool DENSE, int PRE, int SC = 0>
 __device__ __forceinline__ void tile_epilogue16(const NwkTileParams& p, const f32x4 (&acc)[8][4], const float* s_qn, const u64* s_tau,
                                                 const float* s_pre, const float (&bnv)[4], const u32 (&colv)[4], const bool (&colok)[4],
                                                 const float (&cpre)[4], long long q0, int wrow0, int g, int c16,
-                                                LDS_AS u32* s_cnt = nullptr, LDS_AS u64* s_key = nullptr, LDS_AS u32* s_row = nullptr)
+                                                LDS_AS u32* s_cnt = nullptr, LDS_AS u64* s_key = nullptr, LDS_AS u32* s_row = nullptr,
+                                                u32 block_mask = 0xFFu)
 {
     const int cap = p.cap;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
+        if (!((block_mask >> m) & 1u)) continue;                     // wave-uniform: prescreen_block_mask cleared this block
         const int rb = wrow0 + m * 16 + 4 * g;                       // this lane's four query rows: rb .. rb+3
         if (DENSE) {
             const f32x4 qn4 = *(const f32x4*)(s_qn + rb);

@@ -141,6 +141,15 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16p(const NwkTilePara
     zero_acc();
     asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory");  // A-quarter 0 and B of slab 0 have landed (behind B3: A3, N and slab 1's nine)
     __builtin_amdgcn_s_barrier();
+    float pmin[8];                                                // pre-screen: smallest row term of each of this wave's 16-row blocks (prescreen_block_mask)
+    if (PRE) {
+        const float* s_pre = (const float*)(epi + H_TM * 12);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const f32x4 r4 = *(const f32x4*)(s_pre + wr * 128 + m * 16 + 4 * g);
+            pmin[m] = fminf(fminf(r4[0], r4[1]), fminf(r4[2], r4[3]));
+        }
+    }
     read_A(0, 0, 0);
     read_B(0, 0);
 
@@ -203,8 +212,11 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16p(const NwkTilePara
             int g_here = g, c_here = c16;                           // opaque per tile (see nwk_tile_kernel_f16s)
             asm volatile("" : "+v"(g_here));
             asm volatile("" : "+v"(c_here));
-            tile_epilogue16<METRIC, false, PRE, SC>(p, acc, (const float*)epi, (const u64*)(epi + H_TM * 4), (const float*)(epi + H_TM * 12), bnv,
-                                                    colv, colok, cpre, q0, wr * 128, g_here, c_here, s_cnt, s_key, s_row);
+            u32 blocks = 0xFFu;
+            if (PRE) blocks = prescreen_block_mask(acc, pmin, fminf(fminf(cpre[0], cpre[1]), fminf(cpre[2], cpre[3])));
+            if (blocks)
+                tile_epilogue16<METRIC, false, PRE, SC>(p, acc, (const float*)epi, (const u64*)(epi + H_TM * 4), (const float*)(epi + H_TM * 12), bnv,
+                                                        colv, colok, cpre, q0, wr * 128, g_here, c_here, s_cnt, s_key, s_row, blocks);
         }
         ++t; kt = 0;
         if (S + 1 < NS) {
