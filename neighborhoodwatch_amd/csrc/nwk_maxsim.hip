@@ -642,6 +642,177 @@ __global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_ring_kernel(const NwkTi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the workgroup leaves
 }
 
+// The ring kernel on v_mfma_f32_16x16x32_f16 (option ms_mfma = 1).  Under this kernel the chip holds only ~1.7 GHz (PMC: profiles/
+// r02e_c5_pmc_summary.json), and in that power-limited regime the 16x16x32 shape delivers more FLOP/s than 32x32x16 at equal cycles
+// (MI355X_MICROARCH.md, DVFS give-back item 7; the kNN fp16 tile kernel gained 5 % from the same switch).  Same workgroup tile, same LDS
+// image, ring, waits and barriers; a 32-half slab is ONE k-step: 8 row blocks x 4 column blocks = 32 MFMAs per wave and slab.
+// Accumulator layout: lane l holds D[4 (l / 16) + i][l % 16] -- a doc's 64 token rows are 4 row blocks x 4 registers in-lane and the four
+// 16-lane rows of the wave, so the max over a doc is 15 in-lane v_max, one v_permlane16_swap (rows 0|1, 2|3) and one
+// v_permlane32_swap (halves); the sum over a query's 32 tokens is one in-lane add of its two column blocks and the four DPP adds over
+// the 16 lanes of a row.  (The token sum's association differs from the canonical tree here -- block c | c + 16 first -- which an
+// ESTIMATE may do: the bound carries 33 ulps of the sum of norms for exactly that.)
+__device__ __forceinline__ float ms_rows_max(float v)      // max over the wave's four 16-lane rows, in every lane
+{
+    const auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    const unsigned a0 = a[0], a1 = a[1];                     // [r0 r0 r2 r2] | [r1 r1 r3 r3]   (scalars first: see ms_token_sum)
+    const float m1 = fmaxf(__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1));
+    const auto b = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m1), __builtin_bit_cast(unsigned, m1), false, false);
+    const unsigned b0 = b[0], b1 = b[1];
+    return fmaxf(__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1));
+}
+
+__global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_ring16_kernel(const NwkTileParams p)
+{
+    constexpr int TM = 256, TQ = 128, NK = 4, SLAB = TM * 64, RING = 4, B_SLAB = TQ * 64;      // 32-half slabs of 64-B rows
+    constexpr int OFF_CD = RING * SLAB;
+    __shared__ __attribute__((aligned(16))) char smem[OFF_CD + MS_RING_MAX_STRIP * MS_DOCS_PER_TILE * 4];
+
+    const TileCoord tc = tile_from_block(p);         // tc.qt: group of 4 queries, tc.bt: STRIP of document tiles
+    if (!tc.ok) return;
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, l = tid & 63;
+    const int wr = w >> 1, wc = w & 1;
+    const int g = l >> 4, c16 = l & 15;
+    const int T = p.tiles_per_wg > 1 ? p.tiles_per_wg : 1;         // <= MS_RING_MAX_STRIP (launcher)
+    const int bt_first = p.bt0 + (tc.bt - p.bt0) * T;
+    int n_here = p.bt0 + p.n_btiles_real - bt_first;
+    if (n_here > T) n_here = T;
+    const long long qrow0 = (long long)tc.qt * TQ;
+    const int dp = p.dp;                             // halves per row: 32 * nk, nk <= NK
+    const int nk = dp / 32;
+    const _Float16* docs = (const _Float16*)p.bp;
+    const _Float16* qrys = (const _Float16*)p.qp;
+
+    const unsigned voff = (unsigned)((l >> 2) * dp * 2 + (((l & 3) ^ ((0 - (l >> 4)) & 3)) << 4));      // the ring kernel's LDS image
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(qrys + qrow0 * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int rowsA = wu * 64 * dp * 2, rowsB = wu * 32 * dp * 2, step16 = 16 * dp * 2;
+    // fragment of a 16-row block: lane l reads row l % 16, k = 8 (l / 16) .. + 7 = the row's 16-B chunk l / 16, stored in slot chunk ^ swizzle(row)
+    const int swz = (0 - (c16 >> 2)) & 3;
+    const int offA0 = (wr * 128 + c16) * 64 + ((g ^ swz) << 4);      // + 1024 m
+    const int offB0 = (wc * 64 + c16) * 64 + ((g ^ swz) << 4);       // + 1024 n
+
+    for (int kt = 0; kt < nk; ++kt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(smem + kt * B_SLAB + wu * 2048 + i * 1024), 16, voff,
+                                                     kt * 64 + rowsB + i * step16, 0, 0);
+    const long long q_first = (long long)tc.qt * MS_QUERIES_PER_TILE + 2 * wc;
+    const u64 tauq[2] = {p.tau[q_first], p.tau[q_first + 1]};
+    const float rq[2] = {p.ms_rq[q_first], p.ms_rq[q_first + 1]};
+    float cd_mine = 0.0f;
+    {
+        const long long doc = (long long)bt_first * MS_DOCS_PER_TILE + tid;
+        if (tid < n_here * MS_DOCS_PER_TILE && doc < p.nb_valid) cd_mine = p.ms_cd[doc];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ((float*)(smem + OFF_CD))[tid] = cd_mine;
+    __builtin_amdgcn_s_barrier();
+    f16x8 bq[NK][4];
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            bq[kt][n] = (kt < nk) ? *(const f16x8*)(smem + kt * B_SLAB + offB0 + n * 1024) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    float ntd[2], atd[2];
+    bool open_[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        open_[n] = tauq[n] == ~0ull;
+        const float td = unsortable_f32((u32)(tauq[n] >> 32));
+        ntd[n] = -td; atd[n] = fabsf(td);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(docs + (long long)bt_first * TM * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const int NS = n_here * nk;
+    const int tile_bytes = TM * dp * 2;
+    int it = 0, ik = 0, ist = 0;
+    auto issue_next = [&]() {
+        const int soff = it * tile_bytes + ik * 64 + rowsA;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(smem + ist * SLAB + wu * 4096 + i * 1024), 16, voff, soff + i * step16, 0, 0);
+        ist = (ist + 1) & (RING - 1);
+        if (it * nk + ik + 1 < NS) { if (++ik == nk) { ik = 0; ++it; } }
+    };
+    issue_next(); issue_next(); issue_next();
+
+    const int cap = p.cap;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    int st = 0;
+    for (int t = 0; t < n_here; ++t) {
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+            if (kt >= nk) break;
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue_next();
+            const char* sb = smem + st * SLAB;
+            st = (st + 1) & (RING - 1);
+            f16x8 a[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) a[m] = *(const f16x8*)(sb + offA0 + m * 1024);
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], bq[kt][n], kt == 0 ? zero4 : acc[m][n], 0, 0, 0);
+        }
+        // ---- epilogue of tile t: 2 docs (row blocks 4 dd .. 4 dd + 3) x 2 queries (column blocks 2 qn, 2 qn + 1) per wave
+        const float* cd_s = (const float*)(smem + OFF_CD) + t * MS_DOCS_PER_TILE + 2 * wr;
+        float vmx[2][4];
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                float v = fmaxf(acc[4 * dd][n][0], acc[4 * dd][n][1]);
+                v = fmaxf(fmaxf(v, acc[4 * dd][n][2]), acc[4 * dd][n][3]);
+#pragma unroll
+                for (int m = 1; m < 4; ++m) {
+                    v = fmaxf(fmaxf(v, acc[4 * dd + m][n][0]), acc[4 * dd + m][n][1]);
+                    v = fmaxf(fmaxf(v, acc[4 * dd + m][n][2]), acc[4 * dd + m][n][3]);
+                }
+                vmx[dd][n] = v;
+            }
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) vmx[dd][n] = ms_rows_max(vmx[dd][n]);
+        float score[2][2];
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn) {
+                float s = __fadd_rn(vmx[dd][2 * qn], vmx[dd][2 * qn + 1]);      // tokens c and c + 16
+                s = __fadd_rn(s, ms_dpp<0xB1>(s));
+                s = __fadd_rn(s, ms_dpp<0x4E>(s));
+                s = __fadd_rn(s, ms_dpp<0x141>(s));
+                s = __fadd_rn(s, ms_dpp<0x140>(s));
+                score[dd][qn] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 0)) * p.pre_inv_scale;
+            }
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd) {
+            const long long doc = (long long)(bt_first + t) * MS_DOCS_PER_TILE + 2 * wr + dd;
+            const bool doc_ok = doc < p.nb_valid;
+            const float cd = cd_s[dd];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const long long q = q_first + n;
+                const float err = rq[n] + cd;
+                const bool pass = open_[n] || !(score[dd][n] < ntd[n] - err - 2.0e-6f * (atd[n] + err));
+                if (pass && doc_ok && q < p.nq_valid && l == 0) {
+                    const u32 pos = atomicAdd(p.cnt + q, 1u);
+                    if (pos < (u32)cap) p.buf[q * cap + pos] = ((u64)__float_as_uint(-score[dd][n]) << 32) | (u32)doc;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the workgroup leaves
+}
+
 // Rescoring in two launches.  (1) nwk_maxsim_prune_kernel, one wave per query: bounds est +- (R(q) + C(doc)) of the listed pairs,
 // k-th smallest upper bound by bisection, pairs that cannot reach the top k become ~0, the slots of the others go to surv[q][.].
 // (2) nwk_maxsim_rescore_kernel, grid (queries, slices): a wave takes every slices-th survivor of its query, two at a time (each
@@ -911,7 +1082,8 @@ hipError_t nwk_launch_maxsim_pre(hipStream_t st, NwkTileParams p)
     supers = (supers + 7) / 8 * 8;
     const long long grid = supers * 64;
     if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    if (ring) hipLaunchKernelGGL(nwk_maxsim_pre_ring_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
+    if (ring && p.f16_shape == 1) hipLaunchKernelGGL(nwk_maxsim_pre_ring16_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
+    else if (ring) hipLaunchKernelGGL(nwk_maxsim_pre_ring_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
     else if (strip) hipLaunchKernelGGL(nwk_maxsim_pre_strip_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(nwk_maxsim_pre_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
     return hipGetLastError();

@@ -114,7 +114,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_rescore_valu = 0, opt_ms_ring = 1;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_rescore_valu = 0, opt_ms_ring = 1, opt_ms_mfma = 1;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -290,6 +290,9 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
         h->opt_chunk_growth = value;        // a filtered chunk holds up to chunk_growth x the rows seen so far (1: chunks double)
     } else if (!strcmp(name, "ms_rescore_valu")) {
         h->opt_ms_rescore_valu = value ? 1 : 0;   // MaxSim rescoring on the vector pipes (round-1 kernel) instead of the matrix pipes
+    } else if (!strcmp(name, "ms_mfma")) {
+        if (value != 0 && value != 1) return fail(NWKNN_EINVAL, "ms_mfma must be 0 (32x32x16) or 1 (16x16x32)");
+        h->opt_ms_mfma = value;             // MaxSim ring kernel: MFMA shape (1: v_mfma_f32_16x16x32_f16, holds a higher clock under load)
     } else if (!strcmp(name, "ms_ring")) {
         if (value < 0 || value > 7) return fail(NWKNN_EINVAL, "ms_ring must be 0..7");
         h->opt_ms_ring = value;             // MaxSim pre-screen, d <= 128: 1 the ring form of the strip kernel (default), 0 the round-2a strip kernel; dev: +2 / +4 = timing ablations of the ring kernel without its document stream / its epilogues (wrong results)
@@ -1065,7 +1068,7 @@ static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq
     tp.n_qtiles = (int)(nq_pad / 4); tp.bt0 = (int)(doc_lo / 4); tp.n_btiles = (int)(docs / 4);
     tp.dp = h->dp; tp.cap = cap; tp.sq_shift = h->opt_sq_shift >= 0 ? (int)h->opt_sq_shift : 3; tp.walk_q_fastest = h->opt_walk_q > 0 ? 1 : 0;
     const bool prescreen = pre && !dense;                // the dense first chunk runs the fp32 kernel (exact keys)
-    tp.tiles_per_wg = (int)h->opt_ms_strip; tp.ms_ring = (int)h->opt_ms_ring;
+    tp.tiles_per_wg = (int)h->opt_ms_strip; tp.ms_ring = (int)h->opt_ms_ring; tp.f16_shape = (int)h->opt_ms_mfma;
     EvPair* e = ev_begin(h, 0);
     if (prescreen) {
         // the ring kernel streams documents only (the query fragments live in registers): the more query groups of an XCD walk the same
