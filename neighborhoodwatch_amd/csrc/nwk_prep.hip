@@ -59,8 +59,8 @@ __global__ __launch_bounds__(256) void nwk_prep_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------------
 // prep, tiled form (the default for row-major input): a lane-per-row kernel touches 64 different rows per load
 // instruction, 16 B from each, i.e. four requests per 64-B granule (2 TB/s on fp32, 0.9 TB/s on fp16).  Here a block owns
-// 256 rows and walks K in 64-byte steps: every global load and store instruction moves whole 64-B row segments (four lanes
-// per row), the row <-> lane transposition goes through LDS (80-B row pitch: conflict-free for ds_read/write_b128), and the
+// 256 rows and walks K in 128-byte steps: every global load and store instruction moves whole 128-B lines (eight lanes
+// per row; round 1: 64-B segments), the row <-> lane transposition goes through LDS (144-B row pitch: conflict-free for ds_read/write_b128), and the
 // lane that owns a row still runs the norm chain in ascending k, so the results are bit-identical to nwk_prep_kernel.
 // TIN = float | _Float16; OUT16 selects the fp16 layout.  Requires a 16-B aligned source and d*sizeof(TIN) % 16 == 0.
 // ------------------------------------------------------------------------------------------------
@@ -70,12 +70,16 @@ template <typename TIN, bool OUT16>
 __global__ __launch_bounds__(256) void nwk_prep_tiled_kernel(const TIN* __restrict__ raw, long long rows, int d, long long rows_pad, int dp,
                                                               void* __restrict__ prepared, float* __restrict__ norms)
 {
+    // round 2: a step moves 128 B of input per row (was 64): every global access is now a whole 128-B line (eight lanes per row), and
+    // the next step's lines are requested one step ahead (registers) so that they fly under the LDS passes and the stores of this one
+    constexpr int SEGS = 8;                               // 16-B pieces of input per row per step
     constexpr int EIN = 16 / (int)sizeof(TIN);            // elements per 16-B piece of input
-    constexpr int KS = 4 * EIN;                           // elements per step (64 B of input per row)
+    constexpr int KS = SEGS * EIN;                        // elements per step: 32 (float) / 64 (fp16)
     constexpr int OES = OUT16 ? 2 : 4;                    // output element size
-    constexpr int OB = KS * OES;                          // output bytes per row per step: 64 (f32->f32, f16->f16) or 32 (f32->f16)
+    constexpr int OB = KS * OES;                          // output bytes per row per step: 128 (f32->f32, f16->f16) or 64 (f32->f16)
     constexpr int OP = OB / 16;                           // 16-B output pieces per row per step
-    constexpr int PITCH = 80;
+    constexpr int PITCH = 144;                            // 128 + 16: lane-per-row ds_read_b128 / ds_write_b128 stay conflict-free
+    constexpr int RPP = 256 / SEGS;                       // rows per load pass
     __shared__ __attribute__((aligned(16))) char tile_in[256 * PITCH];
     __shared__ __attribute__((aligned(16))) char tile_out[256 * PITCH];
 
@@ -85,28 +89,36 @@ __global__ __launch_bounds__(256) void nwk_prep_tiled_kernel(const TIN* __restri
     const size_t out_row_bytes = (size_t)dp * OES;
     float acc = 0.0f;
 
-    for (int k0 = 0; k0 < dp; k0 += KS) {
-        // load: 4 lanes per row, 64 rows per pass
+    u32x4 v[SEGS];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int row = pass * 64 + (tid >> 2), seg = tid & 3;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (r0 + row < rows && k0 + seg * EIN < d)
-                v = *(const u32x4*)((const char*)raw + (size_t)(r0 + row) * in_row_bytes + (size_t)k0 * sizeof(TIN) + seg * 16);
-            *(u32x4*)(tile_in + row * PITCH + seg * 16) = v;
+        for (int pass = 0; pass < SEGS; ++pass) {
+            const int row = pass * RPP + (tid / SEGS), seg = tid % SEGS;
+            v[pass] = (u32x4){0u, 0u, 0u, 0u};
+            if (k0 < dp && r0 + row < rows && k0 + seg * EIN < d)
+                v[pass] = *(const u32x4*)((const char*)raw + (size_t)(r0 + row) * in_row_bytes + (size_t)k0 * sizeof(TIN) + seg * 16);
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < dp; k0 += KS) {
+#pragma unroll
+        for (int pass = 0; pass < SEGS; ++pass) {
+            const int row = pass * RPP + (tid / SEGS), seg = tid % SEGS;
+            *(u32x4*)(tile_in + row * PITCH + seg * 16) = v[pass];
         }
         __syncthreads();
+        fetch(k0 + KS);                                   // next step's lines: requested now, consumed after this step's stores
         // the lane that owns row `tid`: ascending-k norm chain + output layout for this step
         {
             float x[KS];
 #pragma unroll
-            for (int piece = 0; piece < 4; ++piece) {
-                const u32x4 v = *(const u32x4*)(tile_in + tid * PITCH + piece * 16);
+            for (int piece = 0; piece < SEGS; ++piece) {
+                const u32x4 pv = *(const u32x4*)(tile_in + tid * PITCH + piece * 16);
                 if (sizeof(TIN) == 4) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) x[piece * EIN + j] = __uint_as_float(v[j]);
+                    for (int j = 0; j < 4; ++j) x[piece * EIN + j] = __uint_as_float(pv[j]);
                 } else {
-                    const f16x8 hv = __builtin_bit_cast(f16x8, v);
+                    const f16x8 hv = __builtin_bit_cast(f16x8, pv);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) x[piece * EIN + j] = (float)hv[j];
                 }
