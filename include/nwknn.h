@@ -98,7 +98,10 @@ int nwknn_set_stream(nwknn_handle h, void* hip_stream);
  * "f16_mfma" (fp16 tile kernel build: -1 = auto, default: 3 up to 2048 halves per row, else 1; 3 = v_mfma_f32_16x16x32_f16 streaming
  * form; 1 = the same MFMA, one burst of LDS-DMA per slab; 0 = 32x32x16; 2 = two 4-wave workgroups per CU),
  * "tile_occ" (workgroups per CU of the fp32 tile kernel, 3 default | 2), "chunk_growth" (0 = auto), "super_q_shift" / "super_walk_q"
- * (shape and walk order of an XCD's super-tile), "upload_threads" (host threads of the column upload pipeline, default 8). */
+ * (shape and walk order of an XCD's super-tile), "upload_threads" (host threads of the column upload pipeline, default 8),
+ * MaxSim pre-screen tile kernel, d <= 128: "ms_ring" (1 default: four-stage document ring; 0: the two-stage strip kernel), "ms_mfma"
+ * (1 default: v_mfma_f32_16x16x32_f16; 0: 32x32x16), "ms_strip" (document tiles per workgroup: 0 = auto, 1 = the plain kernel),
+ * "ms_rescore_valu" (1: rescoring on the vector pipes). */
 int nwknn_set_option(nwknn_handle h, const char* name, int64_t value);
 int nwknn_get_stats(nwknn_handle h, nwknn_stats* out);
 /* Wait for everything queued on the handle's stream. */
