@@ -86,7 +86,7 @@ int nwknn_destroy(nwknn_handle h);
  * restores the handle's own stream. */
 int nwknn_set_stream(nwknn_handle h, void* hip_stream);
 /* Tunables: "capacity" (candidate slots per query, power of two >= 4k), "first_chunk", "max_chunk"
- * (base rows per launch, multiples of 128), "profile" (0/1: per-kernel HIP-event timing into nwknn_stats),
+ * (base rows per launch, multiples of 128; MaxSim: a quarter of it in documents), "profile" (0/1: per-kernel HIP-event timing into nwknn_stats),
  * "compute_dtype" (NWKNN_DTYPE_F32 | NWKNN_DTYPE_F16: with F16 the next nwknn_set_base rounds fp32 input to fp16 and
  * distance tiles run on the fp16 MFMA path with fp32 accumulation), "tile_rows" (0 auto | 128 | 256, fp32 path),
  * "prescreen" (0/1, fp32 compute path, all three metrics: the next nwknn_set_base also keeps a scaled fp16 copy of

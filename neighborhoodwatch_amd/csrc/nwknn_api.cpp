@@ -1181,7 +1181,10 @@ static int maxsim_search_impl(nwknn_handle h, const void* query_tokens, int64_t 
     HIPCHK(hipMemsetAsync(h->ovf_any.p, 0, 4, h->stream));
 
     const long long docs_pad = h->nb_pad / NWK_MS_TOKENS_PER_DOC;           // multiple of 4
-    const long long max_chunk = std::max<long long>(4, (h->opt_max_chunk / NWK_MS_TOKENS_PER_DOC) / 4 * 4);
+    // largest chunk: option max_chunk / 4 documents (2^18 by default; round 2a: max_chunk token rows = 2^14 documents, 65 launches per C5
+    // search instead of 11: +3 %, tools/ms_chunk_sweep.py), bounded so that document tiles x query groups stays a legal grid
+    long long max_chunk = std::max<long long>(4, (h->opt_max_chunk / 4) / 4 * 4);
+    max_chunk = std::max<long long>(4, std::min<long long>(max_chunk, ((1ll << 30) / std::max<long long>(1, nq_pad / 4)) / 4 * 4 * 4));
     long long first = h->opt_first_chunk ? round_up(h->opt_first_chunk, 4) : cap / 2;
     first = std::min<long long>(std::max<long long>(first, round_up(k, 4)), cap / 4 * 4);
     long long seen = std::min(docs_pad, first);
