@@ -1184,7 +1184,12 @@ static int maxsim_search_impl(nwknn_handle h, const void* query_tokens, int64_t 
     // largest chunk: option max_chunk / 4 documents (2^18 by default; round 2a: max_chunk token rows = 2^14 documents, 65 launches per C5
     // search instead of 11: +3 %, tools/ms_chunk_sweep.py), bounded so that document tiles x query groups stays a legal grid
     long long max_chunk = std::max<long long>(4, (h->opt_max_chunk / 4) / 4 * 4);
-    max_chunk = std::max<long long>(4, std::min<long long>(max_chunk, ((1ll << 30) / std::max<long long>(1, nq_pad / 4)) / 4 * 4 * 4));
+    {   // HIP refuses launches of 2^32 threads or more: workgroups (256 threads) <= 2^23.  The fp32 and the plain pre-screen kernel take one
+        // document tile per workgroup, the strip / ring kernels at least 8 (the launcher's shortest automatic strip)
+        const long long tiles_per_wg = (pre && h->dp16 <= 128 && h->opt_ms_strip != 1) ? (h->opt_ms_strip > 1 ? h->opt_ms_strip : 8) : 1;
+        const long long wg_budget = (1ll << 23) / std::max<long long>(1, round_up(nq_pad / 4, 64));      // per query group, super-tile padding included
+        max_chunk = std::max<long long>(4, std::min<long long>(max_chunk, wg_budget * tiles_per_wg / 2 * 4));
+    }
     long long first = h->opt_first_chunk ? round_up(h->opt_first_chunk, 4) : cap / 2;
     first = std::min<long long>(std::max<long long>(first, round_up(k, 4)), cap / 4 * 4);
     long long seen = std::min(docs_pad, first);
