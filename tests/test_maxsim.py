@@ -128,3 +128,23 @@ def test_hip_maxsim_prescreen_kernel_forms_give_the_same_bits(oracle, ring, stri
         rs, ri = oracle.maxsim_canonical(docs, qs, k)
         assert np.array_equal(i, ri), f"doc ids differ at {(i != ri).sum()} of {i.size} positions (ring={ring}, strip={strip}, mfma={mfma}, d={d})"
         assert np.array_equal(s.view(np.uint32), rs.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_hip_maxsim_many_queries_chunks_stay_launchable():
+    """70 000 queries are 17 500 query groups: a chunk of document tiles x query groups must stay under HIP's 2^32 threads per
+    launch (the chunk walk bounds its chunks per kernel form); direct and pre-screened results agree bit for bit."""
+    import torch
+    from neighborhoodwatch_amd import KnnEngine
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    docs = torch.randn((9000, 64, 128), device="cuda", generator=g)
+    qs = torch.randn((70_000, 32, 128), device="cuda", generator=g)
+    res = []
+    for pre in (False, True):
+        with KnnEngine(0, profile=True) as eng:
+            eng.set_prescreen(pre)
+            eng.maxsim_set_docs(docs)
+            s, i = eng.maxsim_search(qs, 10)
+            assert eng.stats()["prescreen"] == int(pre)
+            res.append((s.clone(), i.clone()))
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][0], res[1][0])
