@@ -721,9 +721,20 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         if (pl.copies16) { tp.qp = h->qp16.as<float>(); tp.bp = h->bp16.as<float>(); tp.dp = h->dp16; }
         tp.pre_inv_scale = 1.0f / pl.pre_scale;
         tp.pre_scale = pl.pre_scale; tp.pre_eps_half = pl.pre_eps_half; tp.pre_aq = pl.pre_aq; tp.pre_ab = pl.pre_ab; tp.pre_cst = pl.pre_cst;
-        HIPCHK(nwk_launch_tile_prescreen(h->stream, tp, metric, dense));
-    } else if (h->f16) HIPCHK(nwk_launch_tile_f16(h->stream, tp, metric, dense, (int)h->opt_diag));
-    else HIPCHK(nwk_launch_tile(h->stream, tp, metric, dense, pl.tile_rows, (int)h->opt_diag, (int)h->opt_tile_occ));
+    }
+    {   // HIP refuses a launch of 2^32 threads or more.  A chunk of very many query tiles x base tiles (hundreds of thousands of queries)
+        // goes out as several launches over consecutive base-tile ranges: same thresholds, same lists, so the same result
+        const long long per_launch = std::max<long long>(64, (NWK_MAX_WORKGROUPS_PER_LAUNCH / round_up(std::max(1, tp.n_qtiles), 64)) / 64 * 64);
+        const int bt_first = tp.bt0, bt_total = tp.n_btiles;
+        for (long long done = 0; done < bt_total; done += per_launch) {
+            tp.bt0 = bt_first + (int)done;
+            tp.n_btiles = (int)std::min<long long>(per_launch, bt_total - done);
+            if (prescreen) HIPCHK(nwk_launch_tile_prescreen(h->stream, tp, metric, dense));
+            else if (h->f16) HIPCHK(nwk_launch_tile_f16(h->stream, tp, metric, dense, (int)h->opt_diag));
+            else HIPCHK(nwk_launch_tile(h->stream, tp, metric, dense, pl.tile_rows, (int)h->opt_diag, (int)h->opt_tile_occ));
+        }
+        tp.bt0 = bt_first; tp.n_btiles = bt_total;
+    }
     ev_end(h, e);
     if (prescreen) {                                       // listed pairs -> canonical fp32 keys, in place
         if (dense) {                                       // (exact fp16 mode) every slot of the dense chunk is a candidate: [0, rows)

@@ -11,6 +11,7 @@
 #define NWK_QPAD_ROWS 256          // query-side arrays are padded to this (the larger query tile)
 #define NWK_K_ALIGN 32             // prepared fp32 rows are zero padded to a multiple of this many floats
 #define NWK_K_ALIGN_F16 64         // prepared fp16 rows: multiple of this many halves
+#define NWK_MAX_WORKGROUPS_PER_LAUNCH (1ll << 22)   // x 512 threads = 2^31: half of what HIP accepts, super-tile padding has room
 #define NWK_F16_TILE_ROWS 256      // fp16 path: query and base tiles are 256 rows
 
 struct NwkTileParams {

@@ -336,3 +336,24 @@ def test_default_opts_environment_hook(monkeypatch):
     monkeypatch.setenv("NWKNN_DEFAULT_OPTS", "no_such_option=1")
     with pytest.raises(ValueError, match="unknown option"):
         KnnEngine(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prescreen", [False, True])
+def test_very_many_queries_split_a_chunk_into_several_launches(prescreen):
+    """600 000 queries x 600 000 base rows: a chunk of query tiles x base tiles would be more than HIP launches at once (2^32 threads);
+    run_chunk sends it out as several launches over base-tile ranges.  The result must equal the same search done in two halves of the
+    queries (which need no split)."""
+    import torch
+    from neighborhoodwatch_amd import KnnEngine
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    base = torch.randn((600_000, 8), device="cuda", generator=g)
+    q = torch.randn((600_000, 8), device="cuda", generator=g)
+    with KnnEngine(0, profile=True) as eng:
+        eng.set_prescreen(prescreen)
+        eng.set_base(base)
+        d_all, i_all = eng.search(q, 10)
+        assert eng.stats()["prescreen"] == int(prescreen)
+        d_a, i_a = eng.search(q[:300_000], 10)
+        d_b, i_b = eng.search(q[300_000:], 10)
+    assert torch.equal(i_all, torch.cat([i_a, i_b])) and torch.equal(d_all, torch.cat([d_a, d_b]))
