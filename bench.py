@@ -34,6 +34,9 @@ WORKLOADS = {
     "c3": (100_000, 10_000_000, 1024, 100, "sqeuclidean", "f32", "C3: 100k queries x 10M base, d=1024 (e5-large-v2 shape), k=100, fp32 sqeuclidean"),
     "c2": (10_000, 1_000_000, 768, 100, "sqeuclidean", "f32", "C2: 10k queries x 1M base, d=768, k=100, fp32 sqeuclidean"),
     "dev": (4_096, 262_144, 256, 100, "sqeuclidean", "f32", "dev: 4k x 256k, d=256, k=100 (not a headline number)"),
+    # what ONE of eight GPUs does per step of the headline job at --gpus 8 (all queries x its 1.25M-row shard; no collective):
+    # 8 x its queries/s is the ceiling of the 8-GPU line, measurable on a one-GPU box
+    "c3shard": (100_000, 1_250_000, 1024, 100, "sqeuclidean", "f32", "one of eight C3 shards: 100k queries x 1.25M base rows, d=1024, k=100, fp32 (not a headline number)"),
     # BASELINE config 4 (fp16 MFMA + L2, 8 GPUs) and the piece of it one GPU sees (its 12.5M-row shard, a tenth of the queries)
     "c4": (1_000_000, 100_000_000, 1536, 100, "sqeuclidean", "f16", "C4: 1M queries x 100M base, d=1536 (ada-002 shape), k=100, fp16 MFMA sqeuclidean"),
     "c4gpu": (100_000, 12_500_000, 1536, 100, "sqeuclidean", "f16", "C4 per-GPU slice: 100k queries x 12.5M base rows (one of 8 shards), d=1536, k=100, fp16"),
