@@ -91,3 +91,54 @@ def test_two_rank_query_sharded_search_equals_single_rank(tmp_path, oracle):
     for r in range(world):
         g = np.load(tmp_path / f"qrank{r}.npz")
         assert np.array_equal(g["idx"], ri) and np.array_equal(g["dist"].view(np.uint32), rd.view(np.uint32))
+
+
+def _worker_ties(rank, world, port, out_dir):
+    """Three uneven shards (1003 rows: 334/334/335) whose rows repeat across shard borders: a query's equal-distance neighbours
+    live on different ranks, so the merged order is decided by the GLOBAL row id (lower wins), not by the rank that sent it."""
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as td
+    from neighborhoodwatch_amd.distributed import shard_bounds, sharded_search
+    from oracle import cpu_oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    B, Q, d, k = 1003, 17, 32, 24
+    lo, hi = shard_bounds(B, world, rank)
+    base = _tied_base(orc, B, d)[lo:hi]
+    queries = torch.from_numpy(orc.gen(orc.SEED_QUERY, 0, Q, d))
+
+    def search_shard(qs, kk, offset):
+        dd, ii = orc.knn_canonical(base, qs.numpy(), kk, "one_minus_dot")
+        return torch.from_numpy(dd), torch.from_numpy(ii + offset)
+
+    def merge(gd, gi, kk):
+        dd, ii = orc.merge_partials(gd.numpy(), gi.numpy(), kk)
+        return torch.from_numpy(dd), torch.from_numpy(ii)
+
+    dist, idx = sharded_search(search_shard, merge, queries, k, lo, None)
+    np.savez(Path(out_dir) / f"trank{rank}.npz", dist=dist.numpy(), idx=idx.numpy())
+    td.barrier()
+    td.destroy_process_group()
+
+
+def _tied_base(orc, B, d):
+    """Only 97 distinct rows: row r repeats row r % 97, so every neighbour has ~10 exact copies spread over all shards."""
+    distinct = orc.gen(orc.SEED_BASE, 0, 97, d)
+    return np.ascontiguousarray(distinct[np.arange(B) % 97])
+
+
+@pytest.mark.timeout(180)
+def test_three_uneven_ranks_break_cross_shard_ties_by_global_row_id(tmp_path, oracle):
+    world = 3
+    mp.spawn(_worker_ties, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    base = _tied_base(oracle, 1003, 32)
+    queries = oracle.gen(oracle.SEED_QUERY, 0, 17, 32)
+    rd, ri = oracle.knn_canonical(base, queries, 24, "one_minus_dot")
+    assert (np.diff(rd, axis=1) == 0).any()                        # the case really holds ties
+    tied = np.diff(rd, axis=1) == 0
+    assert (np.diff(ri, axis=1)[tied] > 0).all()                   # ... which the single-shard result orders by row id
+    for r in range(world):
+        g = np.load(tmp_path / f"trank{r}.npz")
+        assert np.array_equal(g["idx"], ri), f"rank {r}: merged ids differ from the single-shard result"
+        assert np.array_equal(g["dist"].view(np.uint32), rd.view(np.uint32))
