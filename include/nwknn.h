@@ -95,15 +95,21 @@ int nwknn_set_stream(nwknn_handle h, void* hip_stream);
  * search used it: non-finite or extreme-magnitude inputs fall back to the direct kernel),
  * "f16_exact" (fp16 compute path, default 1: results are the canonical fp32 arithmetic applied to the
  * fp16 values, bit for bit -- the fp16 MFMA kernel pre-screens, listed pairs are rescored; 0: raw fp16-MFMA sums),
- * "f16_mfma" (fp16 tile kernel build: -1 = auto, default: 3 up to 2048 halves per row, else 1; 3 = v_mfma_f32_16x16x32_f16 streaming
- * form; 1 = the same MFMA, one burst of LDS-DMA per slab; 0 = 32x32x16; 2 = two 4-wave workgroups per CU),
+ * "f16_mfma" (fp16 tile kernel build, all on v_mfma_f32_16x16x32_f16: -1 = auto, default: 3 up to 2048 halves per row, else 1;
+ * 3 = streaming form; 1 = burst form, one burst of LDS-DMA per slab),
  * "tile_occ" (workgroups per CU of the fp32 tile kernel, 3 default | 2), "chunk_growth" (0 = auto), "super_q_shift" / "super_walk_q"
  * (shape and walk order of an XCD's super-tile), "upload_threads" (host threads of the column upload pipeline, default 8),
- * MaxSim pre-screen tile kernel, d <= 128: "ms_ring" (1 default: four-stage document ring; 0: the two-stage strip kernel), "ms_mfma"
- * (1 default: v_mfma_f32_16x16x32_f16; 0: 32x32x16), "ms_strip" (document tiles per workgroup: 0 = auto, 1 = the plain kernel),
- * "ms_rescore_valu" (1: rescoring on the vector pipes). */
+ * "pre_eps_pct" (>= 100: percent of the proven pre-screen error bound to apply; larger = more pairs rescored, same result),
+ * MaxSim pre-screen tile kernel, d <= 128: "ms_strip" (document tiles a workgroup of the ring kernel walks: 0 = auto, 1 = the any-d
+ * kernel), "ms_rescore_valu" (1: rescoring on the vector pipes).
+ * No option changes a result: every switch that does (timing ablations, in-kernel stamps, a shrunken error bound) exists only in
+ * developer builds of the library (-DNWKNN_DEV) and is refused with NWKNN_EINVAL here.  The environment variable NWKNN_DEFAULT_OPTS
+ * ("name=value,...") applies options to every new handle through this function and says so on stderr. */
 int nwknn_set_option(nwknn_handle h, const char* name, int64_t value);
 int nwknn_get_stats(nwknn_handle h, nwknn_stats* out);
+/* Name of the distance-tile kernel that carried the filtered launches of the most recent search on the handle, spelled as rocprofv3's
+ * kernel trace prints it (e.g. "nwk_tile_kernel<0,false,256,16,0,3>"); "" before the first search.  The string lives in the handle. */
+const char* nwknn_tile_kernel_name(nwknn_handle h);
 /* Wait for everything queued on the handle's stream. */
 int nwknn_synchronize(nwknn_handle h);
 

@@ -28,7 +28,7 @@ EXPORTS = [
     "nwknn_set_stream", "nwknn_set_option", "nwknn_get_stats", "nwknn_synchronize", "nwknn_set_base", "nwknn_search",
     "nwknn_merge", "nwknn_generate", "nwknn_set_base_columns", "nwknn_search_columns",
     "nwknn_set_base_column_chunks", "nwknn_search_column_chunks",
-    "nwknn_maxsim_set_docs", "nwknn_maxsim_search",
+    "nwknn_maxsim_set_docs", "nwknn_maxsim_search", "nwknn_tile_kernel_name",
 ]
 
 
@@ -95,6 +95,7 @@ def load() -> ctypes.CDLL:
     L.nwknn_set_option.argtypes = [c_void_p, c_char_p, c_int64]
     L.nwknn_get_stats.argtypes = [c_void_p, POINTER(NwknnStats)]
     L.nwknn_synchronize.argtypes = [c_void_p]
+    L.nwknn_tile_kernel_name.argtypes = [c_void_p]
     L.nwknn_set_base.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int, c_int]
     L.nwknn_search.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_int32, c_int, c_int64, c_void_p, c_void_p, c_int]
     L.nwknn_merge.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int]
@@ -108,8 +109,9 @@ def load() -> ctypes.CDLL:
     L.nwknn_generate.argtypes = [c_void_p, c_uint64, c_int64, c_int64, c_int32, c_int, c_void_p]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ("nwknn_last_error",):
+        if name not in ("nwknn_last_error", "nwknn_tile_kernel_name"):
             fn.restype = c_int
+    L.nwknn_tile_kernel_name.restype = c_char_p
     _lib = L
     return L
 

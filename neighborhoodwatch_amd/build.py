@@ -1,6 +1,7 @@
 """Builds libnwknn.so in-tree with hipcc for gfx950 (the only target; no other arch, no CPU build).
 
     python -m neighborhoodwatch_amd.build [--force]
+    python -m neighborhoodwatch_amd.build --dev      # ab/libnwknn_dev.so with -DNWKNN_DEV (timing ablations, in-kernel stamps: tools/ only)
 
 Every source file is compiled to its own object (in parallel, only when it or a header is newer than the object) and the
 objects are linked into the shared library, so touching one kernel file rebuilds one object.
@@ -38,6 +39,27 @@ def needs_build() -> bool:
     return _stale(OUT, SOURCES + HEADERS + [Path(__file__)])
 
 
+def build_dev(verbose: bool = False) -> Path:
+    """Developer build: the same sources with -DNWKNN_DEV, which adds the switches whose results are wrong or unguaranteed by
+    construction (options diag, dbg_ptr, pre_eps_pct < 100, prescreen_prune).  Never the product: it goes to ab/ (git-ignored), the
+    package only ever loads neighborhoodwatch_amd/libnwknn.so unless NWKNN_LIB_PATH points elsewhere (tools/ do that)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out_dir = PKG.parent / "ab"
+    obj_dir = out_dir / "dev_obj"
+    obj_dir.mkdir(parents=True, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = obj_dir / (src.stem + ".o")
+        cmd = [hipcc, *FLAGS[:-2], "-DNWKNN_DEV", "-x", "hip", "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        objs.append(str(obj))
+    out = out_dir / "libnwknn_dev.so"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(out)], check=True)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return OUT
@@ -67,4 +89,4 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build_dev(verbose=True) if "--dev" in sys.argv else build(force="--force" in sys.argv, verbose=True))

@@ -30,7 +30,7 @@
 //   nwk_prep.hip       seeded generator, layout/norm preparation, max|x| and the scaled fp16 copies of the pre-screen
 //   nwk_tile_f32.hip   fp32 distance tile (v_mfma_f32_32x32x2_f32) fused with the running top-k filter
 //   nwk_tile_f16p.hip  fp16 distance tile, streaming form (v_mfma_f32_16x16x32_f16): the default up to 2048 halves per row
-//   nwk_tile_f16.hip   fp16 distance tiles, burst forms (32x32x16, 16x16x32, two-workgroup form), direct and pre-screen (PRE = 1)
+//   nwk_tile_f16.hip   fp16 distance tile, burst form (the build with a dense mode; rows beyond 2048 halves), direct and pre-screen (PRE = 1)
 //   nwk_select.hip     rescoring of pre-screened pairs, list compaction, finalize, partial-list merge
 //   nwk_maxsim.hip     MaxSim late interaction (extension)
 // each with its host-side launchers (declared in nwknn_internal.h, called from nwknn_api.cpp).
@@ -48,6 +48,12 @@ typedef unsigned int u32;
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
+
+// In-kernel cycle stamps go to NwkTileParams::dbg when it is set.  Only a developer build of the library (-DNWKNN_DEV, tools/mk_ab_lib.sh)
+// has the option that sets it ("dbg_ptr") and the DIAG timing ablations, whose results are wrong by construction; in the shipped
+// library the pointer is always null and the stamp code is a never-taken wave-uniform branch outside the K loops (left in place
+// rather than compiled out because removing it changes the fp32 kernel's register allocation: 7 -> 13 spilled VGPRs).
+#define NWK_DBG(p) ((p).dbg)
 
 // ------------------------------------------------------------------------------------------------
 // small device helpers
@@ -329,4 +335,4 @@ __device__ __forceinline__ void stage_query_side(char* lds, int rows, int tid, f
 }
 
 // DIAG (timing experiments only, results are wrong when != 0): 1 = no LDS fragment reads in the loop, 2 = no DMA after
-// slab 0, 4 = no barriers, 8 = no B-operand DMA after slab 0.  The product always launches DIAG = 0.
+// slab 0, 4 = no barriers, 8 = no B-operand DMA after slab 0.  Instantiated under -DNWKNN_DEV only; the product launches DIAG = 0.

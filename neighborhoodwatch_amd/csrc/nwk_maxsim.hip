@@ -322,158 +322,10 @@ __global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_kernel(const NwkTilePar
     }
 }
 
-// The same pre-screen for d <= 128 (ColBERT: 128), "strip" form.  At 87 FLOP per operand byte the kernel above lives off its
-// operand stream, and a third of that stream is the query-token tile, re-fetched for every document tile.  Here a workgroup walks a
-// strip of p.tiles_per_wg consecutive document tiles for ONE group of 4 queries: the query tokens go through LDS once, their
-// fragments (8 k-steps x 2 column blocks = 64 VGPRs) then stay in registers for the whole strip, and only document tokens stream
-// (16 KiB per slab instead of 24; two 16 KiB stages instead of two of 24).  The next tile's first slab is requested before the
-// current tile's epilogue.  Same accumulators, same epilogue, same keys.
-__global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_strip_kernel(const NwkTileParams p)
-{
-    constexpr int TM = 256, TQ = 128, NK = 4, A_STAGE = TM * 64, B_SLAB = TQ * 64;      // 32-half slabs of 64-B rows
-    static_assert(NK * B_SLAB <= 2 * A_STAGE, "the query tile is staged through the document stages");
-    __shared__ __attribute__((aligned(16))) char smem[2 * A_STAGE];
-
-    const TileCoord tc = tile_from_block(p);         // tc.qt: group of 4 queries, tc.bt: STRIP of document tiles
-    if (!tc.ok) return;
-    const int tid = threadIdx.x;
-    const int w = tid >> 6, l = tid & 63;
-    const int wr = w >> 1, wc = w & 1;
-    const int h = l >> 5, c32 = l & 31;
-    const int T = p.tiles_per_wg > 1 ? p.tiles_per_wg : 1;
-    const int bt_first = p.bt0 + (tc.bt - p.bt0) * T;
-    int n_here = p.bt0 + p.n_btiles_real - bt_first;
-    if (n_here > T) n_here = T;
-    const long long qrow0 = (long long)tc.qt * TQ;
-    const int dp = p.dp;                             // halves per row: 32 * nk, nk <= NK
-    const int nk = dp / 32;
-    const _Float16* docs = (const _Float16*)p.bp;
-    const _Float16* qrys = (const _Float16*)p.qp;
-
-    const unsigned voff = (unsigned)((l >> 2) * dp * 2 + (((l & 3) ^ ((0 - (l >> 4)) & 3)) << 4));
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(qrys + qrow0 * dp), 0, 0x7FFFFFFF, 0x00020000);
-    const int wu = __builtin_amdgcn_readfirstlane(w);
-    const int rowsA = wu * 64 * dp * 2, rowsB = wu * 32 * dp * 2, step16 = 16 * dp * 2;
-    const int swz = (0 - (c32 >> 2)) & 3;
-    int offA[4], offB[2];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) offA[m] = (wr * 128 + m * 32 + c32) * 64 + ((h ^ swz) << 4);
-#pragma unroll
-    for (int n = 0; n < 2; ++n) offB[n] = (wc * 64 + n * 32 + c32) * 64 + ((h ^ swz) << 4);
-
-    // ---- the query-token tile: all of its slabs through LDS once, then 8 x 2 fragments in registers for the whole strip
-    for (int kt = 0; kt < nk; ++kt)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(smem + kt * B_SLAB + wu * 2048 + i * 1024), 16, voff,
-                                                     kt * 64 + rowsB + i * step16, 0, 0);
-    const long long q_first = (long long)tc.qt * MS_QUERIES_PER_TILE + 2 * wc;
-    const u64 tauq[2] = {p.tau[q_first], p.tau[q_first + 1]};
-    const float rq[2] = {p.ms_rq[q_first], p.ms_rq[q_first + 1]};
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    f16x8 bq[2 * NK][2];
-#pragma unroll
-    for (int kt = 0; kt < NK; ++kt)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-                bq[2 * kt + ks][n] = (kt < nk) ? *(const f16x8*)(smem + kt * B_SLAB + (offB[n] ^ (ks << 5))) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                    // every wave holds its fragments: the stages now belong to the document stream
-
-    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(docs + (long long)bt_first * TM * dp), 0, 0x7FFFFFFF, 0x00020000);
-    auto issue_A = [&](int stage, int kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(smem + stage * A_STAGE + wu * 4096 + i * 1024), 16, voff,
-                                                     kt * 64 + rowsA + i * step16, 0, 0);
-    };
-    const int cap = p.cap;
-    issue_A(0, 0);
-    for (int t = 0; t < n_here; ++t) {
-        const int bt = bt_first + t;
-        float cdv[2];                                // per-document part of the score bound: requested now, used in the epilogue
-#pragma unroll
-        for (int dd = 0; dd < 2; ++dd) {
-            const long long doc = (long long)bt * MS_DOCS_PER_TILE + 2 * wr + dd;
-            cdv[dd] = doc < p.nb_valid ? p.ms_cd[doc] : 0.0f;
-        }
-        f32x16 acc[4][2];
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-#pragma unroll
-        for (int kt = 0; kt < NK; ++kt) {
-            if (kt >= nk) break;
-            const int cur = kt & 1;
-            if (kt + 1 < nk) {
-                issue_A(cur ^ 1, kt + 1);
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            const char* sb = smem + cur * A_STAGE;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                f16x8 a[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) a[m] = *(const f16x8*)(sb + (offA[m] ^ (ks << 5)));
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], bq[2 * kt + ks][n], acc[m][n], 0, 0, 0);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        if (t + 1 < n_here) {                        // the next tile's first slab goes out before this tile's epilogue
-            rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(docs + (long long)(bt + 1) * TM * dp), 0, 0x7FFFFFFF, 0x00020000);
-            issue_A(0, 0);
-        }
-#pragma unroll
-        for (int dd = 0; dd < 2; ++dd) {
-            const long long doc = (long long)bt * MS_DOCS_PER_TILE + 2 * wr + dd;
-            const bool doc_ok = doc < p.nb_valid;
-            const float cd = cdv[dd];
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                float v = acc[2 * dd][n][0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) v = fmaxf(v, acc[2 * dd][n][r]);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v = fmaxf(v, acc[2 * dd + 1][n][r]);
-                v = fmaxf(v, __shfl_xor(v, 32));
-                float sum = v;
-#pragma unroll
-                for (int o = 1; o < 32; o <<= 1) sum = __fadd_rn(sum, __shfl_xor(sum, o));
-                if (l == 0 && doc_ok) {
-                    const long long q = q_first + n;
-                    const float score = sum * p.pre_inv_scale;                         // fp16 estimate of the MaxSim score
-                    bool pass = true;
-                    if (tauq[n] != ~0ull) {
-                        const float td = unsortable_f32((u32)(tauq[n] >> 32));          // = -(k-th best score so far)
-                        const float err = rq[n] + cd;
-                        pass = !(score < (-td) - err - 2.0e-6f * (fabsf(td) + err));
-                    }
-                    if (pass && q < p.nq_valid) {
-                        const u32 pos = atomicAdd(p.cnt + q, 1u);
-                        if (pos < (u32)cap) p.buf[q * cap + pos] = ((u64)__float_as_uint(-score) << 32) | (u32)doc;
-                    }
-                }
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the workgroup leaves
-}
-
-// "Ring" form of the strip kernel (option ms_ring, the default for d <= 128).  Two things held the strip kernel at 37 % of the fp16
-// MFMA rate although a tile is only 64 MFMAs per wave:
+// The pre-screen for d <= 128 (ColBERT: 128), "ring" form: the default.  A workgroup walks a strip of p.tiles_per_wg consecutive document
+// tiles for ONE group of 4 queries; the query tokens go through LDS once, their fragments then stay in registers for the whole strip, and
+// only document tokens stream.  Round 2's first strip kernel (two 16 KiB stages; removed in round 3 together with the 32x32x16 build of the
+// ring) sat at 37 % of the fp16 MFMA rate although a tile is only 64 MFMAs per wave, for two reasons:
 //   * its two 16 KiB stages let a document slab be requested ONE slab (16 MFMAs per wave, ~0.25 us) before it is waited for, with two
 //     barriers per slab -- the LDS-DMA round trip is several times that, so every slab began with a stall;
 //   * its epilogue ran 4 x 6 ds_bpermute exchanges one after the other, each behind an s_waitcnt lgkmcnt(0) (the butterfly sum over
@@ -489,160 +341,7 @@ __global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_strip_kernel(const NwkT
 // v_readlane for the last level, the four pairs of a wave interleaved.  Same estimates, same keys as the strip kernel.
 #define MS_RING_MAX_STRIP 64
 
-__global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_ring_kernel(const NwkTileParams p)
-{
-    constexpr int TM = 256, TQ = 128, NK = 4, SLAB = TM * 64, RING = 4, B_SLAB = TQ * 64;      // 32-half slabs of 64-B rows
-    constexpr int OFF_CD = RING * SLAB;
-    static_assert(NK * B_SLAB <= RING * SLAB, "the query tile is staged through the document stages");
-    static_assert(MS_RING_MAX_STRIP * MS_DOCS_PER_TILE == 256, "one thread stages one document bound");
-    __shared__ __attribute__((aligned(16))) char smem[OFF_CD + MS_RING_MAX_STRIP * MS_DOCS_PER_TILE * 4];
-
-    const TileCoord tc = tile_from_block(p);         // tc.qt: group of 4 queries, tc.bt: STRIP of document tiles
-    if (!tc.ok) return;
-    const int tid = threadIdx.x;
-    const int w = tid >> 6, l = tid & 63;
-    const int wr = w >> 1, wc = w & 1;
-    const int h = l >> 5, c32 = l & 31;
-    const int T = p.tiles_per_wg > 1 ? p.tiles_per_wg : 1;         // <= MS_RING_MAX_STRIP (launcher)
-    const int bt_first = p.bt0 + (tc.bt - p.bt0) * T;
-    int n_here = p.bt0 + p.n_btiles_real - bt_first;
-    if (n_here > T) n_here = T;
-    const long long qrow0 = (long long)tc.qt * TQ;
-    const int dp = p.dp;                             // halves per row: 32 * nk, nk <= NK
-    const int nk = dp / 32;
-    const _Float16* docs = (const _Float16*)p.bp;
-    const _Float16* qrys = (const _Float16*)p.qp;
-
-    const unsigned voff = (unsigned)((l >> 2) * dp * 2 + (((l & 3) ^ ((0 - (l >> 4)) & 3)) << 4));
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(qrys + qrow0 * dp), 0, 0x7FFFFFFF, 0x00020000);
-    const int wu = __builtin_amdgcn_readfirstlane(w);
-    const int rowsA = wu * 64 * dp * 2, rowsB = wu * 32 * dp * 2, step16 = 16 * dp * 2;
-    const int swz = (0 - (c32 >> 2)) & 3;
-    int offA[4], offB[2];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) offA[m] = (wr * 128 + m * 32 + c32) * 64 + ((h ^ swz) << 4);
-#pragma unroll
-    for (int n = 0; n < 2; ++n) offB[n] = (wc * 64 + n * 32 + c32) * 64 + ((h ^ swz) << 4);
-
-    // ---- once per strip: the query-token tile through LDS into 8 x 2 register fragments; the strip's per-document bounds into LDS
-    for (int kt = 0; kt < nk; ++kt)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(smem + kt * B_SLAB + wu * 2048 + i * 1024), 16, voff,
-                                                     kt * 64 + rowsB + i * step16, 0, 0);
-    const long long q_first = (long long)tc.qt * MS_QUERIES_PER_TILE + 2 * wc;
-    const u64 tauq[2] = {p.tau[q_first], p.tau[q_first + 1]};
-    const float rq[2] = {p.ms_rq[q_first], p.ms_rq[q_first + 1]};
-    float cd_mine = 0.0f;
-    {
-        const long long doc = (long long)bt_first * MS_DOCS_PER_TILE + tid;
-        if (tid < n_here * MS_DOCS_PER_TILE && doc < p.nb_valid) cd_mine = p.ms_cd[doc];
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ((float*)(smem + OFF_CD))[tid] = cd_mine;
-    __builtin_amdgcn_s_barrier();
-    f16x8 bq[2 * NK][2];
-#pragma unroll
-    for (int kt = 0; kt < NK; ++kt)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-                bq[2 * kt + ks][n] = (kt < nk) ? *(const f16x8*)(smem + kt * B_SLAB + (offB[n] ^ (ks << 5))) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    // per (query, .) constants of the filter:  pass  <=>  !(score < lim),  lim = -td - err - 2e-6 (|td| + err),  err = rq + cd
-    float ntd[2], atd[2];
-    bool open_[2];
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        open_[n] = tauq[n] == ~0ull;                                  // fewer than k docs seen: everything is listed
-        const float td = unsortable_f32((u32)(tauq[n] >> 32));       // = -(k-th best score so far)
-        ntd[n] = -td; atd[n] = fabsf(td);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                    // every wave holds its fragments: the stages now belong to the document stream
-
-    // ---- the document stream: slab X (tile X / nk, k-slab X % nk, clamped to the strip's last slab) goes to stage X & 3
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(docs + (long long)bt_first * TM * dp), 0, 0x7FFFFFFF, 0x00020000);
-    const int NS = n_here * nk;
-    const int tile_bytes = TM * dp * 2;
-    int it = 0, ik = 0, ist = 0;
-    auto issue_next = [&]() {
-        const int soff = it * tile_bytes + ik * 64 + rowsA;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(smem + ist * SLAB + wu * 4096 + i * 1024), 16, voff, soff + i * step16, 0, 0);
-        ist = (ist + 1) & (RING - 1);
-        if (it * nk + ik + 1 < NS) { if (++ik == nk) { ik = 0; ++it; } }
-    };
-    issue_next(); issue_next(); issue_next();
-
-    const int cap = p.cap;
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int st = 0;                                      // stage of the slab being multiplied
-    for (int t = 0; t < n_here; ++t) {
-        f32x16 acc[4][2];
-#pragma unroll
-        for (int kt = 0; kt < NK; ++kt) {
-            if (kt >= nk) break;
-            // this wave's requests for the slab have landed (behind them: the 4 + 4 of the next two slabs) and its fragment reads of
-            // the previous slab are done; behind the barrier that holds for every wave, so the previous slab's stage can be refilled
-            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (!(p.ms_ring & 2)) issue_next();      // dev ablation (ms_ring = 3): no document stream inside the loop, timing only
-            const char* sb = smem + st * SLAB;
-            st = (st + 1) & (RING - 1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                f16x8 a[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) a[m] = *(const f16x8*)(sb + (offA[m] ^ (ks << 5)));
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m], bq[2 * kt + ks][n], (kt == 0 && ks == 0) ? zero16 : acc[m][n], 0, 0, 0);
-            }
-        }
-        // ---- epilogue of tile t (the requests of the next three slabs are in flight): 2 docs x 2 queries per wave
-        if ((p.ms_ring & 4) && t + 1 < n_here) continue;      // dev ablation (ms_ring = 5): only the strip's last tile has an epilogue, timing only
-        const float* cd_s = (const float*)(smem + OFF_CD) + t * MS_DOCS_PER_TILE + 2 * wr;
-        float score[2][2];
-#pragma unroll
-        for (int dd = 0; dd < 2; ++dd)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                float v = acc[2 * dd][n][0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) v = fmaxf(v, acc[2 * dd][n][r]);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v = fmaxf(v, acc[2 * dd + 1][n][r]);
-                score[dd][n] = v;
-            }
-#pragma unroll
-        for (int dd = 0; dd < 2; ++dd)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) score[dd][n] = ms_token_sum(score[dd][n]) * p.pre_inv_scale;     // fp16 estimate of the MaxSim score
-#pragma unroll
-        for (int dd = 0; dd < 2; ++dd) {
-            const long long doc = (long long)(bt_first + t) * MS_DOCS_PER_TILE + 2 * wr + dd;
-            const bool doc_ok = doc < p.nb_valid;
-            const float cd = cd_s[dd];
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const long long q = q_first + n;
-                const float err = rq[n] + cd;
-                const bool pass = open_[n] || !(score[dd][n] < ntd[n] - err - 2.0e-6f * (atd[n] + err));
-                if (pass && doc_ok && q < p.nq_valid && l == 0) {
-                    const u32 pos = atomicAdd(p.cnt + q, 1u);
-                    if (pos < (u32)cap) p.buf[q * cap + pos] = ((u64)__float_as_uint(-score[dd][n]) << 32) | (u32)doc;
-                }
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the workgroup leaves
-}
-
-// The ring kernel on v_mfma_f32_16x16x32_f16 (option ms_mfma = 1).  Under this kernel the chip holds only ~1.7 GHz (PMC: profiles/
+// The ring kernel is built on v_mfma_f32_16x16x32_f16.  Under this kernel the chip holds only ~1.7 GHz (PMC: profiles/
 // r02e_c5_pmc_summary.json), and in that power-limited regime the 16x16x32 shape delivers more FLOP/s than 32x32x16 at equal cycles
 // (MI355X_MICROARCH.md, DVFS give-back item 7; the kNN fp16 tile kernel gained 5 % from the same switch).  Same workgroup tile, same LDS
 // image, ring, waits and barriers; a 32-half slab is ONE k-step: 8 row blocks x 4 column blocks = 32 MFMAs per wave and slab.
@@ -876,7 +575,7 @@ __global__ __launch_bounds__(256) void nwk_maxsim_prune_kernel(const NwkMsRescor
     }
     if (lane == 0) {
         p.nsurv[q] = nsurv;
-        if (p.dbg) { atomicAdd(p.dbg, (unsigned long long)(end - start)); atomicAdd(p.dbg + 1, (unsigned long long)nsurv); }
+        if (NWK_DBG(p)) { atomicAdd(NWK_DBG(p), (unsigned long long)(end - start)); atomicAdd(NWK_DBG(p) + 1, (unsigned long long)nsurv); }
     }
 }
 
@@ -1064,14 +763,13 @@ hipError_t nwk_launch_maxsim_pre(hipStream_t st, NwkTileParams p)
 {
     if (p.n_qtiles <= 0 || p.n_btiles <= 0) return hipSuccess;
     if (p.sq_shift < 0 || p.sq_shift > 6) return hipErrorInvalidValue;
-    const bool strip = p.dp <= 128 && p.tiles_per_wg != 1;      // d <= 128: query fragments fit the registers (tiles_per_wg = 1: the plain kernel)
-    const bool ring = strip && p.ms_ring;                       // four-stage document ring, one barrier per slab, DPP epilogue (the default)
-    if (strip) {
-        if (p.tiles_per_wg < 1) {                               // auto (option ms_strip = 0): the ring form likes long strips (64: +3 % over 8 on
-            p.tiles_per_wg = ring ? MS_RING_MAX_STRIP : 8;      // C5) as long as the launch still has a few workgroups for each of the 512 slots
-            while (ring && p.tiles_per_wg > 8 && (long long)((p.n_btiles + p.tiles_per_wg - 1) / p.tiles_per_wg) * p.n_qtiles < 2048) p.tiles_per_wg >>= 1;
+    const bool ring = p.dp <= 128 && p.tiles_per_wg != 1;       // d <= 128: query fragments fit the registers (tiles_per_wg = 1: the plain kernel)
+    if (ring) {
+        if (p.tiles_per_wg < 1) {                               // auto (option ms_strip = 0): the ring likes long strips (64: +3 % over 8 on C5)
+            p.tiles_per_wg = MS_RING_MAX_STRIP;                 // as long as the launch still has a few workgroups for each of the 512 slots
+            while (p.tiles_per_wg > 8 && (long long)((p.n_btiles + p.tiles_per_wg - 1) / p.tiles_per_wg) * p.n_qtiles < 2048) p.tiles_per_wg >>= 1;
         }
-        if (ring && p.tiles_per_wg > MS_RING_MAX_STRIP) p.tiles_per_wg = MS_RING_MAX_STRIP;
+        if (p.tiles_per_wg > MS_RING_MAX_STRIP) p.tiles_per_wg = MS_RING_MAX_STRIP;
         p.n_btiles_real = p.n_btiles;
         p.n_btiles = (p.n_btiles + p.tiles_per_wg - 1) / p.tiles_per_wg;
     }
@@ -1082,9 +780,7 @@ hipError_t nwk_launch_maxsim_pre(hipStream_t st, NwkTileParams p)
     supers = (supers + 7) / 8 * 8;
     const long long grid = supers * 64;
     if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    if (ring && p.f16_shape == 1) hipLaunchKernelGGL(nwk_maxsim_pre_ring16_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
-    else if (ring) hipLaunchKernelGGL(nwk_maxsim_pre_ring_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
-    else if (strip) hipLaunchKernelGGL(nwk_maxsim_pre_strip_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
+    if (ring) hipLaunchKernelGGL(nwk_maxsim_pre_ring16_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(nwk_maxsim_pre_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
     return hipGetLastError();
 }

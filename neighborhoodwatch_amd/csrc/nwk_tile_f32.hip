@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256, OCC) void nwk_tile_kernel(const NwkTileParams 
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
     unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;
-    if (p.dbg) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    if (NWK_DBG(p)) { st0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     const TileCoord tc = tile_from_block(p);
     if (!tc.ok) return;
 
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, OCC) void nwk_tile_kernel(const NwkTileParams 
     }
 
     issue_stage(0, 0);
-    if (p.dbg) st1 = __builtin_amdgcn_s_memtime();
+    if (NWK_DBG(p)) st1 = __builtin_amdgcn_s_memtime();
     f32x4 fa[MT], fb[2];
     if (DIAG & 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -147,14 +147,14 @@ __global__ __launch_bounds__(256, OCC) void nwk_tile_kernel(const NwkTileParams 
         if (!(DIAG & 4)) __builtin_amdgcn_s_barrier();                // everyone is done reading stage `cur`
     }
 
-    if (p.dbg) st2 = __builtin_amdgcn_s_memtime();
+    if (NWK_DBG(p)) st2 = __builtin_amdgcn_s_memtime();
     // ---- epilogue: accumulators -> keys -> filter -> candidate lists (staging reuses the idle operand stages)
     stage_query_side<METRIC, DENSE>(smem, TM, tid, my_qn, my_tau, p, q0);
     __syncthreads();
     tile_epilogue<METRIC, DENSE, MT>(p, acc, (const float*)smem, (const u64*)(smem + TM * 4), (const float*)(smem + TM * 12), bnv, colv, colok,
                                      q0, wr * (TM / 2), h, c32);
-    if (p.dbg && tid == 0) {
-        unsigned long long* o = p.dbg + (size_t)blockIdx.x * 8;
+    if (NWK_DBG(p) && tid == 0) {
+        unsigned long long* o = NWK_DBG(p) + (size_t)blockIdx.x * 8;
         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memtime(); o[4] = rt0; o[5] = __builtin_amdgcn_s_memrealtime();
         o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32      // HW_REG_XCC_ID[3:0]
              | (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));           // HW_REG_HW_ID
@@ -182,13 +182,16 @@ static hipError_t launch_tile_shape(hipStream_t st, const NwkTileParams& p, bool
         }
     }
     if (dense) { hipLaunchKernelGGL((nwk_tile_kernel<METRIC, true, TM, BKT, 0>), dim3(grid), dim3(256), 0, st, p); return hipGetLastError(); }
-    switch (diag) {              // dev-only timing ablations (wrong results by construction)
-    case 1: hipLaunchKernelGGL((nwk_tile_kernel<METRIC, false, TM, BKT, 1>), dim3(grid), dim3(256), 0, st, p); break;
-    case 2: hipLaunchKernelGGL((nwk_tile_kernel<METRIC, false, TM, BKT, 2>), dim3(grid), dim3(256), 0, st, p); break;
-    case 4: hipLaunchKernelGGL((nwk_tile_kernel<METRIC, false, TM, BKT, 4>), dim3(grid), dim3(256), 0, st, p); break;
-    case 8: hipLaunchKernelGGL((nwk_tile_kernel<METRIC, false, TM, BKT, 8>), dim3(grid), dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL((nwk_tile_kernel<METRIC, false, TM, BKT, 0>), dim3(grid), dim3(256), 0, st, p); break;
+#ifdef NWKNN_DEV
+    switch (diag) {              // timing ablations (wrong results by construction): developer builds only
+    case 1: hipLaunchKernelGGL((nwk_tile_kernel<METRIC, false, TM, BKT, 1>), dim3(grid), dim3(256), 0, st, p); return hipGetLastError();
+    case 2: hipLaunchKernelGGL((nwk_tile_kernel<METRIC, false, TM, BKT, 2>), dim3(grid), dim3(256), 0, st, p); return hipGetLastError();
+    case 4: hipLaunchKernelGGL((nwk_tile_kernel<METRIC, false, TM, BKT, 4>), dim3(grid), dim3(256), 0, st, p); return hipGetLastError();
+    case 8: hipLaunchKernelGGL((nwk_tile_kernel<METRIC, false, TM, BKT, 8>), dim3(grid), dim3(256), 0, st, p); return hipGetLastError();
+    default: break;
     }
+#endif
+    hipLaunchKernelGGL((nwk_tile_kernel<METRIC, false, TM, BKT, 0>), dim3(grid), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 

@@ -25,6 +25,16 @@
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
+// Developer builds (-DNWKNN_DEV: tools/mk_ab_lib.sh) add the switches whose results are wrong or unguaranteed by construction -- timing
+// ablations ("diag"), in-kernel stamps ("dbg_ptr"), a shrunken pre-screen bound ("pre_eps_pct" < 100), unpruned rescoring.  The
+// shipped library has none of them: nwknn_set_option answers NWKNN_EINVAL (the reference has no mode that returns wrong neighbours:
+// cu_knn.py:281-282 asserts its output).
+#ifdef NWKNN_DEV
+#define NWK_DEV_BUILD 1
+#else
+#define NWK_DEV_BUILD 0
+#endif
+
 static thread_local std::string g_err;
 
 static int fail(int code, const char* fmt, ...)
@@ -114,7 +124,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_rescore_valu = 0, opt_ms_ring = 1, opt_ms_mfma = 1;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_rescore_valu = 0;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -122,6 +132,7 @@ struct nwknn_ctx {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     double base_prep_ms = 0.0;
     nwknn_stats stats;
+    char tile_kernel[96] = "";      // name (rocprofv3's spelling) of the distance-tile kernel behind the last search's filtered launches
 };
 
 static int use_device(nwknn_ctx* h)
@@ -212,11 +223,13 @@ extern "C" int nwknn_create(nwknn_handle* out, int device)
     memset(&h->stats, 0, sizeof h->stats);
     int rc = create_device_objects(h);
     // NWKNN_DEFAULT_OPTS="name=value,name=value": options applied to every new handle (developers run the whole test suite against
-    // an alternative kernel build this way, e.g. f16_mfma=3); unset in production
+    // an alternative kernel build this way, e.g. f16_mfma=1); unset in production.  It goes through nwknn_set_option, so in the shipped
+    // library it reaches no switch that changes results (those exist under -DNWKNN_DEV only), and its use is reported on stderr.
     if (rc == NWKNN_OK) rc = guarded([&] {
         const char* env = getenv("NWKNN_DEFAULT_OPTS");
-        if (!env) return (int)NWKNN_OK;
+        if (!env || !*env) return (int)NWKNN_OK;
         const std::string all(env);
+        fprintf(stderr, "libnwknn: NWKNN_DEFAULT_OPTS=\"%s\" applied to the handle on device %d\n", env, device);   // never silent
         for (size_t pos = 0; pos < all.size();) {
             const size_t end = std::min(all.find(',', pos), all.size());
             const std::string kv = all.substr(pos, end - pos);
@@ -263,7 +276,11 @@ extern "C" int nwknn_set_stream(nwknn_handle h, void* hip_stream)
 
 extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
 {
-    if (!h || !name) return fail(NWKNN_EINVAL, "null handle or option name");
+    if (!name) return fail(NWKNN_EINVAL, "null handle or option name");
+    // switches that change results exist in developer builds only; refused by name, before anything else is looked at
+    if (!NWK_DEV_BUILD && (!strcmp(name, "diag") || !strcmp(name, "dbg_ptr") || !strcmp(name, "prescreen_prune") || (!strcmp(name, "pre_eps_pct") && value < 100)))
+        return fail(NWKNN_EINVAL, "option '%s'=%lld exists in developer builds of libnwknn only (-DNWKNN_DEV): it changes or unguards results", name, (long long)value);
+    if (!h) return fail(NWKNN_EINVAL, "null handle or option name");
     if (!strcmp(name, "capacity")) {
         if (value != 0 && (value < 256 || value > 4096 || (value & (value - 1)))) return fail(NWKNN_EINVAL, "capacity must be 0 (auto) or a power of two in [256, 4096]");
         h->opt_capacity = value;
@@ -290,15 +307,9 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
         h->opt_chunk_growth = value;        // a filtered chunk holds up to chunk_growth x the rows seen so far (1: chunks double)
     } else if (!strcmp(name, "ms_rescore_valu")) {
         h->opt_ms_rescore_valu = value ? 1 : 0;   // MaxSim rescoring on the vector pipes (round-1 kernel) instead of the matrix pipes
-    } else if (!strcmp(name, "ms_mfma")) {
-        if (value != 0 && value != 1) return fail(NWKNN_EINVAL, "ms_mfma must be 0 (32x32x16) or 1 (16x16x32)");
-        h->opt_ms_mfma = value;             // MaxSim ring kernel: MFMA shape (1: v_mfma_f32_16x16x32_f16, holds a higher clock under load)
-    } else if (!strcmp(name, "ms_ring")) {
-        if (value < 0 || value > 7) return fail(NWKNN_EINVAL, "ms_ring must be 0..7");
-        h->opt_ms_ring = value;             // MaxSim pre-screen, d <= 128: 1 the ring form of the strip kernel (default), 0 the round-2a strip kernel; dev: +2 / +4 = timing ablations of the ring kernel without its document stream / its epilogues (wrong results)
     } else if (!strcmp(name, "ms_strip")) {
         if (value < 0 || value > 64) return fail(NWKNN_EINVAL, "ms_strip must be 0..64");
-        h->opt_ms_strip = value;            // MaxSim pre-screen, d <= 128: document tiles a workgroup walks per query group (0: auto, 1: the plain kernel)
+        h->opt_ms_strip = value;            // MaxSim pre-screen, d <= 128: document tiles a workgroup of the ring kernel walks per query group (0: auto, 1: the any-d kernel)
     } else if (!strcmp(name, "upload_threads")) {
         if (value < 1 || value > 64) return fail(NWKNN_EINVAL, "upload_threads must be 1..64");
         h->opt_upload_threads = value;      // host threads that gather column slabs into the pinned upload buffers
@@ -309,22 +320,26 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
         if (value < -1 || value > 1) return fail(NWKNN_EINVAL, "super_walk_q must be -1 (auto), 0 (base tile index fastest) or 1 (query tile index fastest)");
         h->opt_walk_q = value;              // walk order inside a super-tile
     } else if (!strcmp(name, "pre_eps_pct")) {
-        h->opt_pre_eps_pct = value;         // dev: scales the pre-screen error bound (results are only guaranteed at >= 100)
+        // scales the pre-screen error bound.  Results are guaranteed at >= 100 only: smaller values exist in developer builds
+        if (value < 0 || value > 100000) return fail(NWKNN_EINVAL, "pre_eps_pct must be 100..100000 (percent of the proven bound)");
+        h->opt_pre_eps_pct = value;
     } else if (!strcmp(name, "f16_mfma")) {
-        if (value < -1 || value > 3) return fail(NWKNN_EINVAL, "f16_mfma must be -1 (auto), 0 (32x32x16), 1 (16x16x32), 2 (16x16x32, two 4-wave workgroups per CU) or 3 (16x16x32, streaming)");
+        if (value != -1 && value != 1 && value != 3) return fail(NWKNN_EINVAL, "f16_mfma must be -1 (auto), 1 (burst form) or 3 (streaming form)");
         h->opt_f16_shape = value;
+#if NWK_DEV_BUILD
     } else if (!strcmp(name, "prescreen_prune")) {
         h->opt_pre_prune = value ? 1 : 0;   // dev: 0 rescoring every listed pair (A/B of the bound-based pruning)
+    } else if (!strcmp(name, "diag")) {
+        h->opt_diag = value;             // dev: timing ablations of the tile kernel (results are wrong when != 0)
+    } else if (!strcmp(name, "dbg_ptr")) {
+        h->opt_dbg_ptr = value;          // dev: device buffer of >= grid*64 bytes receiving per-workgroup cycle stamps
+#endif
     } else if (!strcmp(name, "super_q_shift")) {
         if (value < -1 || value > 6) return fail(NWKNN_EINVAL, "super_q_shift must be -1 (auto) or 0..6");
         h->opt_sq_shift = value;         // super-tile of an XCD = 2^v query tiles x 2^(6-v) base tiles
     } else if (!strcmp(name, "tile_rows")) {
         if (value != 0 && value != 128 && value != 256) return fail(NWKNN_EINVAL, "tile_rows must be 0 (auto), 128 or 256");
         h->opt_tile_rows = value;
-    } else if (!strcmp(name, "diag")) {
-        h->opt_diag = value;             // dev: timing ablations of the tile kernel (results are wrong when != 0)
-    } else if (!strcmp(name, "dbg_ptr")) {
-        h->opt_dbg_ptr = value;          // dev: device buffer of >= grid*64 bytes receiving per-workgroup cycle stamps
     } else {
         return fail(NWKNN_EINVAL, "unknown option '%s'", name);
     }
@@ -336,6 +351,11 @@ extern "C" int nwknn_get_stats(nwknn_handle h, nwknn_stats* out)
     if (!h || !out) return fail(NWKNN_EINVAL, "null handle or output");
     *out = h->stats;
     return NWKNN_OK;
+}
+
+extern "C" const char* nwknn_tile_kernel_name(nwknn_handle h)
+{
+    return h ? h->tile_kernel : "";
 }
 
 extern "C" int nwknn_synchronize(nwknn_handle h)
@@ -688,6 +708,7 @@ static NwkCompactParams compact_params(nwknn_ctx* h, const SearchPlan& pl, int k
     return c;
 }
 
+#define NWK_DEV_BUILD_DIAG(h) (NWK_DEV_BUILD && (h)->opt_diag != 0)
 static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long long nq_pad, long long lo, long long rows, bool dense,
                      const int* qtile_list, int n_list_tiles, bool dedupe, bool rescan)
 {
@@ -706,11 +727,8 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
     const bool fp32_kernel = !(h->f16 || prescreen);
     if (h->opt_sq_shift < 0) tp.sq_shift = fp32_kernel ? 3 : 4;
     if (h->opt_walk_q < 0) tp.walk_q_fastest = 0;
-    // rows per base tile of the kernel the launchers below will pick: 128 for the fp32 kernel and for f16_mfma=2 (256 x 128
-    // tiles), 256 for the other fp16 kernels -- and for a dense pre-screened chunk whatever f16_mfma says, because
-    // nwk_launch_tile_prescreen runs those on the 256-row 16x16x32 build only
-    const bool q_shape = f16_shape == 2 && !(prescreen && dense);
-    const int btile = ((h->f16 || prescreen) && !q_shape) ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS;
+    // rows per base tile of the kernel the launchers below will pick: 128 for the fp32 kernel, 256 for the fp16 kernels
+    const int btile = (h->f16 || prescreen) ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS;
     if (rows % btile != 0) return fail(NWKNN_EINVAL, "internal: chunk of %lld rows is not a whole number of %d-row tiles", rows, btile);
     tp.bt0 = (int)(lo / btile);
     tp.n_btiles = (int)(rows / btile);
@@ -729,13 +747,19 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         for (long long done = 0; done < bt_total; done += per_launch) {
             tp.bt0 = bt_first + (int)done;
             tp.n_btiles = (int)std::min<long long>(per_launch, bt_total - done);
-            if (prescreen) HIPCHK(nwk_launch_tile_prescreen(h->stream, tp, metric, dense));
-            else if (h->f16) HIPCHK(nwk_launch_tile_f16(h->stream, tp, metric, dense, (int)h->opt_diag));
+            if (prescreen || h->f16) HIPCHK(nwk_launch_tile_f16(h->stream, tp, metric, dense, prescreen ? 1 : 0));
             else HIPCHK(nwk_launch_tile(h->stream, tp, metric, dense, pl.tile_rows, (int)h->opt_diag, (int)h->opt_tile_occ));
         }
         tp.bt0 = bt_first; tp.n_btiles = bt_total;
     }
     ev_end(h, e);
+    if (!dense && !rescan) {                               // which kernel carried this launch, spelled as rocprofv3 prints it
+        if (!(prescreen || h->f16)) {
+            const bool occ3 = pl.tile_rows == 256 && !NWK_DEV_BUILD_DIAG(h) && h->opt_tile_occ >= 3;
+            snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel<%d,false,%d,%d,0,%d>", metric, pl.tile_rows, pl.tile_rows == 256 ? 16 : 32, occ3 ? 3 : 2);
+        } else if (f16_shape == 3) snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel_f16p<%d,%d>", metric, prescreen ? 1 : 0);
+        else snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel_f16s<%d,false,%d>", metric, prescreen ? 1 : 0);
+    }
     if (prescreen) {                                       // listed pairs -> canonical fp32 keys, in place
         if (dense) {                                       // (exact fp16 mode) every slot of the dense chunk is a candidate: [0, rows)
             HIPCHK(hipMemsetD32Async((hipDeviceptr_t)h->cnt.p, (int)rows, (size_t)nq_pad, h->stream));
@@ -1079,12 +1103,12 @@ static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq
     tp.n_qtiles = (int)(nq_pad / 4); tp.bt0 = (int)(doc_lo / 4); tp.n_btiles = (int)(docs / 4);
     tp.dp = h->dp; tp.cap = cap; tp.sq_shift = h->opt_sq_shift >= 0 ? (int)h->opt_sq_shift : 3; tp.walk_q_fastest = h->opt_walk_q > 0 ? 1 : 0;
     const bool prescreen = pre && !dense;                // the dense first chunk runs the fp32 kernel (exact keys)
-    tp.tiles_per_wg = (int)h->opt_ms_strip; tp.ms_ring = (int)h->opt_ms_ring; tp.f16_shape = (int)h->opt_ms_mfma;
+    tp.tiles_per_wg = (int)h->opt_ms_strip;
     EvPair* e = ev_begin(h, 0);
     if (prescreen) {
         // the ring kernel streams documents only (the query fragments live in registers): the more query groups of an XCD walk the same
         // strip at the same time, the fewer bytes cross the fabric -- 64 x 1 super-tiles instead of 8 x 8: +3.3 % on C5 (tools/ms_order_sweep.py)
-        if (h->opt_sq_shift < 0 && h->opt_ms_ring && h->dp16 <= 128 && h->opt_ms_strip != 1) {
+        if (h->opt_sq_shift < 0 && h->dp16 <= 128 && h->opt_ms_strip != 1) {
             int sh = 3;
             while (sh < 6 && (1 << sh) < tp.n_qtiles) ++sh;
             tp.sq_shift = sh;
@@ -1093,8 +1117,10 @@ static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq
         tp.nq_valid = nq; tp.ms_rq = h->ms_rq.as<float>(); tp.ms_cd = h->ms_cd.as<float>();
         tp.pre_scale = h->ms_scale; tp.pre_inv_scale = 1.0f / h->ms_scale;
         HIPCHK(nwk_launch_maxsim_pre(h->stream, tp));
+        snprintf(h->tile_kernel, sizeof h->tile_kernel, "%s", (h->dp16 <= 128 && h->opt_ms_strip != 1) ? "nwk_maxsim_pre_ring16_kernel" : "nwk_maxsim_pre_kernel");
     } else {
         HIPCHK(nwk_launch_maxsim(h->stream, tp, dense));
+        if (!dense) snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_maxsim_kernel<false>");
     }
     ev_end(h, e);
     if (prescreen) {

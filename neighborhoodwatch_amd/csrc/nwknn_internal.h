@@ -33,7 +33,7 @@ struct NwkTileParams {
     int sq_shift;                  // super-tile = (1 << sq_shift) query tiles x (64 >> sq_shift) base tiles
     int dp;
     int cap;
-    unsigned long long* dbg;       // dev builds only: per-workgroup stamps {t_start, t_loop, t_loop_end, t_end, rt_start, rt_end, xcc, 0}
+    unsigned long long* dbg;       // -DNWKNN_DEV builds only (read through NWK_DBG): per-workgroup stamps {t_start, t_loop, t_loop_end, t_end, rt_start, rt_end, xcc, 0}
     // fp16 pre-screen of the exact fp32 search (nwk_launch_tile_prescreen): qp/bp are the SCALED fp16 copies, qn/bn the canonical
     // fp32 norms; a pair passes when  acc >= pre_scale * (row(q) + col(b))  with the error bound of DESIGN.md folded into row/col
     float pre_scale;               // s_q * s_b (power of two): the accumulators hold pre_scale * dot
@@ -41,13 +41,12 @@ struct NwkTileParams {
     float pre_aq, pre_ab;          // absolute terms: pre_aq * sqrt(|b|^2) and pre_ab * sqrt(|q|^2)
     float pre_cst;
     float pre_inv_scale;           // 1 / pre_scale
-    int f16_shape;                 // fp16 kernels: 0 = v_mfma_f32_32x32x16_f16, 1 = v_mfma_f32_16x16x32_f16, 2 = 4-wave workgroups, two per CU, 3 = 16x16x32 streaming form
+    int f16_shape;                 // fp16 tile kernel build (all on v_mfma_f32_16x16x32_f16): 1 = burst form, 3 = streaming form
     const float* ms_rq;            // MaxSim pre-screen: per-query and per-doc parts of the score bound
     const float* ms_cd;
     int walk_q_fastest;            // 1: inside a super-tile the QUERY tile index runs fastest (consecutive blocks share a base tile), 0: the base tile index
-    int tiles_per_wg;              // 16x16x32 kernel: consecutive base tiles a workgroup walks (strip); the launcher turns n_btiles into strips
+    int tiles_per_wg;              // fp16 kernels: consecutive base tiles a workgroup walks (strip); the launcher turns n_btiles into strips
     int n_btiles_real;             // filled in by the launcher: base tiles of this launch
-    int ms_ring;                   // MaxSim pre-screen, d <= 128: 1 = nwk_maxsim_pre_ring_kernel, 0 = nwk_maxsim_pre_strip_kernel (option "ms_ring")
 };
 
 struct NwkRescoreParams {
@@ -100,13 +99,12 @@ struct NwkCompactParams {
 hipError_t nwk_launch_gen(hipStream_t st, uint64_t seed, long long row0, long long rows, int d, float* out);
 hipError_t nwk_launch_gen_f16(hipStream_t st, uint64_t seed, long long row0, long long rows, int d, void* out);
 hipError_t nwk_launch_prep_f16(hipStream_t st, const void* raw, int raw_is_f16, long long rows, int d, long long rows_pad, int dp, void* prepared, float* norms);
-hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool dense, int diag);
+hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool dense, int pre);   // every fp16 tile launch: raw sums (pre = 0) or pre-screen (pre = 1)
 hipError_t nwk_launch_tile_f16p(hipStream_t st, const NwkTileParams& p, int metric, int pre, unsigned grid);   // streaming form (f16_mfma = 3)
 hipError_t nwk_launch_prep_strided(hipStream_t st, const void* raw, int in_dtype, long long rs, long long ks, long long rows, int d,
                                    long long rows_pad, int dp, int out_f16, void* prepared, float* norms);
 hipError_t nwk_launch_prep(hipStream_t st, const float* raw, long long rows, int d, long long rows_pad, int dp, float* prepared, float* norms);
 hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool dense, int tile_rows, int diag, int occ);   // occ: workgroups per CU of the 256-row shape (2 or 3)
-hipError_t nwk_launch_tile_prescreen(hipStream_t st, NwkTileParams p, int metric, bool dense);
 hipError_t nwk_launch_half_copy16(hipStream_t st, const void* rows16, long long rows_pad, int dp, float scale, const float* norms, void* out16);
 hipError_t nwk_launch_maxabs_f16(hipStream_t st, const void* x, long long n, unsigned int* out_bits);
 hipError_t nwk_launch_rescore(hipStream_t st, const NwkRescoreParams& p, int metric, long long nq_pad);

@@ -44,18 +44,53 @@ def allgather_partials(dist, idx, group=None):
     return cd.to(dist.device), ci.to(idx.device)
 
 
-def sharded_search(search_shard: Callable, merge: Callable, queries, k: int, shard_lo: int, group=None):
+def _timed_allgather(dist, idx, group, timings):
+    """allgather_partials with its duration added to ``timings['allgather_ms']``: HIP events on torch's current stream for
+    device tensors under RCCL (the collective runs on RCCL's stream, which the current stream waits for), the host clock otherwise."""
+    import time
+    import torch
+    import torch.distributed as td
+    if timings is None:
+        return allgather_partials(dist, idx, group)
+    on_dev = dist.is_cuda and td.get_backend(group) == "nccl"
+    if on_dev:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = allgather_partials(dist, idx, group)
+        e1.record()
+        e1.synchronize()
+        timings["allgather_ms"] = timings.get("allgather_ms", 0.0) + e0.elapsed_time(e1)
+    else:
+        t0 = time.perf_counter()
+        out = allgather_partials(dist, idx, group)
+        if dist.is_cuda:
+            torch.cuda.synchronize(dist.device)
+        timings["allgather_ms"] = timings.get("allgather_ms", 0.0) + (time.perf_counter() - t0) * 1e3
+    timings["allgather_bytes"] = int(out[0].numel() * 4 + out[1].numel() * 8)
+    return out
+
+
+def sharded_search(search_shard: Callable, merge: Callable, queries, k: int, shard_lo: int, group=None, timings=None):
     """search_shard(queries, k, index_offset) -> (dist [Q,k] f32 tensor, idx [Q,k] i64 tensor, global ids);
-    merge(dists [W,Q,k], idx [W,Q,k], k) -> ([Q,k], [Q,k]).  Returns the merged table (identical on all ranks)."""
+    merge(dists [W,Q,k], idx [W,Q,k], k) -> ([Q,k], [Q,k]).  Returns the merged table (identical on all ranks).
+    ``timings`` (a dict) accumulates ``allgather_ms`` / ``merge_ms`` of the exchange step (the merge call is blocking: host clock)."""
+    import time
     import torch.distributed as td
     dist, idx = search_shard(queries, k, shard_lo)
     if not td.is_initialized() or td.get_world_size(group) == 1:
         return dist, idx
-    gd, gi = allgather_partials(dist, idx, group)
-    return merge(gd, gi, k)
+    gd, gi = _timed_allgather(dist, idx, group, timings)
+    t0 = time.perf_counter()
+    out = merge(gd, gi, k)
+    if timings is not None:
+        if getattr(out[0], "is_cuda", False):
+            import torch
+            torch.cuda.synchronize(out[0].device)
+        timings["merge_ms"] = timings.get("merge_ms", 0.0) + (time.perf_counter() - t0) * 1e3
+    return out
 
 
-def query_sharded_search(search_all: Callable, queries, k: int, group=None):
+def query_sharded_search(search_all: Callable, queries, k: int, group=None, timings=None):
     """The zero-collective alternative for jobs whose base fits one GPU (C2, C3): every rank holds the WHOLE base and
     searches its contiguous slice of the query rows (``shard_bounds`` over the queries); the slices are concatenated in rank
     order by one all-gather -- there is nothing to merge, a query's neighbours all come from one rank.
@@ -68,9 +103,14 @@ def query_sharded_search(search_all: Callable, queries, k: int, group=None):
     nq = queries.shape[0]
     lo, hi = shard_bounds(nq, world, rank)
     rows = -(-nq // world)                                        # slices differ by at most one row: pad to the longest
-    dist, idx = search_all(queries[lo:hi], k)
-    pd_ = torch.zeros((rows, k), dtype=dist.dtype, device=dist.device); pd_[:hi - lo] = dist
-    pi_ = torch.zeros((rows, k), dtype=idx.dtype, device=idx.device); pi_[:hi - lo] = idx
-    gd, gi = allgather_partials(pd_, pi_, group)                  # [world, rows, k]
+    # fewer queries than ranks: a rank with an empty slice searches nothing and contributes only padding (the engine refuses an
+    # empty query set, and a rank that raised here would leave the others blocked in the all-gather)
+    pd_ = torch.zeros((rows, k), dtype=torch.float32, device=queries.device)
+    pi_ = torch.zeros((rows, k), dtype=torch.int64, device=queries.device)
+    if hi > lo:
+        dist, idx = search_all(queries[lo:hi], k)
+        pd_[:hi - lo] = dist
+        pi_[:hi - lo] = idx
+    gd, gi = _timed_allgather(pd_, pi_, group, timings)           # [world, rows, k]
     parts = [shard_bounds(nq, world, r) for r in range(world)]
     return (torch.cat([gd[r, :b - a] for r, (a, b) in enumerate(parts)]), torch.cat([gi[r, :b - a] for r, (a, b) in enumerate(parts)]))

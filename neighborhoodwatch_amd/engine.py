@@ -78,6 +78,10 @@ class KnnEngine:
         check(self._L.nwknn_get_stats(self._h, ctypes.byref(s)), "nwknn_get_stats")
         return s.as_dict()
 
+    def tile_kernel_name(self) -> str:
+        """The distance-tile kernel behind the last search's filtered launches, as rocprofv3 spells it."""
+        return (self._L.nwknn_tile_kernel_name(self._h) or b"").decode()
+
     # -- data -------------------------------------------------------------------------------------
     @staticmethod
     def _matrix(x, what: str):
@@ -136,9 +140,19 @@ class KnnEngine:
         """-> (ctypes pointer table [chunk][dim], ctypes int64 rows per chunk, n_chunks, rows, dim, dtype id, keepalive list).
         Every column is a 1-D array, or a list of 1-D arrays (the chunks of a pyarrow ChunkedArray: one per parquet row group);
         all columns share one dtype (float32 | float64 | float16) and one chunking.  Nothing is concatenated here."""
-        cols = [[np.asarray(x) for x in c] if isinstance(c, (list, tuple)) else [np.asarray(c)] for c in columns]
+        def chunks_of(c):
+            # a list/tuple whose elements are themselves 1-D array-likes is a list of chunks; anything else (an array, a plain
+            # Python list of numbers) is ONE chunk
+            if isinstance(c, (list, tuple)) and len(c) > 0 and all(np.ndim(x) == 1 for x in c):
+                return [np.asarray(x) for x in c]
+            return [np.asarray(c)]
+        cols = [chunks_of(c) for c in columns]
         if not cols:
             raise ValueError(f"{what}: no columns")
+        for j, c in enumerate(cols):
+            for x in c:
+                if x.ndim != 1:
+                    raise ValueError(f"{what}: column {j} must be a 1-D array or a list of 1-D chunks, got shape {x.shape}")
         dt = cols[0][0].dtype if cols[0] else np.dtype(np.float32)
         if dt not in (np.float32, np.float64, np.float16):
             cols = [[x.astype(np.float32) for x in c] for c in cols]

@@ -53,6 +53,18 @@ def test_argument_errors_do_not_need_a_gpu():
     assert L.nwknn_destroy(None) == 0
 
 
+def test_wrong_result_switches_are_not_in_the_shipped_library():
+    """Timing ablations, in-kernel stamps, a shrunken pre-screen bound and unpruned rescoring exist under -DNWKNN_DEV only: the default
+    build refuses them by name (no handle, hence no GPU, is needed to see that), and the build script does not define the macro."""
+    from neighborhoodwatch_amd import _lib, build
+    L = _lib.load()
+    for name, value in ((b"diag", 1), (b"diag", 32), (b"dbg_ptr", 4096), (b"pre_eps_pct", 99), (b"prescreen_prune", 0)):
+        assert L.nwknn_set_option(None, name, value) == -1
+        assert b"developer builds" in L.nwknn_last_error(), (name, L.nwknn_last_error())
+    assert L.nwknn_set_option(None, b"pre_eps_pct", 100) == -1 and b"null handle" in L.nwknn_last_error()   # a legal value gets as far as the handle check
+    assert not any("NWKNN_DEV" in f for f in build.FLAGS)
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import torch
     if torch.cuda.is_available():

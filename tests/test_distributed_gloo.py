@@ -142,3 +142,46 @@ def test_three_uneven_ranks_break_cross_shard_ties_by_global_row_id(tmp_path, or
         g = np.load(tmp_path / f"trank{r}.npz")
         assert np.array_equal(g["idx"], ri), f"rank {r}: merged ids differ from the single-shard result"
         assert np.array_equal(g["dist"].view(np.uint32), rd.view(np.uint32))
+
+
+def _worker_few(rank, world, port, out_dir):
+    """Fewer queries than ranks (2 over 3): the rank with an empty slice contributes padding only; nobody hangs in the all-gather."""
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as td
+    from neighborhoodwatch_amd.distributed import query_sharded_search
+    from oracle import cpu_oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    B, Q, d, k = 300, 2, 16, 5
+    base = orc.gen(orc.SEED_BASE, 0, B, d)
+    queries = torch.from_numpy(orc.gen(orc.SEED_QUERY, 0, Q, d))
+    calls = []
+
+    def search_all(qs, kk):
+        assert qs.shape[0] > 0, "an empty slice must not reach the engine"
+        calls.append(qs.shape[0])
+        dd, ii = orc.knn_canonical(base, qs.numpy(), kk, "sqeuclidean")
+        return torch.from_numpy(dd), torch.from_numpy(ii)
+
+    timings = {}
+    dist, idx = query_sharded_search(search_all, queries, k, None, timings)
+    assert timings["allgather_ms"] >= 0.0 and timings["allgather_bytes"] == world * 1 * k * 12
+    np.savez(Path(out_dir) / f"frank{rank}.npz", dist=dist.numpy(), idx=idx.numpy(), calls=np.array(calls, dtype=np.int64))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_fewer_queries_than_ranks_does_not_hang(tmp_path, oracle):
+    world = 3
+    mp.spawn(_worker_few, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    base = oracle.gen(oracle.SEED_BASE, 0, 300, 16)
+    queries = oracle.gen(oracle.SEED_QUERY, 0, 2, 16)
+    rd, ri = oracle.knn_canonical(base, queries, 5, "sqeuclidean")
+    n_calls = 0
+    for r in range(world):
+        g = np.load(tmp_path / f"frank{r}.npz")
+        assert np.array_equal(g["idx"], ri) and np.array_equal(g["dist"].view(np.uint32), rd.view(np.uint32))
+        n_calls += len(g["calls"])
+    assert n_calls == 2                                           # shard_bounds(2, 3, r): one rank holds no query row

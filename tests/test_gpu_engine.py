@@ -324,12 +324,17 @@ def test_non_finite_inputs_do_not_break_parity(engine, oracle):
         assert np.array_equal(dist.view(np.uint32), rd.view(np.uint32))
 
 
-def test_default_opts_environment_hook(monkeypatch):
-    """NWKNN_DEFAULT_OPTS applies options to every new handle (how the whole suite is run against an alternative kernel build);
-    a malformed entry or an unknown option makes nwknn_create fail loudly instead of being ignored."""
+def test_default_opts_environment_hook(monkeypatch, capfd):
+    """NWKNN_DEFAULT_OPTS applies options to every new handle (how the whole suite is run against an alternative kernel build) and
+    says so on stderr; a malformed entry, an unknown option or a developer-only switch makes nwknn_create fail loudly."""
     from neighborhoodwatch_amd import KnnEngine
     monkeypatch.setenv("NWKNN_DEFAULT_OPTS", "f16_mfma=1,tile_occ=2")
     KnnEngine(0).close()
+    assert "NWKNN_DEFAULT_OPTS" in capfd.readouterr().err
+    for dev_only in ("diag=1", "dbg_ptr=4096", "pre_eps_pct=50", "prescreen_prune=0"):
+        monkeypatch.setenv("NWKNN_DEFAULT_OPTS", dev_only)
+        with pytest.raises(ValueError):
+            KnnEngine(0)
     monkeypatch.setenv("NWKNN_DEFAULT_OPTS", "f16_mfma")
     with pytest.raises(ValueError, match="name=value"):          # NWKNN_EINVAL
         KnnEngine(0)

@@ -142,18 +142,19 @@ def test_random_cases_against_the_oracle(oracle, seed):
 
 
 @pytest.mark.parametrize("metric", EXACT)
-def test_two_workgroup_tile_shape_with_exact_mode_walks_the_right_tiles(oracle, metric):
-    """Dev option f16_mfma=2 (256 x 128 tiles) together with exact fp16 mode: the dense first chunk always runs the 256-row
-    16x16x32 build, so its tile count must be in 256-row tiles whatever f16_mfma says (counted in 128-row tiles the kernel
-    walked twice the chunk and past the base allocation)."""
+@pytest.mark.parametrize("form", [1, 3])
+def test_exact_mode_on_either_kernel_form(oracle, metric, form):
+    """Exact fp16 mode with the burst (1) or the streaming (3) form selected: the dense first chunk always runs the burst build (the
+    only one with a dense mode), the filtered chunks the selected one; the result is the oracle's bits either way."""
     from neighborhoodwatch_amd import KnnEngine
     rng = np.random.default_rng(11)
     base16 = rng.standard_normal((3000, 96)).astype(np.float16)
     queries16 = rng.standard_normal((70, 96)).astype(np.float16)
     with KnnEngine(0) as eng:
-        eng.set_option("f16_mfma", 2)
+        eng.set_option("f16_mfma", form)
         eng.set_base(base16)
         dist, idx = eng.search(queries16, 20, metric)
         assert eng.stats()["prescreen"] == 1
+        assert eng.tile_kernel_name().startswith("nwk_tile_kernel_f16s" if form == 1 else "nwk_tile_kernel_f16p")
     rd, ri = oracle.knn_canonical(base16.astype(np.float32), queries16.astype(np.float32), 20, metric)
     assert np.array_equal(idx, ri) and _bitwise(dist, rd)

@@ -109,24 +109,23 @@ def test_hip_maxsim_prescreened_overflow_repair_unit_tokens_and_offsets(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ring,strip,mfma", [(1, 0, 1), (1, 3, 1), (1, 64, 1), (1, 0, 0), (1, 5, 0), (0, 8, 0), (0, 1, 0)])
-def test_hip_maxsim_prescreen_kernel_forms_give_the_same_bits(oracle, ring, strip, mfma):
-    """The forms of the d <= 128 pre-screen tile kernel (ring on either MFMA shape with auto / odd / longest strips, the strip kernel,
-    the plain kernel) list under the same bound, so each of them must end in the oracle's bits; d = 64 is two k-slabs per tile in the
+@pytest.mark.parametrize("strip", [0, 3, 5, 64, 1])
+def test_hip_maxsim_prescreen_kernel_forms_give_the_same_bits(oracle, strip):
+    """The forms of the d <= 128 pre-screen tile kernel (the ring kernel with auto / odd / longest strips; ms_strip = 1: the any-d
+    kernel) list under the same bound, so each of them must end in the oracle's bits; d = 64 is two k-slabs per tile in the
     four-stage ring (stage != k-slab), with a document count whose last strip is ragged."""
     from neighborhoodwatch_amd import KnnEngine
     for nd, nq, k, d in ((9000, 21, 64, 128), (3333, 6, 100, 64)):
         docs, qs = _tokens(oracle, 0xD1 + nd, nd, 64, d), _tokens(oracle, 0xD2 + nq, nq, 32, d)
         with KnnEngine(0, profile=True) as eng:
             eng.set_prescreen(True)
-            eng.set_option("ms_ring", ring)
             eng.set_option("ms_strip", strip)
-            eng.set_option("ms_mfma", mfma)
             eng.maxsim_set_docs(docs)
             s, i = eng.maxsim_search(qs, k)
             assert eng.stats()["prescreen"] == 1
+            assert eng.tile_kernel_name() == ("nwk_maxsim_pre_kernel" if strip == 1 else "nwk_maxsim_pre_ring16_kernel")
         rs, ri = oracle.maxsim_canonical(docs, qs, k)
-        assert np.array_equal(i, ri), f"doc ids differ at {(i != ri).sum()} of {i.size} positions (ring={ring}, strip={strip}, mfma={mfma}, d={d})"
+        assert np.array_equal(i, ri), f"doc ids differ at {(i != ri).sum()} of {i.size} positions (strip={strip}, d={d})"
         assert np.array_equal(s.view(np.uint32), rs.view(np.uint32))
 
 
