@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the brute-force kNN hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|dev]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|...]
+
+With N > 1 and no RANK in the environment the script starts its own N ranks (a child `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py ...`, one rank per GPU over RCCL) before
+anything touches the GPU, relays the child's output and exits with its code; launched under torch.distributed.run by the caller
+it joins the existing rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
 
 Metric (BASELINE.json): queries/s (+ pairwise-distance TFLOP/s) for 100k queries x 10M base rows, d=1024, k=100,
 fp32 squared-L2 ("c3"; 41 GB of base fits one 288 GB MI355X, so N=1 runs the same job).  One *step* is one
@@ -14,14 +17,21 @@ fixed: strong scaling); queries are replicated.  Inputs are seeded synthetic emb
 
 The JSON line also carries
   roofline     -- distance-tile kernel: algorithmic FLOPs (2*Q*B*d per launch set) / its summed HIP-event time,
-                  against the 157.3 TFLOP/s dense f32 MFMA peak of MI355X_MICROARCH.md;
-  cpu_baseline -- numpy/BLAS brute force (oracle.cpu_oracle.knn_blas_fp32) on a bounded sample, rank 0, N=1 only.
+                  against the dense f32 / f16 MFMA peak of MI355X_MICROARCH.md; `kernel` is the kernel that ran, as rocprofv3 spells it;
+  cpu_baseline -- numpy/BLAS brute force (oracle.cpu_oracle.knn_blas_fp32) on a bounded sample, rank 0, N=1 only, with
+                  sklearn.neighbors.NearestNeighbors(algorithm='brute') on a second sample beside it (`cpu_baseline.sklearn`);
+  ranks / devices / collective -- what torch.distributed saw: world size, every rank's GPU, backend and the per-step time of the
+                  all-gather and of the merge (N > 1);
+  secondary    -- N=1, default workload only: the other BASELINE configs one GPU can hold (C2; one of eight C3 shards; the C4 per-GPU
+                  slice), a few steps each with their own value / ms_per_step / roofline, on the same clock as the headline.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -46,14 +56,29 @@ WORKLOADS = {
     "dev5": (256, 100_000, 128, 100, "maxsim", "f32", "dev5: MaxSim 256 queries vs 100k docs (not a headline number)"),
     "dev16": (32_768, 1_048_576, 1536, 100, "sqeuclidean", "f16", "dev16: 32k x 1M, d=1536, k=100, fp16 (not a headline number)"),
 }
+SECONDARY = (("c2", 10, 2), ("c3shard", 3, 2), ("c4gpu", 2, 0))     # (workload, timed steps, timed steps of its pre-screened leg); 1 warm-up each
 SEED_BASE, SEED_QUERY = 0x6E770001, 0x6E770002
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0}      # MI355X_MICROARCH.md: dense f32 / f16 MFMA peaks
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` as typed: start the N ranks as a CHILD process (never an exec: this process has not touched the
+    GPU and never will), pass its output through, return its exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the pool's host driver supports dmabuf IPC only (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    print(f"bench.py: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def recorded_traffic(workload):
     """HBM/fabric bytes per launch of the tile kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
     gfx950 correction + WRITE_SIZE, separate passes; profiles/traffic_<workload>.json).  PMC cannot be sampled from inside
-    this process, so the figure is the recorded one for this workload, or None."""
+    this process, so the figure is the recorded one for this workload (its `source` says which round's build), or None."""
     f = ROOT / "profiles" / f"traffic_{workload}.json"
     try:
         rec = json.loads(f.read_text())
@@ -62,8 +87,9 @@ def recorded_traffic(workload):
         return None
 
 
-def cpu_baseline(eng, base_dev, queries_dev, k, metric, full_b):
-    """numpy/BLAS brute force on a bounded sample of the same workload, timed on this box's host cores."""
+def cpu_baseline(base_dev, queries_dev, k, metric, full_b, flop_budget=0.7e13):
+    """Brute force on the host cores over a bounded sample of the same workload: numpy/BLAS (the oracle's sgemm form) and, beside it,
+    scikit-learn's NearestNeighbors(algorithm='brute').  Each leg is sized to ~flop_budget of sgemm (10-20 s on a 16..64-core host)."""
     import numpy as np
     from oracle import cpu_oracle
     cores = len(os.sched_getaffinity(0))
@@ -74,7 +100,7 @@ def cpu_baseline(eng, base_dev, queries_dev, k, metric, full_b):
         blas_threads = cores
     d = base_dev.shape[1]
     qs = min(queries_dev.shape[0], 2048)
-    bs = min(base_dev.shape[0], max(10_000, int(1.0e13 / (2.0 * qs * d))))     # ~10 TFLOP of sgemm: 10-30 s on a 16..64-core host
+    bs = min(base_dev.shape[0], max(10_000, int(flop_budget / (2.0 * qs * d))))
     base = base_dev[:bs].float().cpu().numpy()
     qry = queries_dev[:qs].float().cpu().numpy()
     cpu_oracle.knn_blas_fp32(base[: min(bs, 20000)], qry[:64], min(k, 100), metric)      # warm-up
@@ -82,11 +108,228 @@ def cpu_baseline(eng, base_dev, queries_dev, k, metric, full_b):
     cpu_oracle.knn_blas_fp32(base, qry, k, metric)
     dt = time.perf_counter() - t0
     scale = bs / float(full_b)                                                   # brute force is linear in B
-    return {
+    out = {
         "value": qs / dt * scale, "unit": "queries/s", "cores": int(blas_threads), "kind": "port",
         "sample": f"{qs} queries x first {bs} of {full_b} base rows in {dt:.2f}s (numpy sgemm + argpartition, "
                   f"oracle.cpu_oracle.knn_blas_fp32); rate scaled by {bs}/{full_b} to the full base",
     }
+    if metric in ("sqeuclidean", "cosine"):
+        try:
+            from sklearn.neighbors import NearestNeighbors
+            nn = NearestNeighbors(n_neighbors=min(k, bs), algorithm="brute", metric=metric, n_jobs=-1)
+            nn.fit(base[: min(bs, 20000)]).kneighbors(qry[:64], return_distance=True)     # warm-up
+            t0 = time.perf_counter()
+            nn.fit(base).kneighbors(qry, return_distance=True)
+            dts = time.perf_counter() - t0
+            out["sklearn"] = {"value": qs / dts * scale, "unit": "queries/s", "cores": cores, "kind": "library",
+                              "sample": f"sklearn.neighbors.NearestNeighbors(algorithm='brute', metric='{metric}', n_jobs=-1).kneighbors on the same "
+                                        f"{qs} x {bs} sample in {dts:.2f}s; same scaling"}
+        except Exception as e:                                                    # the baseline is a report, never a reason to lose the line
+            out["sklearn"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+class Bench:
+    def __init__(self, args):
+        # before anything initialises the HIP runtime: the host driver of this pool only supports dmabuf IPC (RCCL needs it)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import torch
+        import torch.distributed as td
+        from neighborhoodwatch_amd import KnnEngine
+        self.torch, self.td, self.args = torch, td, args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                             "(or plain `python bench.py --gpus N`, which starts the ranks itself)")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+        # NWKNN_DIST_BACKEND=gloo rehearses the N-rank path on a box with fewer GPUs than ranks (ranks share devices, the
+        # all-gather goes through the host); production is nccl == RCCL, one rank per GPU.
+        self.backend = os.environ.get("NWKNN_DIST_BACKEND", "nccl") if self.world > 1 else "none"
+        n_dev = torch.cuda.device_count()
+        if self.backend == "nccl" and n_dev < self.world:
+            raise SystemExit(f"--gpus {self.world} over RCCL needs {self.world} GPUs, this node shows {n_dev} "
+                             "(NWKNN_DIST_BACKEND=gloo rehearses the N-rank path on fewer)")
+        self.dev_index = local_rank if self.backend == "nccl" else local_rank % n_dev
+        torch.cuda.set_device(self.dev_index)
+        if self.world > 1:
+            if self.backend == "nccl":
+                td.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.dev_index))
+            else:
+                td.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+        self.red_dev = "cuda" if self.backend == "nccl" else "cpu"
+        self.eng = KnnEngine(self.dev_index, profile=True)
+        for kvs in args.opt:
+            for kv in kvs.split(","):
+                name, value = kv.split("=")
+                self.eng.set_option(name, int(value))
+
+    # ---- what torch.distributed saw ---------------------------------------------------------------------------------------------
+    def devices(self):
+        torch, td = self.torch, self.td
+        props = torch.cuda.get_device_properties(self.dev_index)
+        mine = {"rank": self.rank, "device": self.dev_index, "name": props.name, "gcn_arch": getattr(props, "gcnArchName", ""),
+                "uuid": str(getattr(props, "uuid", "")), "hbm_gib": round(props.total_memory / 2**30, 1)}
+        if self.world == 1:
+            return [mine]
+        gathered = [None] * self.world
+        td.all_gather_object(gathered, mine)
+        return gathered
+
+    # ---- one workload ----------------------------------------------------------------------------------------------------------------
+    def run(self, name, steps, warmup, pre_steps, metric_override=None, shard="base", verify=False, with_cpu=False):
+        torch, td, eng, world, rank = self.torch, self.td, self.eng, self.world, self.rank
+        from neighborhoodwatch_amd.distributed import query_sharded_search, shard_bounds, sharded_search
+        Q, B, d, k, metric, dtype, desc = WORKLOADS[name]
+        if metric_override and metric != "maxsim":
+            metric = metric_override
+            desc += f" [metric overridden: {metric}]"
+        peak = MFMA_PEAK_TFLOPS[dtype]
+        by_query = shard == "queries" and world > 1
+        lo, hi = (0, B) if by_query else shard_bounds(B, world, rank)
+        maxsim = metric == "maxsim"
+        if maxsim:                                                    # token matrices: docs [B, 64, d], queries [Q, 32, d]
+            base_raw = eng.generate(SEED_BASE, lo * 64, (hi - lo) * 64, d, dtype).view(hi - lo, 64, d)
+            queries = eng.generate(SEED_QUERY, 0, Q * 32, d, dtype).view(Q, 32, d)
+        else:
+            base_raw = eng.generate(SEED_BASE, lo, hi - lo, d, dtype)     # this rank's shard, raw row-major in HBM (an fp16 base selects the fp16 path)
+            queries = eng.generate(SEED_QUERY, 0, Q, d, dtype)            # replicated
+        host_d = torch.empty((Q, k), dtype=torch.float32).pin_memory() if rank == 0 else None
+        host_i = torch.empty((Q, k), dtype=torch.int64).pin_memory() if rank == 0 else None
+
+        def search_shard(qs, kk, offset):
+            if maxsim:
+                eng.maxsim_set_docs(base_raw)
+                score, doc = eng.maxsim_search(qs, kk, doc_offset=offset)
+                return -score, doc                                    # ranked like distances through the shared merge
+            eng.set_base(base_raw)                                    # layout + norms are part of every job
+            return eng.search(qs, kk, metric, index_offset=offset)
+
+        def fence():
+            if world > 1:
+                td.barrier()
+            torch.cuda.synchronize()
+
+        def measure(n_steps, n_warmup):
+            """n_warmup untimed + n_steps timed steps, fenced on both sides; MAX over ranks of the elapsed time, SUM of the kernel accounting."""
+            agg = {"tile_ms": 0.0, "tile_flops": 0.0, "tile_launches": 0, "compact_ms": 0.0, "prep_ms": 0.0, "rescan_launches": 0,
+                   "overflowed_queries": 0, "rescore_ms": 0.0, "prescreen": 0}
+            coll = {}
+            last = None
+
+            def step(record):
+                tm = coll if record else None
+                if by_query:
+                    dist, idx = query_sharded_search(lambda qs, kk: search_shard(qs, kk, 0), queries, k, None, tm)
+                else:
+                    dist, idx = sharded_search(search_shard, eng.merge, queries, k, lo, None, tm)
+                if rank == 0:
+                    host_d.copy_(dist, non_blocking=True)
+                    host_i.copy_(idx, non_blocking=True)
+                torch.cuda.synchronize()
+                if record:
+                    s = eng.stats()
+                    for key in agg:
+                        agg[key] += s[key]
+                return dist, idx
+
+            for _ in range(n_warmup):
+                step(False)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
+                last = step(True)
+            fence()
+            elapsed = time.perf_counter() - t0
+            kernel = eng.tile_kernel_name()
+            if world > 1:
+                t = torch.tensor([elapsed], dtype=torch.float64, device=self.red_dev)
+                td.all_reduce(t, op=td.ReduceOp.MAX)
+                elapsed = float(t.item())
+                fl = torch.tensor([agg["tile_flops"], agg["tile_ms"]], dtype=torch.float64, device=self.red_dev)
+                td.all_reduce(fl, op=td.ReduceOp.SUM)
+                sum_flops, sum_ms = float(fl[0]), float(fl[1])
+                cm = torch.tensor([coll.get("allgather_ms", 0.0), coll.get("merge_ms", 0.0)], dtype=torch.float64, device=self.red_dev)
+                td.all_reduce(cm, op=td.ReduceOp.MAX)
+                coll = {"backend": self.backend, "allgather_ms": float(cm[0]) / n_steps, "merge_ms": float(cm[1]) / n_steps,
+                        "allgather_bytes_per_rank": coll.get("allgather_bytes", 0),
+                        "timing": "per step, max over ranks; all-gather: HIP events on the rank's current stream (RCCL) or host clock "
+                                  "around the host-staged gloo exchange; merge: host clock around the blocking merge call"}
+            else:
+                sum_flops, sum_ms = agg["tile_flops"], agg["tile_ms"]
+                coll = None
+            return elapsed, agg, sum_flops, sum_ms, last, kernel, coll
+
+        def roofline(agg_, flops_, ms_, n_steps, kernel, pk, traffic):
+            ach = (flops_ / 1e12) / (ms_ / 1e3) if ms_ > 0 else 0.0      # FLOPs summed over ranks / kernel time summed over ranks = per-GPU rate
+            # one launch per search is the dense first chunk (cap/2 base rows, a different template instance in the
+            # rocprofv3 stats, ~1 ms): the per-launch figures are over the filtered launches that carry the work
+            n_l = max(agg_["tile_launches"] - n_steps, 1)
+            return {"bound": "mfma", "achieved": ach, "peak": pk, "unit": "TFLOP/s", "frac": ach / pk, "traffic": traffic,
+                    "traffic_note": "bytes per launch, rocprofv3 PMC passes recorded in profiles/ (not sampled live)",
+                    "kernel": kernel, "launches": n_l, "avg_launch_ms": agg_["tile_ms"] / n_l, "flops_per_launch": agg_["tile_flops"] / n_l}
+
+        elapsed, agg, sum_flops, sum_ms, last, kernel, coll = measure(steps, warmup)         # exactly K timed steps after W warm-up steps
+        flop_mult = 32 * 64 if maxsim else 1
+
+        # the same job through the fp16 pre-screen + fp32 rescoring (engine option "prescreen"): results must be the same bits
+        pre = None
+        if dtype == "f32" and pre_steps > 0 and not any("prescreen" in o for o in self.args.opt):
+            direct = (last[0].clone(), last[1].clone()) if rank == 0 else None
+            eng.set_prescreen(True)
+            p_warm = min(warmup, 1)
+            p_elapsed, p_agg, p_flops, p_ms, p_last, p_kernel, _ = measure(pre_steps, p_warm)
+            eng.set_prescreen(False)
+            if rank == 0:
+                pre = {
+                    "what": "same search, same bits out: fp16 MFMA pre-screen over scaled fp16 copies + canonical fp32 rescoring of every listed pair",
+                    "value": Q * pre_steps / p_elapsed, "unit": "queries/s", "steps": pre_steps, "warmup": p_warm, "ms_per_step": p_elapsed / pre_steps * 1e3,
+                    "pairwise_tflops": 2.0 * Q * B * d * flop_mult * pre_steps / p_elapsed / 1e12,
+                    "identical_to_direct": bool(torch.equal(direct[0], p_last[0])) and bool(torch.equal(direct[1], p_last[1])),
+                    "prescreen_searches": p_agg["prescreen"],
+                    "roofline": roofline(p_agg, p_flops, p_ms, pre_steps, p_kernel, MFMA_PEAK_TFLOPS["f16"],
+                                         recorded_traffic(name + "_prescreen") if world == 1 else None),
+                    "breakdown_ms_per_step": {"tile": p_agg["tile_ms"] / pre_steps, "rescore": p_agg["rescore_ms"] / pre_steps,
+                                              "compact": p_agg["compact_ms"] / pre_steps, "prep": p_agg["prep_ms"] / pre_steps,
+                                              "rescan_launches": p_agg["rescan_launches"], "overflowed_queries": p_agg["overflowed_queries"]},
+                }
+
+        out = None
+        if rank == 0:
+            out = {
+                "value": Q * steps / elapsed, "unit": "queries/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+                "dtype": dtype, "pairwise_tflops": 2.0 * Q * B * d * flop_mult * steps / elapsed / 1e12,
+                "config": {"workload": desc, "queries": Q, "base_rows": B, "dim": d, "k": k, "metric": metric,
+                           "parallelism": (f"query rows sharded x{world}, base replicated + RCCL all-gather of the [Q/N,k] slices" if by_query else
+                                           f"base rows sharded x{world}" + (" + RCCL all-gather of [Q,k] partials + merge" if world > 1 else ""))},
+                "roofline": roofline(agg, sum_flops, sum_ms, steps, kernel, peak, recorded_traffic(name) if world == 1 else None),
+                "breakdown_ms_per_step": {"tile": agg["tile_ms"] / steps, "compact": agg["compact_ms"] / steps,
+                                          "prep": agg["prep_ms"] / steps, "rescore": agg["rescore_ms"] / steps, "rescan_launches": agg["rescan_launches"],
+                                          "overflowed_queries": agg["overflowed_queries"]},
+            }
+            if coll is not None:
+                out["collective"] = coll
+            if pre is not None:
+                out["exact_prescreen"] = pre
+            if with_cpu and not maxsim:
+                out["cpu_baseline"] = cpu_baseline(base_raw, queries, k, metric, B)
+        ok = None
+        if verify and rank == 0:
+            if maxsim:
+                eng.maxsim_set_docs(eng.generate(SEED_BASE, 0, B * 64, d, dtype).view(B, 64, d))
+                rs, ri = eng.maxsim_search(queries, k)
+                rd = -rs
+            else:
+                full = eng.generate(SEED_BASE, 0, B, d, dtype)      # same dtype as the shards: an fp16 base selects the fp16 path again
+                eng.set_base(full)
+                rd, ri = eng.search(queries, k, metric)
+            ok = bool(torch.equal(ri, last[1])) and bool(torch.equal(rd, last[0]))
+        del base_raw, queries, last
+        torch.cuda.empty_cache()
+        return out, ok
 
 
 def main():
@@ -100,189 +343,49 @@ def main():
                          "'queries' replicates the base and shards the query rows (no merge; only when the base fits one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prescreen", action="store_true", help="skip the second measurement (fp16 pre-screen + fp32 rescoring)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary block (C2, one C3 shard, the C4 per-GPU slice) that follows the default workload at N=1")
     ap.add_argument("--verify", action="store_true", help="compare the merged result with a single-engine search of the whole base (small workloads)")
     ap.add_argument("--metric", default=None, choices=["sqeuclidean", "one_minus_dot", "cosine"], help="override the workload's metric (dev)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option (nwknn_set_option), dev use")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))              # nothing above has imported torch or touched the GPU
 
-    # before anything initialises the HIP runtime: the host driver of this pool only supports dmabuf IPC (RCCL needs it)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    import torch
-    import torch.distributed as td
-    from neighborhoodwatch_amd import KnnEngine
-    from neighborhoodwatch_amd.distributed import query_sharded_search, shard_bounds, sharded_search
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
-    # NWKNN_DIST_BACKEND=gloo rehearses the N-rank path on a box with fewer GPUs than ranks (ranks share devices, the
-    # all-gather goes through the host); production is nccl == RCCL, one rank per GPU.
-    backend = os.environ.get("NWKNN_DIST_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    if world > 1:
-        if backend == "nccl":
-            td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-        else:
-            td.init_process_group(backend, rank=rank, world_size=world)
-    red_dev = "cuda" if backend == "nccl" else "cpu"
-
-    Q, B, d, k, metric, dtype, desc = WORKLOADS[args.workload]
-    if args.metric and metric != "maxsim":
-        metric = args.metric
-        desc += f" [metric overridden: {metric}]"
-    peak = MFMA_PEAK_TFLOPS[dtype]
-    by_query = args.shard == "queries" and world > 1
-    lo, hi = (0, B) if by_query else shard_bounds(B, world, rank)
-    eng = KnnEngine(dev_index, profile=True)
-    for kvs in args.opt:
-        for kv in kvs.split(","):
-            name, value = kv.split("=")
-            eng.set_option(name, int(value))
-    maxsim = metric == "maxsim"
-    if maxsim:                                                    # token matrices: docs [B, 64, d], queries [Q, 32, d]
-        base_raw = eng.generate(SEED_BASE, lo * 64, (hi - lo) * 64, d, dtype).view(hi - lo, 64, d)
-        queries = eng.generate(SEED_QUERY, 0, Q * 32, d, dtype).view(Q, 32, d)
-    else:
-        base_raw = eng.generate(SEED_BASE, lo, hi - lo, d, dtype)     # this rank's shard, raw row-major in HBM (an fp16 base selects the fp16 path)
-        queries = eng.generate(SEED_QUERY, 0, Q, d, dtype)            # replicated
-    host_d = torch.empty((Q, k), dtype=torch.float32).pin_memory() if rank == 0 else None
-    host_i = torch.empty((Q, k), dtype=torch.int64).pin_memory() if rank == 0 else None
-
-    def search_shard(qs, kk, offset):
-        if maxsim:
-            eng.maxsim_set_docs(base_raw)
-            score, doc = eng.maxsim_search(qs, kk, doc_offset=offset)
-            return -score, doc                                    # ranked like distances through the shared merge
-        eng.set_base(base_raw)                                    # layout + norms are part of every job
-        return eng.search(qs, kk, metric, index_offset=offset)
-
-    def fence():
-        if world > 1:
-            td.barrier()
-        torch.cuda.synchronize()
-
-    def measure(n_steps, n_warmup):
-        """n_warmup untimed + n_steps timed steps, fenced on both sides; MAX over ranks of the elapsed time, SUM of the kernel accounting."""
-        agg = {"tile_ms": 0.0, "tile_flops": 0.0, "tile_launches": 0, "compact_ms": 0.0, "prep_ms": 0.0, "rescan_launches": 0,
-               "overflowed_queries": 0, "rescore_ms": 0.0, "prescreen": 0}
-        last = None
-
-        def step(record):
-            if by_query:
-                dist, idx = query_sharded_search(lambda qs, kk: search_shard(qs, kk, 0), queries, k, None)
-            else:
-                dist, idx = sharded_search(search_shard, eng.merge, queries, k, lo, None)
-            if rank == 0:
-                host_d.copy_(dist, non_blocking=True)
-                host_i.copy_(idx, non_blocking=True)
-            torch.cuda.synchronize()
-            if record:
-                s = eng.stats()
-                for key in agg:
-                    agg[key] += s[key]
-            return dist, idx
-
-        for _ in range(n_warmup):
-            step(False)
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(n_steps):
-            last = step(True)
-        fence()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-            td.all_reduce(t, op=td.ReduceOp.MAX)
-            elapsed = float(t.item())
-            fl = torch.tensor([agg["tile_flops"], agg["tile_ms"]], dtype=torch.float64, device=red_dev)
-            td.all_reduce(fl, op=td.ReduceOp.SUM)
-            sum_flops, sum_ms = float(fl[0]), float(fl[1])
-        else:
-            sum_flops, sum_ms = agg["tile_flops"], agg["tile_ms"]
-        return elapsed, agg, sum_flops, sum_ms, last
-
-    elapsed, agg, sum_flops, sum_ms, last = measure(args.steps, args.warmup)         # exactly K timed steps after W warm-up steps
-
-    # the same job through the fp16 pre-screen + fp32 rescoring (engine option "prescreen"): results must be the same bits
-    pre = None
-    if dtype == "f32" and not args.no_prescreen and not any("prescreen" in o for o in args.opt):
-        direct = (last[0].clone(), last[1].clone()) if rank == 0 else None
-        eng.set_prescreen(True)
-        p_steps, p_warm = min(args.steps, 5), min(args.warmup, 1)     # a secondary figure: bounded so the default run stays within minutes
-        p_elapsed, p_agg, p_flops, p_ms, p_last = measure(p_steps, p_warm)
-        eng.set_prescreen(False)
-        if rank == 0:
-            p_ach = (p_flops / 1e12) / (p_ms / 1e3) if p_ms > 0 else 0.0     # FLOPs summed over ranks / kernel time summed over ranks = per-GPU rate
-            pre = {
-                "what": "same search, same bits out: fp16 MFMA pre-screen over scaled fp16 copies + canonical fp32 rescoring of every listed pair",
-                "value": Q * p_steps / p_elapsed, "unit": "queries/s", "steps": p_steps, "warmup": p_warm, "ms_per_step": p_elapsed / p_steps * 1e3,
-                "pairwise_tflops": 2.0 * Q * B * d * (32 * 64 if maxsim else 1) * p_steps / p_elapsed / 1e12,
-                "identical_to_direct": bool(torch.equal(direct[0], p_last[0])) and bool(torch.equal(direct[1], p_last[1])),
-                "prescreen_searches": p_agg["prescreen"],
-                "roofline": {"bound": "mfma", "achieved": p_ach, "peak": MFMA_PEAK_TFLOPS["f16"], "unit": "TFLOP/s",
-                             "frac": p_ach / MFMA_PEAK_TFLOPS["f16"],
-                             "kernel": "nwk_maxsim_pre_ring_kernel" if maxsim else "nwk_tile_kernel_f16p<metric, PRE=1>",
-                             "traffic": recorded_traffic(args.workload + "_prescreen") if world == 1 else None,
-                             "launches": max(p_agg["tile_launches"] - p_steps, 1),
-                             "avg_launch_ms": p_agg["tile_ms"] / max(p_agg["tile_launches"] - p_steps, 1)},
-                "breakdown_ms_per_step": {"tile": p_agg["tile_ms"] / p_steps, "rescore": p_agg["rescore_ms"] / p_steps,
-                                          "compact": p_agg["compact_ms"] / p_steps, "prep": p_agg["prep_ms"] / p_steps,
-                                          "rescan_launches": p_agg["rescan_launches"], "overflowed_queries": p_agg["overflowed_queries"]},
-            }
-
+    b = Bench(args)
+    td, world, rank = b.td, b.world, b.rank
+    devices = b.devices()
+    out, ok = b.run(args.workload, args.steps, args.warmup, 0 if args.no_prescreen else min(args.steps, 5), args.metric, args.shard,
+                    args.verify, with_cpu=(world == 1 and not args.no_cpu_baseline))
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        qps = Q * args.steps / elapsed
-        achieved = (sum_flops / 1e12) / (sum_ms / 1e3) if sum_ms > 0 else 0.0       # per-GPU TFLOP/s of the tile kernel: both sums run over the ranks
-        out = {
-            "metric": "queries/sec + pairwise-dist TFLOP/s, 100k x 10M d=1024 k=100" if args.workload == "c3" else f"queries/sec ({args.workload})",
-            "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": dtype, "data": "synthetic (seeded counter-based embeddings in [-1,1), generated on device)",
-            "pairwise_tflops": 2.0 * Q * B * d * (32 * 64 if maxsim else 1) * args.steps / elapsed / 1e12,
-            "config": {"workload": desc, "queries": Q, "base_rows": B, "dim": d, "k": k, "metric": metric,
-                       "parallelism": (f"query rows sharded x{world}, base replicated + RCCL all-gather of the [Q/N,k] slices" if by_query else
-                                       f"base rows sharded x{world}" + (" + RCCL all-gather of [Q,k] partials + merge" if world > 1 else ""))},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": recorded_traffic(args.workload) if world == 1 else None,   # recorded for the 1-GPU launches only
-                         "traffic_note": "bytes per launch, rocprofv3 PMC passes recorded in profiles/ (not sampled live)",
-                         # one launch per search is the dense first chunk (cap/2 base rows, a different template instance in the
-                         # rocprofv3 stats, ~1 ms): the per-launch figures are over the filtered launches that carry the work
-                         "kernel": "nwk_tile_kernel", "launches": max(agg["tile_launches"] - args.steps, 1),
-                         "avg_launch_ms": agg["tile_ms"] / max(agg["tile_launches"] - args.steps, 1),
-                         "flops_per_launch": agg["tile_flops"] / max(agg["tile_launches"] - args.steps, 1)},
-            "breakdown_ms_per_step": {"tile": agg["tile_ms"] / args.steps, "compact": agg["compact_ms"] / args.steps,
-                                      "prep": agg["prep_ms"] / args.steps, "rescore": agg["rescore_ms"] / args.steps, "rescan_launches": agg["rescan_launches"],
-                                      "overflowed_queries": agg["overflowed_queries"]},
-        }
-        if pre is not None:
-            out["exact_prescreen"] = pre
-        if world == 1 and not args.no_cpu_baseline and not maxsim:
-            out["cpu_baseline"] = cpu_baseline(eng, base_raw, queries, k, metric, B)
-        print(json.dumps(out), flush=True)
-    if args.verify and rank == 0:
-        if maxsim:
-            eng.maxsim_set_docs(eng.generate(SEED_BASE, 0, B * 64, d, dtype).view(B, 64, d))
-            rs, ri = eng.maxsim_search(queries, k)
-            rd = -rs
-        else:
-            full = eng.generate(SEED_BASE, 0, B, d, dtype)      # same dtype as the shards: an fp16 base selects the fp16 path again
-            eng.set_base(full)
-            rd, ri = eng.search(queries, k, metric)
-        dist, idx = last
-        same = bool(torch.equal(ri, idx)) and bool(torch.equal(rd, dist))
-        print(json.dumps({"verify": "merged N-rank result == single-engine result", "ok": same}), flush=True)
-        if not same:
-            raise SystemExit(3)
+        line = {"metric": "queries/sec + pairwise-dist TFLOP/s, 100k x 10M d=1024 k=100" if args.workload == "c3" else f"queries/sec ({args.workload})",
+                "value": out.pop("value"), "unit": out.pop("unit"), "n_gpus": world, "steps": out.pop("steps"), "warmup": out.pop("warmup"),
+                "ms_per_step": out.pop("ms_per_step"), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": out.pop("dtype"), "data": "synthetic (seeded counter-based embeddings in [-1,1), generated on device)",
+                "ranks": td.get_world_size() if world > 1 else 1, "devices": devices}
+        line.update(out)
+    if world == 1 and args.workload == "c3" and not args.no_secondary and not args.opt and not args.metric:
+        sec = {}
+        for name, s_steps, s_pre in SECONDARY:
+            t0 = time.perf_counter()
+            try:
+                s_out, _ = b.run(name, s_steps, 1, 0 if args.no_prescreen else s_pre)
+                s_out["wall_s"] = time.perf_counter() - t0
+                sec[name] = s_out
+            except Exception as e:                                  # a secondary figure must never cost the headline line
+                sec[name] = {"error": f"{type(e).__name__}: {e}"}
+        line["secondary"] = sec
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+        if args.verify:
+            print(json.dumps({"verify": "merged N-rank result == single-engine result", "ok": ok}), flush=True)
+    rc = 3 if (args.verify and rank == 0 and not ok) else 0
     if world > 1:
         td.barrier()
         td.destroy_process_group()
+    if rc:
+        raise SystemExit(rc)
 
 
 if __name__ == "__main__":

@@ -99,6 +99,7 @@ int nwknn_set_stream(nwknn_handle h, void* hip_stream);
  * 3 = streaming form; 1 = burst form, one burst of LDS-DMA per slab),
  * "tile_occ" (workgroups per CU of the fp32 tile kernel, 3 default | 2), "chunk_growth" (0 = auto), "super_q_shift" / "super_walk_q"
  * (shape and walk order of an XCD's super-tile), "upload_threads" (host threads of the column upload pipeline, default 8),
+ * "upload_slab_mib" (slab size of that pipeline, default 128),
  * "pre_eps_pct" (>= 100: percent of the proven pre-screen error bound to apply; larger = more pairs rescored, same result),
  * MaxSim pre-screen tile kernel, d <= 128: "ms_strip" (document tiles a workgroup of the ring kernel walks: 0 = auto, 1 = the any-d
  * kernel), "ms_rescore_valu" (1: rescoring on the vector pipes).

@@ -124,7 +124,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_rescore_valu = 0;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -313,6 +313,9 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
     } else if (!strcmp(name, "upload_threads")) {
         if (value < 1 || value > 64) return fail(NWKNN_EINVAL, "upload_threads must be 1..64");
         h->opt_upload_threads = value;      // host threads that gather column slabs into the pinned upload buffers
+    } else if (!strcmp(name, "upload_slab_mib")) {
+        if (value < 1 || value > 1024) return fail(NWKNN_EINVAL, "upload_slab_mib must be 1..1024");
+        h->opt_upload_slab_mib = value;     // size of one slab of the column upload pipeline (two pinned + two device slabs of this size)
     } else if (!strcmp(name, "tile_occ")) {
         if (value != 2 && value != 3) return fail(NWKNN_EINVAL, "tile_occ must be 2 or 3");
         h->opt_tile_occ = value;            // workgroups per CU of the fp32 tile kernel's 256-row shape (3: default)
@@ -415,7 +418,7 @@ struct ColumnSource {
 //   stages through the driver's own bounce buffers at ~11 GB/s)  ->  one H2D copy of the whole slab on a copy stream
 //   ->  the strided layout kernel on the compute stream.  Two pinned slabs and two device slabs: slab s+1 is gathered and copied
 //   while slab s is laid out.  C2's base (1M x 768 float32 columns = 3.07 GB): 0.28 s -> see DESIGN.md section 6.
-#define NWK_UPLOAD_SLAB_BYTES (128ull << 20)
+// (slab size: option "upload_slab_mib", 128 by default)
 
 static int ensure_upload_pipeline(nwknn_ctx* h, size_t slab_bytes)
 {
@@ -450,7 +453,7 @@ static int stage_and_prep_columns(nwknn_ctx* h, const ColumnSource& src, int in_
     }
     if (chunk_start[src.n_chunks] != rows) return fail(NWKNN_EINVAL, "column chunks hold %lld rows, expected %lld", chunk_start[src.n_chunks], rows);
     // slab = as many rows (a multiple of 256) as fit NWK_UPLOAD_SLAB_BYTES with all d columns
-    const long long slab_rows = std::max<long long>(256, (long long)(NWK_UPLOAD_SLAB_BYTES / ((size_t)d * in_es)) / 256 * 256);
+    const long long slab_rows = std::max<long long>(256, (long long)(((size_t)h->opt_upload_slab_mib << 20) / ((size_t)d * in_es)) / 256 * 256);
     const long long stage_rows = std::min(slab_rows, round_up(std::max<long long>(rows, 1), 256));
     const size_t slab_bytes = (size_t)stage_rows * d * in_es;
     RCCHK(raw.ensure(2 * slab_bytes));
@@ -503,7 +506,9 @@ static int stage_and_prep_columns(nwknn_ctx* h, const ColumnSource& src, int in_
                 }
             }
             if (s >= 2) HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_prepped[b], 0));   // the layout kernel of slab s-2 has read this device slab
-            HIPCHK(hipMemcpyAsync(dev_slab, h->pin[b], slab_bytes, hipMemcpyHostToDevice, h->copy_stream));
+            // column j sits at j * stage_rows: on a short (last) slab the copy ends with the last column's real rows
+            const size_t copy_bytes = ((size_t)(d - 1) * stage_rows + (size_t)real_here) * in_es;
+            HIPCHK(hipMemcpyAsync(dev_slab, h->pin[b], copy_bytes, hipMemcpyHostToDevice, h->copy_stream));
             HIPCHK(hipEventRecord(h->ev_h2d[b], h->copy_stream));
             HIPCHK(hipStreamWaitEvent(h->stream, h->ev_h2d[b], 0));
         }

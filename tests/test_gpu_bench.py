@@ -33,10 +33,40 @@ def test_bench_line_has_the_contract_fields():
     rf = b["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and 0.0 < rf["frac"] < 1.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["launches"] > 0 and rf["avg_launch_ms"] > 0.0
+    assert rf["kernel"] == "nwk_tile_kernel<0,false,256,16,0,3>"          # the kernel that ran, as rocprofv3 spells it
     cb = b["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "queries/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    sk = cb["sklearn"]
+    assert sk["unit"] == "queries/s" and sk["value"] > 0 and sk["cores"] >= 1 and "NearestNeighbors" in sk["sample"]
     pre = b["exact_prescreen"]
     assert pre["identical_to_direct"] is True and pre["value"] > 0 and pre["roofline"]["peak"] == 2500.0
+    assert pre["roofline"]["kernel"] == "nwk_tile_kernel_f16p<0,1>"
+    assert b["ranks"] == 1 and len(b["devices"]) == 1 and b["devices"][0]["rank"] == 0 and "gfx950" in b["devices"][0]["gcn_arch"]
+    assert "collective" not in b and "secondary" not in b                  # N = 1, not the default workload
+
+
+@pytest.mark.gpu
+def test_default_workload_carries_the_other_baseline_configs():
+    """The default (C3) line at N = 1 ends with a bounded `secondary` block: C2, one of eight C3 shards and the C4 per-GPU slice, each
+    with its own value / ms_per_step / roofline (kernel, achieved, peak, frac).  One timed step here; the driver runs 20."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout[-2000:]
+    b = lines[0]
+    assert b["metric"].startswith("queries/sec + pairwise-dist TFLOP/s, 100k x 10M") and b["config"]["base_rows"] == 10_000_000
+    assert b["exact_prescreen"]["identical_to_direct"] is True
+    sec = b["secondary"]
+    assert sorted(sec) == ["c2", "c3shard", "c4gpu"]
+    for name, peak, kernel in (("c2", 157.3, "nwk_tile_kernel<"), ("c3shard", 157.3, "nwk_tile_kernel<"), ("c4gpu", 2500.0, "nwk_tile_kernel_f16")):
+        s = sec[name]
+        assert "error" not in s, s
+        assert s["value"] > 0 and s["ms_per_step"] > 0 and s["unit"] == "queries/s" and s["steps"] >= 1
+        rf = s["roofline"]
+        assert rf["peak"] == peak and rf["kernel"].startswith(kernel) and 0.0 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / peak) < 1e-9
+    assert sec["c2"]["exact_prescreen"]["identical_to_direct"] is True and sec["c3shard"]["exact_prescreen"]["identical_to_direct"] is True
+    assert sec["c4gpu"]["dtype"] == "f16" and sec["c2"]["config"]["base_rows"] == 1_000_000
 
 
 @pytest.mark.gpu
@@ -56,3 +86,39 @@ def test_bench_two_ranks_over_gloo_match_the_single_engine(shard):
     assert len(bench) == 1 and bench[0]["n_gpus"] == 2 and bench[0]["scaling"] == "strong" and "cpu_baseline" not in bench[0]
     assert ("sharded x2" in bench[0]["config"]["parallelism"])
     assert len(verify) == 1 and verify[0]["ok"] is True
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks_when_typed_as_the_driver_types_it():
+    """`python bench.py --gpus 2 ...` with NO torchrun around it: the script starts its two ranks itself (a child process, before
+    anything touches the GPU) and the line proves two ranks ran: `ranks`, one `devices` entry per rank, the collective's backend and
+    timings.  gloo here (two ranks share the box's one GPU); nccl == RCCL is the default."""
+    env = dict(os.environ, NWKNN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(var, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--workload", "dev", "--steps", "1", "--warmup", "1", "--verify"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    lines = _json_lines(r.stdout)
+    bench = [x for x in lines if "metric" in x]
+    verify = [x for x in lines if "verify" in x]
+    assert len(bench) == 1 and len(verify) == 1 and verify[0]["ok"] is True
+    b = bench[0]
+    assert b["n_gpus"] == 2 and b["ranks"] == 2 and [d["rank"] for d in b["devices"]] == [0, 1]
+    assert all("gfx950" in d["gcn_arch"] for d in b["devices"])
+    c = b["collective"]
+    assert c["backend"] == "gloo" and c["allgather_ms"] > 0.0 and c["merge_ms"] > 0.0 and c["allgather_bytes_per_rank"] == 2 * 4096 * 100 * 12
+    assert "torch.distributed.run" in r.stderr                     # the parent said what it started
+
+
+@pytest.mark.gpu
+def test_bench_over_rccl_refuses_more_ranks_than_gpus():
+    """The production backend is nccl == RCCL, one rank per GPU: asking for more ranks than the node has GPUs fails loudly in every
+    rank (no silent device sharing), and the self-launching parent hands the failure through as its exit code."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "NWKNN_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(n), "--workload", "dev", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert f"needs {n} GPUs" in (r.stdout + r.stderr)

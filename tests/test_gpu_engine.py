@@ -286,6 +286,44 @@ def test_chunked_columns_equal_plain_columns(engine, oracle):
         engine.set_base_columns([[base[:10, 0], base[10:30, 0]], [base[:15, 1], base[15:30, 1]]])     # different chunking per column
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_upload_pipeline_reuses_its_buffers_over_many_slabs(oracle, dtype):
+    """The column upload pipeline double-buffers: from the third slab on, a pinned buffer is refilled only after its H2D copy has left
+    it, and a device slab is overwritten only after the layout kernel has read it.  With 1 MiB slabs (option upload_slab_mib) a
+    21 001-row x 96-column base is 9 (float32) or 17 (float64) slabs with a ragged last slab -- copied only up to its last real row --
+    and chunk borders inside slabs; every real `nw` base tile goes through this path (C2: 24 slabs of 128 MiB).  Bits must equal the
+    row-major upload, for the base and for the queries (search_columns runs the same pipeline)."""
+    from neighborhoodwatch_amd import KnnEngine
+    B, Q, d, k = 21_001, 2_900, 96, 17
+    base, queries = oracle.gen(0xE1, 0, B, d), oracle.gen(0xE2, 0, Q, d)
+    # 1 MiB / (96 columns x 4 or 8 B) = 2 730 or 1 365 rows -> slabs of 2 560 / 1 280 rows: 9 or 17 base slabs, 2 or 3 query slabs
+    cuts = [0, 1, 2_560, 2_561, 7_000, 7_003, 12_800, 20_999, B]
+    bcols = [[base[a:b, j].astype(dtype) for a, b in zip(cuts[:-1], cuts[1:])] for j in range(d)]
+    qcols = [[queries[:1_279, j].astype(dtype), queries[1_279:, j].astype(dtype)] for j in range(d)]
+    with KnnEngine(0) as eng:
+        eng.set_option("upload_slab_mib", 1)
+        eng.set_option("upload_threads", 3)
+        eng.set_base_columns(bcols)
+        dist, idx = eng.search_columns(qcols, k)
+        eng.set_base(base)                                             # row-major reference upload on the same engine
+        d2, i2 = eng.search(queries, k)
+    assert np.array_equal(idx, i2) and _same_bits(dist, d2)
+    rd, ri = oracle.knn_canonical(base, queries, k)
+    assert np.array_equal(idx, ri) and _same_bits(dist, rd)
+
+
+def test_plain_python_lists_are_columns_not_chunk_lists(engine, oracle):
+    """A column passed as a plain Python list of numbers is ONE chunk (np.asarray), as before chunk lists existed; a column whose
+    elements are neither scalars nor 1-D chunks is refused with a ValueError, not an IndexError."""
+    base, queries = oracle.gen(0xE5, 0, 300, 6), oracle.gen(0xE6, 0, 9, 6)
+    engine.set_base_columns([base[:, j].tolist() for j in range(6)])
+    d, i = engine.search_columns([tuple(queries[:, j].tolist()) for j in range(6)], 5)
+    rd, ri = oracle.knn_canonical(base, queries, 5)
+    assert np.array_equal(i, ri) and _same_bits(d, rd)
+    with pytest.raises(ValueError, match="1-D"):
+        engine.set_base_columns([base[:, :2] for _ in range(6)])
+
+
 def test_merge_folds_more_than_4096_entries(engine, oracle):
     """8 shards x k=1000 (BASELINE config 5 on 8 GPUs) exceeds one LDS sort: folded in groups, same result; torch and numpy."""
     import torch
