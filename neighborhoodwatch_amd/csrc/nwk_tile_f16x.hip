@@ -1,0 +1,351 @@
+// nwk_tile_f16x.hip -- fp16 distance tile + filter, "ping-pong" form (option f16_mfma = 4).  (gfx950 only; shared pieces: nwk_device.h,
+// nwk_f16_common.h)
+//
+// Same workgroup tile as the burst and the streaming form (256 queries x 256 base rows, 8 waves 2 x 4, a wave owns 128 x 64 = 8 x 4
+// accumulators of v_mfma_f32_16x16x32_f16), same LDS image (two 64 KiB stages of 128-B rows, 16-B chunk c of row r in slot
+// c ^ ((r >> 1) & 7)), same filter epilogue, same accumulation order per output element (ascending k) -- so the same bits.  What changes
+// is WHO does WHAT WHEN.  In the other two forms all eight waves run one program: every phase each of them issues LDS-DMA, reads
+// fragments and runs MFMAs, and the two waves that share a SIMD reach their DMA issue, their LDS reads, their MFMAs and the barrier
+// together -- the matrix pipe idles while both are in their memory instructions and is fought over when both have operands (PMC, round 2:
+// MFMA busy 55 % of SIMD cycles; a bare MFMA loop of this shape runs 1.6-1.7 PF on random data where the kernel ran 1.16-1.2).
+//
+// Here the two waves of a SIMD alternate roles, slab by slab (a slab = 64 halves of K = two k-steps = 64 MFMAs per wave):
+//
+//     group 0 = waves 0-3 (query rows   0-127 of the tile, one wave per SIMD)      group 1 = waves 4-7 (query rows 128-255)
+//     phase 2s   : group 0 LOADS slab s                                             group 1 COMPUTES slab s-1
+//     phase 2s+1 : group 0 COMPUTES slab s                                          group 1 LOADS slab s
+//
+//   LOAD    = issue this group's share of the LDS-DMA stream, (at a tile boundary: the previous tile's epilogue), then bring ALL of the
+//             slab's fragments into registers: 16 A + 8 B ds_read_b128 (96 VGPRs), s_waitcnt, s_barrier;
+//   COMPUTE = 64 MFMAs back to back on registers -- no LDS access, no vector memory, no wait in between -- then s_barrier.
+// So at any time exactly one wave per SIMD owns the matrix pipe and has everything it needs in registers, while its partner's DMA issue,
+// LDS round trips and epilogue VALU hide behind it (MI355X_MICROARCH.md, "Two waves per SIMD").  Two barriers per slab (the streaming
+// form: four).
+//
+// LDS-DMA shares (one instruction = 8 rows x 128 B = 1 KiB; a stage = A rows 0-255 | B rows 0-255 of one slab).  A piece of LDS may be
+// refilled once its last reader has passed a barrier:
+//     group 1, in phase 2s+1 (its LOAD of slab s):  A rows   0-127 of slab s+2 -> stage s&1       (read by group 0 in phase 2s;  4 per wave)
+//     group 0, in phase 2s   (its LOAD of slab s):  A rows 128-255, B and the tile's column norms of slab s+1 -> stage (s+1)&1
+//                                                    (read by group 1 in phase 2s-1; 4 + 8 + 1 per wave)
+// i.e. a piece has one (B, lower A) to one and a half (upper A) slab periods to arrive.  Waits: a wave can only wait for its own
+// DMA, so each group waits for what it issued and the barrier that follows publishes it to the other:
+//     group 0: s_waitcnt vmcnt(0) at the end of its COMPUTE phase (its share of slab s+1, issued a phase earlier);
+//     group 1: s_waitcnt vmcnt(4) at the end of its LOAD phase -- all but the four instructions just issued, i.e. upper A of slab s+1
+//              (past the end of the strip the four are still issued, source clamped, into a piece nobody reads again: the count
+//              stays a constant).
+// Epilogue inputs as in the streaming form: query norms | thresholds | row terms staged once per strip, column norms by DMA.
+// Survivors are staged in the LDS list and flushed once at the end of the strip (an entry that finds the list full goes out
+// directly); the first slab of a tile takes a zero C operand instead of cleared accumulators.
+#include <type_traits>
+
+#include "nwk_f16_common.h"
+
+#define X_BN_BUFS 4                   // column-norm buffers (tile & 3)
+
+template <int METRIC, int PRE>
+__global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTileParams p)
+{
+    constexpr int SC = H_SC;
+    constexpr int OFF_EPI = 2 * H_STAGE, OFF_BN = OFF_EPI + H_TM * 16, OFF_KEY = OFF_BN + X_BN_BUFS * H_TN * 4, OFF_ROW = OFF_KEY + SC * 8,
+                  OFF_CNT = OFF_ROW + SC * 4;
+    __shared__ __attribute__((aligned(16))) char smem[OFF_CNT + 16];
+    char* const epi = smem + OFF_EPI;
+    LDS_AS u64* const s_key = (LDS_AS u64*)(smem + OFF_KEY);
+    LDS_AS u32* const s_row = (LDS_AS u32*)(smem + OFF_ROW);
+    LDS_AS u32* const s_cnt = (LDS_AS u32*)(smem + OFF_CNT);
+
+    const TileCoord tc = tile_from_block(p);
+    if (!tc.ok) return;
+#ifdef NWKNN_DEV
+    const int diag = p.diag;              // timing ablations (wrong results): 1 no fragment reads, 2 no LDS-DMA inside the loop, 4 no MFMAs, 8 no epilogue
+#else
+    constexpr int diag = 0;
+#endif
+
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, l = tid & 63;
+    const int wr = w >> 2, wc = w & 3;
+    const int g = l >> 4, c16 = l & 15;
+    const long long q0 = (long long)tc.qt * H_TM;
+    const int T = p.tiles_per_wg > 1 ? p.tiles_per_wg : 1;
+    const int bt_first = p.bt0 + (tc.bt - p.bt0) * T;             // tc.bt numbers the strip
+    int n_here = p.bt0 + p.n_btiles_real - bt_first;
+    if (n_here > T) n_here = T;
+    const long long b_first = (long long)bt_first * H_TN;
+    const int dp = p.dp;
+    const int nk = dp / H_BK;
+    const int S = n_here * nk;                                    // slabs of the strip
+    const _Float16* qp = (const _Float16*)p.qp;
+    const _Float16* bp = (const _Float16*)p.bp;
+
+    // ---- LDS-DMA ----------------------------------------------------------------------------------------------------------------------
+    // piece pi of an operand = rows 8 pi .. 8 pi + 7.  Wave u (0..3) of a group brings pieces u + 4 j: they share the parity of pi, hence
+    // the swizzle term ((row >> 1) & 7) = (4 (pi & 1) + l / 16) & 7 of row 8 pi + l / 8: one per-lane offset for all of them.
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int grp = wu >> 2, u = wu & 3;
+    const unsigned voff = (unsigned)((l >> 3) * dp * 2 + (((l & 7) ^ ((4 * (u & 1) + (l >> 4)) & 7)) << 4));
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(qp + q0 * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(bp + b_first * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bn + b_first), 0, 0x7FFFFFFF, 0x00020000);
+    auto issue_A = [&](int half, int stage, int k) {              // half 0: rows 0-127 (group 1 issues), 1: rows 128-255 (group 0)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pi = 16 * half + u + 4 * j;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(smem + stage * H_STAGE + pi * 1024), 16, voff, k * 128 + pi * 8 * dp * 2, 0, 0);
+        }
+    };
+    auto issue_B = [&](int stage, int t, int k) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int pi = u + 4 * j;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(smem + stage * H_STAGE + 32768 + pi * 1024), 16, voff,
+                                                     k * 128 + (t * H_TN + pi * 8) * dp * 2, 0, 0);
+        }
+    };
+    auto issue_N = [&](int t) {                                   // wave u brings the 64 column norms of columns 64 u .. of tile t
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsN, (LDS_AS void*)(smem + OFF_BN + (t & (X_BN_BUFS - 1)) * H_TN * 4 + u * 256), 4, (unsigned)(l * 4),
+                                                 (t * H_TN + u * 64) * 4, 0, 0);
+    };
+
+    // ---- fragments --------------------------------------------------------------------------------------------------------------------
+    const int swz = (c16 >> 1) & 7;
+    const int offA0 = (wr * 128 + c16) * 128 + ((g ^ swz) << 4);
+    const int offB0 = 32768 + (wc * 64 + c16) * 128 + ((g ^ swz) << 4);
+    f32x4 acc[8][4];
+    f16x8 fa[2][8], fb[2][4];                                     // [k-step][row block] / [k-step][column block] of ONE slab
+    auto read_frags = [&](int stage) {
+        if (diag & 1) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) asm volatile("" : "+v"(fb[ks][n]));
+#pragma unroll
+                for (int m = 0; m < 8; ++m) asm volatile("" : "+v"(fa[ks][m]));
+            }
+            return;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) fb[ks][n] = *(const f16x8*)(smem + stage * H_STAGE + (offB0 ^ (ks << 6)) + n * 2048);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) fa[ks][m] = *(const f16x8*)(smem + stage * H_STAGE + (offA0 ^ (ks << 6)) + m * 2048);
+        }
+    };
+    auto compute = [&](auto first_tag) {                          // 64 MFMAs on registers; FIRST: the tile's first slab starts from a zero C
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (diag & 4) {
+            if (FIRST) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[m][n] = zero;
+            }
+            return;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ks][m], fb[ks][n], (FIRST && ks == 0) ? zero : acc[m][n], 0, 0, 0);
+    };
+
+    // ---- epilogue of tile t (this wave's 128 x 64 part) ------------------------------------------------------------------------
+    auto epilogue = [&](int t) {
+        if (diag & 8) return;
+        const long long col0 = b_first + (long long)t * H_TN + wc * 64 + c16;
+        const float* s_bn = (const float*)(smem + OFF_BN + (t & (X_BN_BUFS - 1)) * H_TN * 4);
+        float bnv[4], cpre[4];
+        u32 colv[4];
+        bool colok[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const long long col = col0 + n * 16;
+            bnv[n] = s_bn[wc * 64 + n * 16 + c16];
+            colv[n] = (u32)col;
+            colok[n] = col < p.nb_valid;
+            const float c = PRE ? prescreen_col<METRIC>(bnv[n], p) : prefilter_col<METRIC>(bnv[n]);
+            cpre[n] = colok[n] ? c : __builtin_inff();
+        }
+        int g_here = g, c_here = c16;                               // opaque per tile (see nwk_tile_kernel_f16s)
+        asm volatile("" : "+v"(g_here));
+        asm volatile("" : "+v"(c_here));
+        u32 blocks = 0xFFu;
+        if (PRE) {                                                  // smallest row term of each 16-row block: recomputed per tile (8 LDS reads)
+            const float* s_pre = (const float*)(epi + H_TM * 12);   // rather than kept in 8 registers across the K loops
+            float pmin[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const f32x4 r4 = *(const f32x4*)(s_pre + wr * 128 + m * 16 + 4 * g_here);
+                pmin[m] = fminf(fminf(r4[0], r4[1]), fminf(r4[2], r4[3]));
+            }
+            blocks = prescreen_block_mask(acc, pmin, fminf(fminf(cpre[0], cpre[1]), fminf(cpre[2], cpre[3])));
+        }
+        if (blocks)
+            tile_epilogue16<METRIC, false, PRE, SC>(p, acc, (const float*)epi, (const u64*)(epi + H_TM * 4), (const float*)(epi + H_TM * 12), bnv,
+                                                    colv, colok, cpre, q0, wr * 128, g_here, c_here, s_cnt, s_key, s_row, blocks);
+    };
+
+#define X_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // developer builds: per-wave cycle sums of the pieces of a phase (tools/f16x_stamps.py).  Slots: 0 DMA issue, 1 epilogue, 2 fragment
+    // reads until they have landed, 3 wait at the barrier that ends the LOAD phase, 4 MFMA issue, 5 wait for this wave's DMA, 6 wait at
+    // the barrier that ends the COMPUTE phase.  The product compiles none of it.
+#ifdef NWKNN_DEV
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool stamp_on = NWK_DBG(p) != nullptr;
+    unsigned long long tlast = stamp_on ? __builtin_amdgcn_s_memtime() : 0;
+#define X_STAMP(I)                                                     \
+    do {                                                               \
+        if (stamp_on) {                                                \
+            X_FENCE();                                                 \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+            tsum[I] += now_ - tlast;                                   \
+            tlast = now_;                                              \
+            X_FENCE();                                                 \
+        }                                                              \
+    } while (0)
+#else
+#define X_STAMP(I) do { } while (0)
+#endif
+#define X_BARRIER(WAIT, SLOT_WAIT, SLOT_BAR)               \
+    do {                                                   \
+        X_FENCE();                                         \
+        asm volatile(WAIT ::: "memory");                   \
+        X_STAMP(SLOT_WAIT);                                \
+        __builtin_amdgcn_s_barrier();                      \
+        X_STAMP(SLOT_BAR);                                 \
+        X_FENCE();                                         \
+    } while (0)
+
+    if (grp == 0) {
+        // =========================================================== group 0 ===========================================================
+        float my_qn = p.qn[q0 + tid];                             // tid < 256 here: one query row per thread
+        u64 my_tau = p.tau[q0 + tid];
+        X_FENCE();
+        issue_A(1, 0, 0); issue_B(0, 0, 0); issue_N(0);           // this group's share of slab 0 -> stage 0
+        X_FENCE();
+        stage_query_side<METRIC, false, PRE>(epi, H_TM, tid, my_qn, my_tau, p, q0);
+        if (tid == 0) *s_cnt = 0;
+        X_BARRIER("s_waitcnt vmcnt(0) lgkmcnt(0)", 7, 7);         // [pre] slab 0 complete (group 1 waited for its part), epilogue inputs staged
+        int sigma = 0;
+        for (int t = 0; t < n_here; ++t) {
+            // ---- first slab of tile t: LOAD (+ the previous tile's epilogue), COMPUTE from a zero C ------------------------------------
+            {
+                const int st = sigma & 1;
+                if (sigma + 1 < S && !(diag & 2)) {                 // wave-uniform: slab sigma + 1 is (t, 1) or, when nk == 1, (t + 1, 0)
+                    const int t2 = nk > 1 ? t : t + 1, k2 = nk > 1 ? 1 : 0;
+                    issue_A(1, st ^ 1, k2); issue_B(st ^ 1, t2, k2); issue_N(t2);
+                }
+                X_STAMP(0);
+                X_FENCE();
+                if (t > 0) epilogue(t - 1);
+                X_STAMP(1);
+                X_FENCE();
+                read_frags(st);
+                X_BARRIER("s_waitcnt lgkmcnt(0)", 2, 3);
+                compute(std::true_type{});
+                X_STAMP(4);
+                X_BARRIER("s_waitcnt vmcnt(0)", 5, 6);
+                ++sigma;
+            }
+            for (int kt = 1; kt < nk; ++kt) {
+                const int st = sigma & 1;
+                if (sigma + 1 < S && !(diag & 2)) {
+                    const bool wrap = kt + 1 == nk;
+                    const int t2 = wrap ? t + 1 : t, k2 = wrap ? 0 : kt + 1;
+                    issue_A(1, st ^ 1, k2); issue_B(st ^ 1, t2, k2); issue_N(t2);
+                }
+                X_STAMP(0);
+                X_FENCE();
+                read_frags(st);
+                X_BARRIER("s_waitcnt lgkmcnt(0)", 2, 3);
+                compute(std::false_type{});
+                X_STAMP(4);
+                X_BARRIER("s_waitcnt vmcnt(0)", 5, 6);
+                ++sigma;
+            }
+        }
+        epilogue(n_here - 1);                                       // while group 1 computes the strip's last slab
+    } else {
+        // =========================================================== group 1 ===========================================================
+        X_FENCE();
+        issue_A(0, 0, 0);                                           // upper A of slab 0 -> stage 0
+        issue_A(0, 1, S > 1 ? (nk > 1 ? 1 : 0) : 0);                // upper A of slab 1 -> stage 1 (a one-slab strip: a copy nobody reads)
+        X_BARRIER("s_waitcnt vmcnt(4)", 7, 7);                      // [pre] slab 0's part has landed
+        X_BARRIER("s_nop 0", 7, 7);                                 // end of phase 0 (group 0 loaded slab 0; nothing to compute yet)
+        int sigma = 0;
+        int k2 = nk > 2 ? 2 : 0;                                    // k-slab index of slab sigma + 2 (2 mod nk), kept incrementally
+        auto next_k2 = [&]() { k2 = (k2 + 1 == nk) ? 0 : k2 + 1; };
+        for (int t = 0; t < n_here; ++t) {
+            {
+                const int st = sigma & 1;
+                if (!(diag & 2)) issue_A(0, st, sigma + 2 < S ? k2 : nk - 1);        // past the end of the strip: the last slab again (never read)
+                next_k2();
+                X_STAMP(0);
+                X_FENCE();
+                if (t > 0) epilogue(t - 1);
+                X_STAMP(1);
+                X_FENCE();
+                read_frags(st);
+                if (diag & 2) X_BARRIER("s_waitcnt vmcnt(0) lgkmcnt(0)", 2, 3); else X_BARRIER("s_waitcnt vmcnt(4) lgkmcnt(0)", 2, 3);
+                compute(std::true_type{});
+                X_STAMP(4);
+                ++sigma;
+                if (sigma < S) X_BARRIER("s_nop 0", 5, 6);
+            }
+            for (int kt = 1; kt < nk; ++kt) {
+                const int st = sigma & 1;
+                if (!(diag & 2)) issue_A(0, st, sigma + 2 < S ? k2 : nk - 1);
+                next_k2();
+                X_STAMP(0);
+                X_FENCE();
+                read_frags(st);
+                if (diag & 2) X_BARRIER("s_waitcnt vmcnt(0) lgkmcnt(0)", 2, 3); else X_BARRIER("s_waitcnt vmcnt(4) lgkmcnt(0)", 2, 3);
+                compute(std::false_type{});
+                X_STAMP(4);
+                ++sigma;
+                if (sigma < S) X_BARRIER("s_nop 0", 5, 6);
+            }
+        }
+        epilogue(n_here - 1);
+    }
+#ifdef NWKNN_DEV
+    if (stamp_on && l == 0) {
+        unsigned long long* o = NWK_DBG(p) + ((size_t)blockIdx.x * 8 + w) * 8;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) o[i] = tsum[i];
+        o[7] = (unsigned long long)S;
+    }
+#endif
+#undef X_BARRIER
+#undef X_STAMP
+#undef X_FENCE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // no LDS-DMA may still be in flight when the workgroup leaves the CU
+    __syncthreads();
+    flush_survivors(p, s_cnt, s_key, s_row, q0, tid, 512);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launcher (host side, called from nwk_launch_tile_f16 in nwk_tile_f16.hip)
+// ------------------------------------------------------------------------------------------------
+extern "C++" {
+
+hipError_t nwk_launch_tile_f16x(hipStream_t st, const NwkTileParams& p, int metric, int pre, unsigned grid)
+{
+#define NWK_X(M)                                                                                                  \
+    do {                                                                                                           \
+        if (pre) hipLaunchKernelGGL((nwk_tile_kernel_f16x<M, 1>), dim3(grid), dim3(512), 0, st, p);                \
+        else hipLaunchKernelGGL((nwk_tile_kernel_f16x<M, 0>), dim3(grid), dim3(512), 0, st, p);                    \
+    } while (0)
+    if (metric == NWKNN_METRIC_SQEUCLIDEAN) NWK_X(NWKNN_METRIC_SQEUCLIDEAN);
+    else if (metric == NWKNN_METRIC_ONE_MINUS_DOT) NWK_X(NWKNN_METRIC_ONE_MINUS_DOT);
+    else if (metric == NWKNN_METRIC_COSINE) NWK_X(NWKNN_METRIC_COSINE);
+    else return hipErrorInvalidValue;
+#undef NWK_X
+    return hipGetLastError();
+}
+
+}  // extern "C++"

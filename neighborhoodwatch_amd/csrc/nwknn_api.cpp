@@ -327,7 +327,7 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
         if (value < 0 || value > 100000) return fail(NWKNN_EINVAL, "pre_eps_pct must be 100..100000 (percent of the proven bound)");
         h->opt_pre_eps_pct = value;
     } else if (!strcmp(name, "f16_mfma")) {
-        if (value != -1 && value != 1 && value != 3) return fail(NWKNN_EINVAL, "f16_mfma must be -1 (auto), 1 (burst form) or 3 (streaming form)");
+        if (value != -1 && value != 1 && value != 3 && value != 4) return fail(NWKNN_EINVAL, "f16_mfma must be -1 (auto), 1 (burst form), 3 (streaming form) or 4 (ping-pong form)");
         h->opt_f16_shape = value;
 #if NWK_DEV_BUILD
     } else if (!strcmp(name, "prescreen_prune")) {
@@ -699,6 +699,7 @@ static NwkTileParams tile_params(nwknn_ctx* h, const SearchPlan& pl, long long n
     p.f16_shape = (int)h->opt_f16_shape;              // -1 (auto) is resolved in run_chunk, once the row length the kernel sees is known
     p.tiles_per_wg = (int)h->opt_f16_strip;
     p.dbg = h->opt_dbg_ptr ? (unsigned long long*)(uintptr_t)h->opt_dbg_ptr : nullptr;
+    p.diag = NWK_DEV_BUILD ? (int)h->opt_diag : 0;
     return p;
 }
 
@@ -762,7 +763,7 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         if (!(prescreen || h->f16)) {
             const bool occ3 = pl.tile_rows == 256 && !NWK_DEV_BUILD_DIAG(h) && h->opt_tile_occ >= 3;
             snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel<%d,false,%d,%d,0,%d>", metric, pl.tile_rows, pl.tile_rows == 256 ? 16 : 32, occ3 ? 3 : 2);
-        } else if (f16_shape == 3) snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel_f16p<%d,%d>", metric, prescreen ? 1 : 0);
+        } else if (f16_shape == 3 || f16_shape == 4) snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel_f16%c<%d,%d>", f16_shape == 3 ? 'p' : 'x', metric, prescreen ? 1 : 0);
         else snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel_f16s<%d,false,%d>", metric, prescreen ? 1 : 0);
     }
     if (prescreen) {                                       // listed pairs -> canonical fp32 keys, in place

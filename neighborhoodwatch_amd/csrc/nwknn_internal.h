@@ -41,12 +41,13 @@ struct NwkTileParams {
     float pre_aq, pre_ab;          // absolute terms: pre_aq * sqrt(|b|^2) and pre_ab * sqrt(|q|^2)
     float pre_cst;
     float pre_inv_scale;           // 1 / pre_scale
-    int f16_shape;                 // fp16 tile kernel build (all on v_mfma_f32_16x16x32_f16): 1 = burst form, 3 = streaming form
+    int f16_shape;                 // fp16 tile kernel build (all on v_mfma_f32_16x16x32_f16): 1 = burst form, 3 = streaming form, 4 = ping-pong form
     const float* ms_rq;            // MaxSim pre-screen: per-query and per-doc parts of the score bound
     const float* ms_cd;
     int walk_q_fastest;            // 1: inside a super-tile the QUERY tile index runs fastest (consecutive blocks share a base tile), 0: the base tile index
     int tiles_per_wg;              // fp16 kernels: consecutive base tiles a workgroup walks (strip); the launcher turns n_btiles into strips
     int n_btiles_real;             // filled in by the launcher: base tiles of this launch
+    int diag;                      // -DNWKNN_DEV builds only: timing ablations of nwk_tile_kernel_f16x (1 no fragment reads, 2 no LDS-DMA in the loop, 4 no MFMAs, 8 no epilogue); 0 in the product
 };
 
 struct NwkRescoreParams {
@@ -101,6 +102,7 @@ hipError_t nwk_launch_gen_f16(hipStream_t st, uint64_t seed, long long row0, lon
 hipError_t nwk_launch_prep_f16(hipStream_t st, const void* raw, int raw_is_f16, long long rows, int d, long long rows_pad, int dp, void* prepared, float* norms);
 hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool dense, int pre);   // every fp16 tile launch: raw sums (pre = 0) or pre-screen (pre = 1)
 hipError_t nwk_launch_tile_f16p(hipStream_t st, const NwkTileParams& p, int metric, int pre, unsigned grid);   // streaming form (f16_mfma = 3)
+hipError_t nwk_launch_tile_f16x(hipStream_t st, const NwkTileParams& p, int metric, int pre, unsigned grid);   // ping-pong form (f16_mfma = 4)
 hipError_t nwk_launch_prep_strided(hipStream_t st, const void* raw, int in_dtype, long long rs, long long ks, long long rows, int d,
                                    long long rows_pad, int dp, int out_f16, void* prepared, float* norms);
 hipError_t nwk_launch_prep(hipStream_t st, const float* raw, long long rows, int d, long long rows_pad, int dp, float* prepared, float* norms);

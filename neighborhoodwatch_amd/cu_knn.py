@@ -38,6 +38,7 @@ import pyarrow.parquet as pq
 from .engine import KnnEngine, default_engine, mem_info, resolve_metric
 from .nw_utils import (get_full_filename, get_partial_distances_filename, get_partial_indices_filename,
                        output_dimension_validity_check)
+from .parquet_stream import ParquetRows, Prefetch
 
 PARQUET_ROW_GROUP = 100000          # cu_knn.py:284-285
 
@@ -89,13 +90,22 @@ def get_embedding_count(table):
     return sum(1 for name in table.schema.names if name.startswith("embedding_"))
 
 
-def prep_table(data_dir, model_name, filename, count, dimension):
-    """Load, slice to ``count`` rows, check the number of embedding_* columns, keep only those (cu_knn.py:132-148)."""
-    table = load_table(data_dir, filename, 0, count)
+def prep_table(data_dir, model_name, filename, count, dimension, lazy: bool = False):
+    """Load, slice to ``count`` rows, check the number of embedding_* columns, keep only those (cu_knn.py:132-148).
+    ``lazy=True`` (how compute_knn opens the BASE file) reads the file's metadata only and returns a ``ParquetRows`` window with the
+    same ``len`` / ``schema`` / ``slice`` face: base tiles are then decoded from their own row groups, one tile ahead of the GPU
+    (process_batches), instead of the whole file up front -- the reference's read is the wall clock of its kNN stage at C2 size."""
+    if lazy:
+        table = ParquetRows(get_full_filename(data_dir, filename), count)
+    else:
+        table = load_table(data_dir, filename, 0, count)
     total_dimensions = sum("embedding_" in c for c in table.column_names)
     assert output_dimension_validity_check(model_name, dimension, total_dimensions), \
         f"Expected {dimension} values, got {total_dimensions} for model {model_name} [filename: {filename}]"
-    return drop_columns(table, [f"embedding_{i}" for i in range(total_dimensions)])
+    keep = [f"embedding_{i}" for i in range(total_dimensions)]
+    if lazy:
+        return table.select([name for name in table.column_names if name in set(keep)])
+    return drop_columns(table, keep)
 
 
 def table_to_matrix(table) -> np.ndarray:
@@ -199,7 +209,7 @@ def compute_knn(data_dir,
     print("-- prepare query source table for brute-force KNN computation.")
     query_table = prep_table(data_dir, model_name, query_filename, query_count, dimensions)
     print("-- prepare base source table for brute-force KNN computation.")
-    base_table = prep_table(data_dir, model_name, base_filename, base_count, dimensions)
+    base_table = prep_table(data_dir, model_name, base_filename, base_count, dimensions, lazy=True)
 
     if mem_tune:
         batch_size = tune_memory(base_table, batch_size, max_memory_threshold, None, device)
@@ -265,7 +275,10 @@ def process_batches(data_dir,
         eng: KnnEngine = default_engine(devices[slot]) if len(devices) == 1 else KnnEngine(devices[slot])
         eng.set_compute_dtype(dtype)
         eng.set_prescreen(prescreen)
-        try:
+
+        def tiles():
+            """This slot's tiles, decoded on the prefetch thread: tile i+1 is read (base_table.slice reads just its row groups when the
+            base is a lazy ParquetRows; a pyarrow.Table slices for free) while tile i is on the GPU."""
             for start in range(slot, batch_count, len(devices)):
                 batch_offset = start * batch_size
                 batch_length = batch_size if start != batch_count - 1 else len(base_table) - batch_offset
@@ -273,21 +286,33 @@ def process_batches(data_dir,
                 if resume and _partial_pair_exists(data_dir, start, len(query_table), k, tag):
                     print(f"-- base tile {start}: partial files of the same metric/dtype/tile present, skipped")
                     continue
-                dataset = table_columns(base_table.slice(batch_offset, batch_length))
-                assert (k <= batch_length)                              # cu_knn.py:237
-                print(f"Dataset shape: ({batch_length}, {len(dataset)}), Query shape: ({len(query_table)}, {len(queries)})")
-                eng.set_base_columns(dataset)
-                distances, indices = eng.search_columns(queries, k, metric, index_offset=batch_offset)   # + batch_offset, cu_knn.py:273
-                assert (len(distances) == len(query_table))             # cu_knn.py:281-282
-                assert (len(indices) == len(query_table))
-                stream_cudf_to_parquet(get_partial_distances_filename(data_dir, start), distances, PARQUET_ROW_GROUP, tag)
-                stream_cudf_to_parquet(get_partial_indices_filename(data_dir, start), indices, PARQUET_ROW_GROUP, tag)
-                cleanup(dataset, distances, indices)
+                tile = base_table.slice(batch_offset, batch_length)
+                yield start, batch_offset, batch_length, tag, table_columns(tile), tile
+
+        def write_pair(start, distances, indices, tag):
+            stream_cudf_to_parquet(get_partial_distances_filename(data_dir, start), distances, PARQUET_ROW_GROUP, tag)
+            stream_cudf_to_parquet(get_partial_indices_filename(data_dir, start), indices, PARQUET_ROW_GROUP, tag)
+
+        writes = []
+        try:
+            with Prefetch(tiles, slots=2) as feed, ThreadPoolExecutor(max_workers=1) as writer:      # the pair of tile i is written while tile i+1 is searched
+                for start, batch_offset, batch_length, tag, dataset, tile in feed:
+                    assert (k <= batch_length)                              # cu_knn.py:237
+                    print(f"Dataset shape: ({batch_length}, {len(dataset)}), Query shape: ({len(query_table)}, {len(queries)})")
+                    eng.set_base_columns(dataset)
+                    distances, indices = eng.search_columns(queries, k, metric, index_offset=batch_offset)   # + batch_offset, cu_knn.py:273
+                    assert (len(distances) == len(query_table))             # cu_knn.py:281-282
+                    assert (len(indices) == len(query_table))
+                    writes.append(writer.submit(write_pair, start, distances, indices, tag))
+                    del dataset, tile, distances, indices
+                for w in writes:
+                    w.result()
         finally:
             eng.set_compute_dtype('fp32')
             eng.set_prescreen(False)
             if len(devices) > 1:
                 eng.close()
+            gc.collect()
 
     if len(devices) == 1:
         run_tiles(0)

@@ -3,23 +3,30 @@
     compute_knn_ds(data_dir, dimensions, query_filename, query_count, base_filename, base_count,
                    mem_tune=False, k=100, initial_batch_size=200000, max_memory_threshold=0.2, split=True)
 
-The base file is streamed in record batches of ``batch_size`` rows (cu_knn_ds.py:190); each batch is searched on
-the GPU with global row ids and folded into the running result with the device merge kernel, and
-``partial/final_distances.parquet`` / ``final_indices.parquet`` are written ONCE at the end.  (The reference writes
-the final files inside the loop, cu_knn_ds.py:232-233, so every base batch overwrites the previous one and the
-result is only right for a single batch; merge then finds no partial files and is a no-op, merge.py:40-42.)
+The base file is STREAMED in batches of ``batch_size`` rows (cu_knn_ds.py:181-239): a reader thread decodes batch s+1 from its own
+parquet row groups while batch s is on the GPU (host memory holds at most two batches, never the file); each batch is searched
+with global row ids (``+ batch_offset``, cu_knn_ds.py:216) and folded into the running ``[Q,k]`` result by the device merge kernel --
+the running pair lives in HBM between batches, nothing round-trips through numpy -- and ``partial/final_distances.parquet`` /
+``final_indices.parquet`` are written ONCE at the end.  (The reference writes the final files inside the loop, cu_knn_ds.py:232-233,
+so every base batch overwrites the previous one and the result is only right for a single batch; merge then finds no partial files
+and is a no-op, merge.py:40-42.)  ``resume=True`` checkpoints the running pair after every batch (written behind the GPU's back by
+a writer thread) and continues an interrupted run from the last checkpoint whose metric / k / row counts match.
 """
 from __future__ import annotations
 
 import math
+import os
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import pyarrow as pa
 import pyarrow.dataset as ds
+import pyarrow.parquet as pq
 
 from .cu_knn import PARQUET_ROW_GROUP, cleanup, stream_cudf_to_parquet, table_columns
 from .engine import default_engine, mem_info, resolve_metric
 from .nw_utils import get_full_filename, get_partial_distances_filename, get_partial_indices_filename
+from .parquet_stream import ParquetRows, Prefetch
 
 
 def get_gpu_memory(device: int = 0):
@@ -32,10 +39,18 @@ def load_dataset(data_dir, filename):
 
 
 def dataset_count(dataset):
-    return dataset.scanner(batch_size=100000).count_rows()
+    if isinstance(dataset, ParquetRows):
+        return len(dataset)
+    return dataset.count_rows()                                   # parquet metadata only
 
 
 def slice_dataset(dataset, start, end):
+    """Rows [start, end) of a dataset (cu_knn_ds.py:48-49).  The reference materialises them (``dataset.take(arange)``); for the
+    only use it makes of this -- ``slice_dataset(ds, 0, count)`` over parquet files -- a lazy ``ParquetRows`` window is returned
+    instead: nothing is read until a batch is asked for.  Other cases fall back to the reference's materialising form."""
+    files = getattr(dataset, "files", None)
+    if start == 0 and files:
+        return ParquetRows(files, end)
     return ds.dataset(dataset.take(np.arange(start, min(end, dataset_count(dataset)))))
 
 
@@ -82,7 +97,8 @@ def compute_knn_ds(data_dir,
                    engine='raft',
                    metric=None,
                    device: int = 0,
-                   prescreen: bool = False):
+                   prescreen: bool = False,
+                   resume: bool = False):
     batch_size = initial_batch_size
     query_dataset = slice_dataset(load_dataset(data_dir, query_filename), 0, query_count)
     query_column_names = get_dataset_columns(query_dataset, dimensions)
@@ -93,7 +109,65 @@ def compute_knn_ds(data_dir,
     assert (base_count % batch_size == 0) or k <= (base_count % batch_size), \
         f"Cannot generate k of {k} with only {base_count} rows and batch_size of {batch_size}."           # cu_knn_ds.py:167
     process_dataset_batches(data_dir, base_dataset, base_column_names, query_dataset, query_column_names, batch_size,
-                            query_count, k, split, engine=engine, metric=metric, device=device, prescreen=prescreen)
+                            query_count, k, split, engine=engine, metric=metric, device=device, prescreen=prescreen, resume=resume)
+
+
+def _embedding_columns(names):
+    return [c for c in names if c.startswith("embedding_")]
+
+
+def _as_rows(dataset, column_names) -> ParquetRows:
+    """A dataset argument as a lazy row window over its float columns (the text column the reference's scanner also carries,
+    cu_knn_ds.py:122-133, never reaches the GPU and is not decoded here)."""
+    cols = _embedding_columns(column_names)
+    if isinstance(dataset, ParquetRows):
+        return dataset.select(cols)
+    return ParquetRows(dataset.files, None, cols)
+
+
+# ---- resume: the running [Q,k] pair after `rows_done` base rows ------------------------------------------------------------
+def _checkpoint_names(data_dir):
+    return f"{data_dir}/partial/running_distances.parquet", f"{data_dir}/partial/running_indices.parquet"
+
+
+def _checkpoint_tag(metric, k, query_count, base_rows, rows_done) -> dict:
+    return {"nwknn.metric": metric, "nwknn.k": str(k), "nwknn.queries": str(query_count), "nwknn.base_rows": str(base_rows),
+            "nwknn.rows_done": str(rows_done)}
+
+
+def _write_checkpoint(data_dir, dist, idx, tag):
+    fd, fi = _checkpoint_names(data_dir)
+    for name, arr in ((fd, dist), (fi, idx)):                    # whole files, swapped in by rename: a reader never sees half a table
+        stream_cudf_to_parquet(name + ".tmp", arr, PARQUET_ROW_GROUP, tag)
+        os.replace(name + ".tmp", name)
+
+
+def _load_checkpoint(data_dir, metric, k, query_count, base_rows):
+    """-> (rows_done, distances [Q,k] f32, indices [Q,k] i64) of a checkpoint written by a run of the same job, or None."""
+    fd, fi = _checkpoint_names(data_dir)
+    try:
+        td, ti = pq.read_table(fd), pq.read_table(fi)
+        kd, ki = td.schema.metadata or {}, ti.schema.metadata or {}
+        rows_done = int(kd[b"nwknn.rows_done"])
+        want = _checkpoint_tag(metric, k, query_count, base_rows, rows_done)
+        if any(kd.get(a.encode()) != b.encode() or ki.get(a.encode()) != b.encode() for a, b in want.items()):
+            return None
+        if len(td) != query_count or len(ti) != query_count or td.num_columns != k or ti.num_columns != k or not (0 < rows_done <= base_rows):
+            return None
+        dist = np.stack([td.column(str(j)).to_numpy() for j in range(k)], axis=1).astype(np.float32)
+        idx = np.stack([ti.column(str(j)).to_numpy() for j in range(k)], axis=1).astype(np.int64)
+        return rows_done, np.ascontiguousarray(dist), np.ascontiguousarray(idx)
+    except (OSError, KeyError, ValueError, pa.ArrowInvalid):
+        return None
+
+
+def _drop_checkpoint(data_dir):
+    for name in _checkpoint_names(data_dir):
+        for f in (name, name + ".tmp"):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
 
 
 def process_dataset_batches(data_dir,
@@ -109,43 +183,59 @@ def process_dataset_batches(data_dir,
                             engine='raft',
                             metric=None,
                             device: int = 0,
-                            prescreen: bool = False):
+                            prescreen: bool = False,
+                            resume: bool = False):
+    import torch
     metric = resolve_metric(metric, engine)
     eng = default_engine(device)
     eng.set_prescreen(prescreen)
-    query_table = query_dataset.to_table(columns=query_column_names)
+    query_table = _as_rows(query_dataset, query_column_names).to_table()
     queries = table_columns(query_table)
     assert len(query_table) == query_count                                        # cu_knn_ds.py:229-230
-    run_d = run_i = None
-    batch_offset = 0
-    pending, pending_rows = [], 0
+    base_rows = _as_rows(base_dataset, base_column_names)
+    n_base = len(base_rows)
+    os.makedirs(f"{data_dir}/partial", exist_ok=True)
 
-    def flush():
-        nonlocal run_d, run_i, batch_offset, pending, pending_rows
-        base_table = pa.Table.from_batches(pending)
-        base = table_columns(base_table)
-        assert (k <= len(base_table))                                             # cu_knn_ds.py:203
-        eng.set_base_columns(base)
-        d, i = eng.search_columns(queries, k, metric, index_offset=batch_offset)  # + batch_offset, cu_knn_ds.py:216
-        if run_d is None:
-            run_d, run_i = d, i
-        else:
-            run_d, run_i = eng.merge(np.stack([run_d, d]), np.stack([run_i, i]), k)
-        batch_offset += len(base_table)
-        pending, pending_rows = [], 0
-        cleanup(base)
+    run_d = run_i = None                                                          # the running pair: torch CUDA tensors [Q,k]
+    start_row = 0
+    ckpt = _load_checkpoint(data_dir, metric, k, query_count, n_base) if resume else None
+    if ckpt is not None:
+        start_row = ckpt[0]
+        dev = torch.device("cuda", device)
+        run_d, run_i = torch.from_numpy(ckpt[1]).to(dev), torch.from_numpy(ckpt[2]).to(dev)
+        print(f"-- resuming after {start_row} of {n_base} base rows (checkpoint of the same metric / k / row counts)")
+    else:
+        _drop_checkpoint(data_dir)
 
-    # the scanner may cut record batches at row-group boundaries; regroup to exactly batch_size rows
-    for rb in base_dataset.to_batches(batch_size=batch_size, columns=base_column_names):
-        while rb.num_rows:
-            take = min(batch_size - pending_rows, rb.num_rows)
-            pending.append(rb.slice(0, take)); pending_rows += take
-            rb = rb.slice(take)
-            if pending_rows == batch_size:
-                flush()
-    if pending_rows:
-        flush()
-    eng.set_prescreen(False)
+    def batches():
+        """(first row, rows, column views, arrow table) per base batch, decoded on the reader thread one batch ahead of the GPU."""
+        for off in range(start_row, n_base, batch_size):
+            t = base_rows.slice(off, batch_size)
+            yield off, len(t), table_columns(t), t
+
+    pending_write = None
+    try:
+        with Prefetch(batches, slots=2) as feed, ThreadPoolExecutor(max_workers=1) as writer:
+            for batch_offset, rows, base, table in feed:
+                assert (k <= rows)                                                # cu_knn_ds.py:203
+                eng.set_base_columns(base)
+                d, i = eng.search_columns(queries, k, metric, index_offset=batch_offset, out_device=True)   # + batch_offset, cu_knn_ds.py:216
+                if run_d is None:
+                    run_d, run_i = d, i
+                else:                                                             # fold on the device: [2,Q,k] -> [Q,k]
+                    run_d, run_i = eng.merge(torch.stack([run_d, d]), torch.stack([run_i, i]), k)
+                del base, table, d, i
+                if resume and batch_offset + rows < n_base:
+                    if pending_write is not None:
+                        pending_write.result()                                    # one checkpoint in flight at a time
+                    tag = _checkpoint_tag(metric, k, query_count, n_base, batch_offset + rows)
+                    pending_write = writer.submit(_write_checkpoint, data_dir, run_d.cpu().numpy(), run_i.cpu().numpy(), tag)
+            if pending_write is not None:
+                pending_write.result()
+    finally:
+        eng.set_prescreen(False)
+        cleanup()
     assert run_d is not None and len(run_d) == query_count
-    stream_cudf_to_parquet(get_partial_distances_filename(data_dir, -1), run_d, PARQUET_ROW_GROUP)
-    stream_cudf_to_parquet(get_partial_indices_filename(data_dir, -1), run_i, PARQUET_ROW_GROUP)
+    stream_cudf_to_parquet(get_partial_distances_filename(data_dir, -1), run_d.cpu().numpy(), PARQUET_ROW_GROUP)
+    stream_cudf_to_parquet(get_partial_indices_filename(data_dir, -1), run_i.cpu().numpy(), PARQUET_ROW_GROUP)
+    _drop_checkpoint(data_dir)

@@ -179,7 +179,9 @@ class KnnEngine:
         self.rows, self.dim = rows, dim
         del keep
 
-    def search_columns(self, columns, k: int, metric: str = "sqeuclidean", index_offset: int = 0):
+    def search_columns(self, columns, k: int, metric: str = "sqeuclidean", index_offset: int = 0, out_device: bool = False):
+        """Queries as per-dimension host arrays (or chunk lists).  -> (distances [q,k] f32, indices [q,k] i64): numpy arrays, or torch
+        CUDA tensors on this engine's GPU with ``out_device=True`` (results that are folded on the device never visit the host)."""
         metric = resolve_metric(metric)
         table, rows_arr, n_chunks, nq, dim, dt, keep = self._columns(columns, "queries")
         if self.rows == 0:
@@ -190,10 +192,19 @@ class KnnEngine:
             raise ValueError(f"k={k} must satisfy 0 < k <= {self.rows} dataset rows")      # cu_knn.py:237
         if nq == 0:
             raise ValueError("queries are empty")
-        od = np.empty((nq, k), dtype=np.float32)
-        oi = np.empty((nq, k), dtype=np.int64)
+        if out_device:
+            import torch
+            dev = torch.device("cuda", self.device)
+            od = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            oi = torch.empty((nq, k), dtype=torch.int64, device=dev)
+            torch.cuda.current_stream(dev).synchronize()
+            pd_, pi_, oloc = od.data_ptr(), oi.data_ptr(), DEVICE
+        else:
+            od = np.empty((nq, k), dtype=np.float32)
+            oi = np.empty((nq, k), dtype=np.int64)
+            pd_, pi_, oloc = od.ctypes.data, oi.ctypes.data, HOST
         check(self._L.nwknn_search_column_chunks(self._h, table, rows_arr, n_chunks, nq, dt, int(k), METRIC_IDS[metric], int(index_offset),
-                                                 ctypes.c_void_p(od.ctypes.data), ctypes.c_void_p(oi.ctypes.data), HOST), "nwknn_search_column_chunks")
+                                                 ctypes.c_void_p(pd_), ctypes.c_void_p(pi_), oloc), "nwknn_search_column_chunks")
         del keep
         return od, oi
 

@@ -117,7 +117,8 @@ def main(argv=None):
     section = time.time()
     if args.use_dataset_api:
         compute_knn_ds(data_dir, output_dimension, query_filename, args.query_count, base_filename, args.base_count,
-                       args.enable_memory_tuning, args.k, engine=args.engine, device=args.device, prescreen=args.prescreen)
+                       args.enable_memory_tuning, args.k, engine=args.engine, device=args.device, prescreen=args.prescreen,
+                       resume=args.resume)
     else:
         compute_knn(data_dir, args.model_name, output_dimension, query_filename, args.query_count, base_filename,
                     args.base_count, args.enable_memory_tuning, args.k, engine=args.engine, device=args.device,

@@ -330,34 +330,119 @@ int nwo_merge(const float* dists, const int64_t* idx, int32_t n_lists, int64_t n
  *        m_i             = max_j dot(q_i, d_j)
  *        score           = balanced pairwise tree sum of m_0..m_{tq-1} in natural order (tq a power of two)
  *      ranked by (-score, doc id).  docs: [nd][td][d], queries: [nq][tq][d]. --------------------------------------- */
+/* m[i] = max over the doc's td token rows of the ascending-k fmaf chain dot(q_i, d_j); the doc's tokens arrive transposed in
+ * blocks of 16 rows (nwo_transpose_block) so that the AVX2 path runs 16 independent per-row chains per query token -- the chains
+ * themselves are the scalar ones (same operations in the same order), so both paths give the same bits. */
+static void nwo_maxsim_token_max(const float* T, int nblk, int32_t td, const float* qtok, int32_t tq, int32_t d, int fast, float* m)
+{
+    float dots[NWO_QB * NWO_RB];
+    for (int32_t i0 = 0; i0 < tq; i0 += NWO_QB) {
+        const int nqv = (tq - i0 < NWO_QB) ? (int)(tq - i0) : NWO_QB;
+        const float* qv[NWO_QB];
+        for (int i = 0; i < nqv; ++i) { qv[i] = qtok + (size_t)(i0 + i) * d; m[i0 + i] = -INFINITY; }
+        for (int blk = 0; blk < nblk; ++blk) {
+            const int rows = (td - blk * NWO_RB < NWO_RB) ? (td - blk * NWO_RB) : NWO_RB;
+            if (fast) nwo_block_dots(T + (size_t)blk * d * NWO_RB, qv, nqv, d, dots);
+            else nwo_block_dots_scalar(T + (size_t)blk * d * NWO_RB, qv, nqv, d, dots);
+            for (int i = 0; i < nqv; ++i)
+                for (int r = 0; r < rows; ++r) m[i0 + i] = fmaxf(m[i0 + i], dots[i * NWO_RB + r]);     /* ascending j, as the scalar loop */
+        }
+    }
+}
+
+static float nwo_tree_sum(float* m, int32_t tq)
+{
+    for (int32_t step = 1; step < tq; step <<= 1)          /* butterfly: every element ends up holding the tree sum */
+        for (int32_t i = 0; i < tq; i += 2 * step)
+            for (int32_t t = 0; t < step; ++t) {
+                const float a = m[i + t] + m[i + t + step];
+                m[i + t] = a; m[i + t + step] = a;
+            }
+    return m[0];
+}
+
 int nwo_maxsim(const float* docs, int64_t nd, int32_t td, const float* queries, int64_t nq, int32_t tq, int32_t d, int32_t k,
                float* out_score, int64_t* out_doc)
 {
     if (!docs || !queries || !out_score || !out_doc || k <= 0 || k > nd || tq <= 0 || (tq & (tq - 1)) || tq > 64 || nd >= (1ll << 32)) return -1;
-#pragma omp parallel
+    if (td <= 0 || d <= 0) return -1;
+    const int fast = nwo_has_avx2_fma();
+    const int nblk = (td + NWO_RB - 1) / NWO_RB;
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+#endif
+    /* Work is dealt out in chunks of documents, every thread keeping its own k-heap per query (few queries against many documents:
+     * the sampled checks of the full-size tests), merged at the end; the k best by key do not depend on the visiting order.  When
+     * that would need too much memory the queries are dealt out instead, one heap each. */
+    const int by_docs = (double)nq * (double)k * 8.0 * (double)nthreads <= 512.0 * 1048576.0;
+    if (by_docs) {
+        uint64_t* heaps = (uint64_t*)malloc((size_t)nthreads * (size_t)nq * (size_t)k * sizeof(uint64_t));
+        int32_t* hn = (int32_t*)calloc((size_t)nthreads * (size_t)nq, sizeof(int32_t));
+        if (!heaps || !hn) { free(heaps); free(hn); return -3; }
+        const int64_t chunk = 256;
+        const int64_t nchunk = (nd + chunk - 1) / chunk;
+#pragma omp parallel num_threads(nthreads)
+        {
+            int tnum = 0;
+#ifdef _OPENMP
+            tnum = omp_get_thread_num();
+#endif
+            float* T = (float*)aligned_alloc(64, (size_t)nblk * d * NWO_RB * sizeof(float));
+            float m[64];
+            uint64_t* my = heaps + (size_t)tnum * nq * k;
+            int32_t* myn = hn + (size_t)tnum * nq;
+#pragma omp for schedule(dynamic, 1)
+            for (int64_t c = 0; c < nchunk; ++c) {
+                const int64_t d0 = c * chunk, d1 = (d0 + chunk < nd) ? d0 + chunk : nd;
+                for (int64_t doc = d0; doc < d1; ++doc) {
+                    for (int blk = 0; blk < nblk; ++blk)
+                        nwo_transpose_block(docs + (size_t)doc * td * d, (int64_t)blk * NWO_RB, td, d, T + (size_t)blk * d * NWO_RB);
+                    for (int64_t q = 0; q < nq; ++q) {
+                        nwo_maxsim_token_max(T, nblk, td, queries + (size_t)q * tq * d, tq, d, fast, m);
+                        const float score = nwo_tree_sum(m, tq);
+                        nwo_heap h = { my + (size_t)q * k, myn[q], k };
+                        nwo_heap_push(&h, ((uint64_t)nwo_sortable(-score) << 32) | (uint64_t)doc);
+                        myn[q] = h.n;
+                    }
+                }
+            }
+            free(T);
+        }
+        /* merge the per-thread heaps: the k smallest keys of their union */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+        for (int64_t q = 0; q < nq; ++q) {
+            uint64_t* all = (uint64_t*)malloc((size_t)nthreads * (size_t)k * sizeof(uint64_t));
+            size_t n = 0;
+            for (int t = 0; t < nthreads; ++t) {
+                const int32_t cnt = hn[(size_t)t * nq + q];
+                memcpy(all + n, heaps + ((size_t)t * nq + q) * k, (size_t)cnt * sizeof(uint64_t));
+                n += (size_t)cnt;
+            }
+            qsort(all, n, sizeof(uint64_t), nwo_cmp_u64);
+            for (int32_t j = 0; j < k; ++j) {
+                out_score[q * k + j] = -nwo_unsortable((uint32_t)(all[j] >> 32));
+                out_doc[q * k + j] = (int64_t)(uint32_t)all[j];
+            }
+            free(all);
+        }
+        free(heaps); free(hn);
+        return 0;
+    }
+#pragma omp parallel num_threads(nthreads)
     {
         uint64_t* keys = (uint64_t*)malloc((size_t)k * sizeof(uint64_t));
+        float* T = (float*)aligned_alloc(64, (size_t)nblk * d * NWO_RB * sizeof(float));
         float m[64];
 #pragma omp for schedule(dynamic, 1)
         for (int64_t q = 0; q < nq; ++q) {
             nwo_heap h = { keys, 0, k };
             for (int64_t doc = 0; doc < nd; ++doc) {
-                for (int32_t i = 0; i < tq; ++i) {
-                    const float* qv = queries + ((size_t)q * tq + i) * d;
-                    float best = -INFINITY;
-                    for (int32_t j = 0; j < td; ++j) {
-                        const float dot = nwo_dot_chain(qv, docs + ((size_t)doc * td + j) * d, d);
-                        best = fmaxf(best, dot);
-                    }
-                    m[i] = best;
-                }
-                for (int32_t step = 1; step < tq; step <<= 1)          /* butterfly: every element ends up holding the tree sum */
-                    for (int32_t i = 0; i < tq; i += 2 * step)
-                        for (int32_t t = 0; t < step; ++t) {
-                            const float a = m[i + t] + m[i + t + step];
-                            m[i + t] = a; m[i + t + step] = a;
-                        }
-                nwo_heap_push(&h, ((uint64_t)nwo_sortable(-m[0]) << 32) | (uint64_t)doc);
+                for (int blk = 0; blk < nblk; ++blk)
+                    nwo_transpose_block(docs + (size_t)doc * td * d, (int64_t)blk * NWO_RB, td, d, T + (size_t)blk * d * NWO_RB);
+                nwo_maxsim_token_max(T, nblk, td, queries + (size_t)q * tq * d, tq, d, fast, m);
+                const float score = nwo_tree_sum(m, tq);
+                nwo_heap_push(&h, ((uint64_t)nwo_sortable(-score) << 32) | (uint64_t)doc);
             }
             qsort(h.key, (size_t)h.n, sizeof(uint64_t), nwo_cmp_u64);
             for (int32_t j = 0; j < k; ++j) {
@@ -365,7 +450,7 @@ int nwo_maxsim(const float* docs, int64_t nd, int32_t td, const float* queries, 
                 out_doc[q * k + j] = (int64_t)(uint32_t)h.key[j];
             }
         }
-        free(keys);
+        free(keys); free(T);
     }
     return 0;
 }

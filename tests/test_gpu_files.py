@@ -91,6 +91,83 @@ def test_dataset_api_writes_the_final_tables_once(dataset, oracle, prescreen):
     assert np.array_equal(_arr(fi, np.int64), ri) and np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
 
 
+def test_dataset_api_streams_batches_and_resumes_from_its_checkpoint(dataset, oracle, monkeypatch):
+    """7 base batches of 400 rows (the last one 200: unequal), row groups of 700 rows so batches straddle them.  The first run dies
+    inside its fourth batch; the second, with resume=True, picks up the checkpoint written after the third batch (1 200 rows done),
+    searches only the remaining four and ends in the oracle's bits.  Host memory held at most two batches at any time; the running
+    pair stayed on the device between batches."""
+    from neighborhoodwatch_amd import engine as eng_mod
+    from neighborhoodwatch_amd import parquet_stream
+    data_dir, qf, bf = dataset
+    real_search = eng_mod.KnnEngine.search_columns
+    calls = []
+
+    def flaky(self, columns, k, metric="sqeuclidean", index_offset=0, out_device=False):
+        calls.append((index_offset, out_device))
+        if len(calls) == 4:
+            raise RuntimeError("simulated crash in batch 4")
+        return real_search(self, columns, k, metric, index_offset, out_device)
+
+    monkeypatch.setattr(eng_mod.KnnEngine, "search_columns", flaky)
+    with pytest.raises(RuntimeError, match="simulated crash"):
+        cu_knn_ds.compute_knn_ds(data_dir, 384, qf, 300, bf, 2600, False, 10, 400, resume=True)
+    assert [c[0] for c in calls] == [0, 400, 800, 1200] and all(c[1] for c in calls)     # global offsets; results asked for on the device
+    ck = cu_knn_ds._load_checkpoint(data_dir, "sqeuclidean", 10, 300, 2600)
+    assert ck is not None and ck[0] == 1200
+    assert cu_knn_ds._load_checkpoint(data_dir, "cosine", 10, 300, 2600) is None         # another metric's checkpoint is not trusted
+
+    monkeypatch.setattr(eng_mod.KnnEngine, "search_columns", real_search)
+    seen = []
+    real_prefetch = parquet_stream.Prefetch
+
+    class Watched(real_prefetch):
+        def __init__(self, *a, **kw):
+            super().__init__(*a, **kw)
+            seen.append(self)
+
+    monkeypatch.setattr(cu_knn_ds, "Prefetch", Watched)
+    calls2 = []
+    monkeypatch.setattr(eng_mod.KnnEngine, "search_columns",
+                        lambda self, columns, k, metric="sqeuclidean", index_offset=0, out_device=False:
+                        (calls2.append(index_offset), real_search(self, columns, k, metric, index_offset, out_device))[1])
+    cu_knn_ds.compute_knn_ds(data_dir, 384, qf, 300, bf, 2600, False, 10, 400, resume=True)
+    assert calls2 == [1200, 1600, 2000, 2400]                                             # the first three batches were not searched again
+    assert len(seen) == 1 and seen[0].max_alive <= 2                                      # at most two batches in host memory
+    fd, fi = _final(data_dir)
+    base = synth.gen_unit_rows(0x72, 0, 2600, 384); queries = synth.gen_unit_rows(0x71, 0, 300, 384)
+    rd, ri = oracle.knn_canonical(base, queries, 10)
+    assert np.array_equal(_arr(fi, np.int64), ri) and np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
+    import os
+    assert not any(os.path.exists(f) for f in cu_knn_ds._checkpoint_names(data_dir))      # a finished job leaves no checkpoint behind
+
+
+def test_compute_knn_reads_tiles_lazily_and_overlaps(dataset, oracle, monkeypatch):
+    """compute_knn opens the base file lazily: a tile is decoded from its own row groups on the prefetch thread while the previous
+    one is searched (two tiles alive at most), and the partial pairs -- written by a writer thread -- are the reference layout."""
+    from neighborhoodwatch_amd import parquet_stream
+    data_dir, qf, bf = dataset
+    seen = []
+    real_prefetch = parquet_stream.Prefetch
+
+    class Watched(real_prefetch):
+        def __init__(self, *a, **kw):
+            super().__init__(*a, **kw)
+            seen.append(self)
+
+    monkeypatch.setattr(cu_knn, "Prefetch", Watched)
+    read_calls = []
+    real_slice = parquet_stream.ParquetRows.slice
+    monkeypatch.setattr(parquet_stream.ParquetRows, "slice", lambda self, off=0, ln=None: (read_calls.append((off, ln)), real_slice(self, off, ln))[1])
+    cu_knn.compute_knn(data_dir, "intfloat/e5-small-v2", 384, qf, 300, bf, 2600, False, 10, 900)
+    assert read_calls == [(0, 900), (900, 900), (1800, 800)]                               # one read per tile, nothing up front
+    assert len(seen) == 1 and seen[0].max_alive <= 2
+    merge.merge_indices_and_distances(data_dir, k=10)
+    fd, fi = _final(data_dir)
+    base = synth.gen_unit_rows(0x72, 0, 2600, 384); queries = synth.gen_unit_rows(0x71, 0, 300, 384)
+    rd, ri = oracle.knn_canonical(base, queries, 10)
+    assert np.array_equal(_arr(fi, np.int64), ri) and np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
+
+
 def test_merge_drops_rownum_and_handles_many_lists(tmp_path, oracle):
     """tests/test_03_merge.py:14-24 writes a RowNum column next to the k columns."""
     import pandas as pd

@@ -129,3 +129,51 @@ def test_c4_per_gpu_slice_properties_and_sampled_parity(oracle):
     rd, ri = oracle.knn_canonical(hb, hq, k)
     assert np.array_equal(ii, ri + offset)
     assert np.array_equal(di.view(np.uint32), rd.view(np.uint32))
+
+
+@pytest.mark.timeout(1500)
+def test_c5_maxsim_full_size_properties_and_sampled_parity(oracle):
+    """BASELINE.json config 5 at full size on one GPU: 2 048 queries x 32 tokens against 1M documents x 64 tokens, d=128, k=1000
+    (MaxSim is an extension: the reference's `ck` runs flat token kNN, colbert_knn.py:84-126, so the checker is the MaxSim oracle and
+    there is no reference parity to claim).  Size-independent properties for all rows, pre-screened == direct bit for bit over the
+    whole [2048, 1000] result, and 8 sampled queries recomputed by oracle.maxsim_canonical against ALL 1M documents."""
+    import torch
+    from neighborhoodwatch_amd import KnnEngine
+    Q, B, d, k = 2_048, 1_000_000, 128, 1000
+    with KnnEngine(0) as eng:
+        docs = eng.generate(oracle.SEED_BASE, 0, B * 64, d).view(B, 64, d)
+        queries = eng.generate(oracle.SEED_QUERY, 0, Q * 32, d).view(Q, 32, d)
+        eng.maxsim_set_docs(docs)
+        score, doc = eng.maxsim_search(queries, k)
+        st = eng.stats()
+        # a query made of a document's own first 32 tokens: every token finds itself, so the score is at least the sum of those
+        # tokens' squared norms (~1 365 on this data, where an unrelated document scores ~300)
+        probe_docs = torch.arange(654_321, 654_321 + 8, device="cuda")
+        probe = docs[probe_docs, :32, :].clone()
+        ps, pdoc = eng.maxsim_search(probe, 5)
+        eng.set_prescreen(True)
+        eng.maxsim_set_docs(docs)
+        pscore, pdoc_all = eng.maxsim_search(queries, k)
+        pst = eng.stats()
+        eng.set_prescreen(False)
+    assert st["prescreen"] == 0 and pst["prescreen"] == 1 and st["overflowed_queries"] == 0
+    assert torch.equal(pdoc_all, doc) and torch.equal(pscore.view(torch.int32), score.view(torch.int32))     # pre-screened == direct, all 2 048 000 entries
+    del pscore, pdoc_all
+    assert bool((score[:, 1:] <= score[:, :-1]).all())                          # descending by score
+    assert int(doc.min()) >= 0 and int(doc.max()) < B
+    srt = torch.sort(doc, dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())                              # no duplicate documents
+    self_norms = (probe.double() ** 2).sum(dim=2).sum(dim=1)                    # sum over the 32 tokens of |token|^2
+    assert bool((ps[:, 0].double() >= self_norms * (1 - 1e-5)).all())
+    assert bool((pdoc[:, 0] == probe_docs).all())                               # on random tokens nothing comes near a document's own prefix
+    rows = np.linspace(0, Q - 1, 8).astype(np.int64)
+    sel = torch.from_numpy(rows).cuda()
+    hq = queries[sel].cpu().numpy()
+    hs, hd = score[sel].cpu().numpy(), doc[sel].cpu().numpy()
+    del score, doc, queries
+    hdocs = docs.cpu().numpy()                                                   # 32.8 GB D2H
+    del docs
+    rs, ri = oracle.maxsim_canonical(hdocs, hq, k)
+    assert np.array_equal(hd, ri)
+    assert np.array_equal(hs.view(np.uint32), rs.view(np.uint32))
+    assert np.array_equal(hdocs[777_000, :2], oracle.gen_numpy(oracle.SEED_BASE, 777_000 * 64, 2, d))

@@ -241,3 +241,78 @@ def test_table_columns_hands_over_chunks_without_copying(tmp_path):
                       "embedding_1": pa.chunked_array([[4.0], [5.0, 6.0]], type=pa.float32())})
     m = cu_knn.table_columns(mixed)
     assert all(isinstance(c, np.ndarray) for c in m) and m[1].tolist() == [4.0, 5.0, 6.0]
+
+
+def test_parquet_rows_reads_only_what_a_tile_needs(tmp_path):
+    """ParquetRows: a lazy window with a pyarrow.Table's len / schema / slice; a slice decodes the row groups that overlap it and
+    nothing else; windows over several files number their rows through."""
+    from neighborhoodwatch_amd.parquet_stream import ParquetRows
+    f1 = synth.write_source_parquet(str(tmp_path / "a.parquet"), 5, 50, 8, chunk_rows=16)
+    f2 = synth.write_source_parquet(str(tmp_path / "b.parquet"), 6, 30, 8, chunk_rows=7)
+    ref = np.concatenate([synth.gen_rows(5, 0, 50, 8), synth.gen_rows(6, 0, 30, 8)])
+    cols = [f"embedding_{i}" for i in range(8)]
+    rows = ParquetRows([f1, f2], 77, cols)
+    assert len(rows) == 77 and rows.num_rows == 77 and rows.schema.names == cols and rows.column_names == cols
+    for off, ln in [(0, 77), (3, 9), (15, 20), (40, 30), (49, 3), (70, 100), (77, 5), (16, 16)]:
+        t = rows.slice(off, ln)
+        assert np.array_equal(cu_knn.table_to_matrix(t), ref[off:min(off + ln, 77)]), (off, ln)
+    assert [len(t) for t in rows.iter_tables(20)] == [20, 20, 20, 17]
+    assert [len(t) for t in rows.iter_tables(20, start=40)] == [20, 17]
+    opened = []
+    real = pq.ParquetFile.read_row_groups
+    try:
+        pq.ParquetFile.read_row_groups = lambda self, groups, **kw: (opened.append(list(groups)), real(self, groups, **kw))[1]
+        ParquetRows(f1, 50, cols).slice(17, 10)                                  # rows 17..26 live in row group 1 (rows 16..31)
+    finally:
+        pq.ParquetFile.read_row_groups = real
+    assert opened == [[1]]
+    assert len(ParquetRows(f1).select(["embedding_3"]).head(5).to_table()) == 5
+    with pytest.raises(KeyError):
+        ParquetRows(f1, 10, ["no_such_column"])
+
+
+def test_prefetch_keeps_two_items_alive_and_hands_errors_over():
+    import time
+    from neighborhoodwatch_amd.parquet_stream import Prefetch
+
+    def gen():
+        for i in range(8):
+            yield i
+
+    p = Prefetch(gen, slots=2)
+    got = []
+    for x in p:
+        time.sleep(0.01)                                                         # the producer runs ahead while the consumer works
+        got.append(x)
+    assert got == list(range(8)) and p.max_alive == 2
+
+    def bad():
+        yield 1
+        raise RuntimeError("boom")
+
+    with pytest.raises(RuntimeError, match="boom"):
+        for _ in Prefetch(bad, slots=2):
+            pass
+    with Prefetch(gen, slots=1) as q:                                            # closing early stops the producer
+        assert next(q) == 0
+
+
+def test_slice_dataset_is_lazy_and_checkpoints_round_trip(tmp_path):
+    from neighborhoodwatch_amd import cu_knn_ds
+    from neighborhoodwatch_amd.parquet_stream import ParquetRows
+    f = synth.write_source_parquet(str(tmp_path / "b.parquet"), 6, 30, 8, chunk_rows=7)
+    d = cu_knn_ds.load_dataset(str(tmp_path), "b.parquet")
+    w = cu_knn_ds.slice_dataset(d, 0, 20)                                        # cu_knn_ds.py:48-49, without materialising
+    assert isinstance(w, ParquetRows) and cu_knn_ds.dataset_count(w) == 20 and cu_knn_ds.dataset_count(d) == 30
+    assert cu_knn_ds.get_dataset_columns(w, 8)[-1] == "embedding_7"
+    (tmp_path / "partial").mkdir()
+    rng = np.random.default_rng(1)
+    dist = np.sort(rng.random((12, 5)).astype(np.float32), axis=1); idx = rng.integers(0, 1000, (12, 5)).astype(np.int64)
+    cu_knn_ds._write_checkpoint(str(tmp_path), dist, idx, cu_knn_ds._checkpoint_tag("sqeuclidean", 5, 12, 1000, 400))
+    ck = cu_knn_ds._load_checkpoint(str(tmp_path), "sqeuclidean", 5, 12, 1000)
+    assert ck[0] == 400 and np.array_equal(ck[1], dist) and np.array_equal(ck[2], idx)
+    assert cu_knn_ds._load_checkpoint(str(tmp_path), "sqeuclidean", 6, 12, 1000) is None       # other k
+    assert cu_knn_ds._load_checkpoint(str(tmp_path), "sqeuclidean", 5, 12, 999) is None        # other base
+    assert merge.get_file_count(str(tmp_path / "partial")) == 0                             # checkpoints are not partial pairs
+    cu_knn_ds._drop_checkpoint(str(tmp_path))
+    assert cu_knn_ds._load_checkpoint(str(tmp_path), "sqeuclidean", 5, 12, 1000) is None
