@@ -157,6 +157,42 @@ int nwknn_search_column_chunks(nwknn_handle h, const void* const* chunks, const 
 int nwknn_merge(nwknn_handle h, const float* dists, const int64_t* idx, int32_t n_lists, int64_t nq, int32_t k_in,
                 int32_t k_out, float* out_dist, int64_t* out_idx, int location);
 
+/* ---- one process, N GPUs of one node: base rows sharded over the devices, ONE RCCL all-gather of the [Q,k] partial lists over
+ *      xGMI, merge by (distance, index).  The reference is pinned to GPU 0 (cu_knn.py:65) and folds per-base-tile partial tables on
+ *      the CPU (merge.py:56-101): this is that fold across GPUs, reachable from any host language (the one-process-per-GPU flavour
+ *      of the same exchange is neighborhoodwatch_amd/distributed.py over torch.distributed).  RCCL is bound at run time (librccl.so.1);
+ *      a call fails with NWKNN_EHIP when it cannot be loaded. ------------------------------------------------------------------- */
+typedef struct nwknn_comm* nwknn_comm_handle;
+/* accounting of the most recent nwknn_search_sharded (milliseconds from HIP events; maxima over the devices) */
+typedef struct nwknn_comm_stats {
+    int32_t n_devices, k;
+    int64_t nq;
+    double search_ms;                     /* slowest device: its shard search, first to last launch (needs option "profile" = 1) */
+    double allgather_ms;                  /* the two ncclAllGather calls (distances, indices) */
+    double merge_ms;                      /* merge of a device's slice of the query rows */
+    double allgather_bytes_per_device;    /* bytes every device receives: N * Q * k * 12 */
+    double tile_flops, tile_ms;           /* sums over the devices (option "profile"): tile_flops / tile_ms = per-GPU kernel rate */
+} nwknn_comm_stats;
+/* An engine handle + an RCCL communicator per listed device (ncclCommInitAll: all ranks live in this process).  devices: distinct HIP
+ * device ordinals, all gfx950.  n_dev = 1 is valid (the exchange is then a copy) and gives the result of nwknn_search. */
+int nwknn_comm_create(nwknn_comm_handle* out, const int* devices, int n_dev);
+int nwknn_comm_destroy(nwknn_comm_handle c);
+int nwknn_comm_device_count(nwknn_comm_handle c);
+/* The engine handle of device i (owned by the communicator): for per-device nwknn_get_stats; options are set on all devices at once with */
+nwknn_handle nwknn_comm_engine(nwknn_comm_handle c, int i);
+int nwknn_comm_set_option(nwknn_comm_handle c, const char* name, int64_t value);
+/* Shard rows [0, rows) of a HOST row-major base contiguously over the devices: device g takes rows [rows*g/N, rows*(g+1)/N), uploaded and
+ * laid out by one host thread per device.  dtype NWKNN_DTYPE_F32 | NWKNN_DTYPE_F16 as in nwknn_set_base. */
+int nwknn_comm_set_base(nwknn_comm_handle c, const void* base_host, int64_t rows, int32_t d, int dtype);
+/* The same with seeded synthetic rows generated on the devices (nwknn_generate; row r of the global base on whichever device holds it). */
+int nwknn_comm_generate_base(nwknn_comm_handle c, uint64_t seed, int64_t rows, int32_t d, int dtype);
+/* distances, indices = knn(whole base, queries, k) with HOST queries and HOST outputs [nq][k]: every device searches its shard with global
+ * row ids (index_offset = first row of the shard: "+ batch_offset", cu_knn.py:273), one all-gather per array, device g merges rows
+ * [nq*g/N, nq*(g+1)/N) of the result.  Requires k <= rows of the smallest shard (cu_knn.py:177-178,237). */
+int nwknn_search_sharded(nwknn_comm_handle c, const void* queries_host, int64_t nq, int dtype, int32_t k, int metric, float* out_dist,
+                         int64_t* out_idx);
+int nwknn_comm_get_stats(nwknn_comm_handle c, nwknn_comm_stats* out);
+
 /* ---- MaxSim late interaction (BASELINE.json config 5).  NOT in the reference: its `ck` program runs flat token-level
  *      kNN through process_batches (colbert_knn.py:84-126); this is the ColBERT scoring rule itself, provided as an
  *      extension with its own oracle (oracle nwo_maxsim) and no reference parity claim. ---------------------------- */

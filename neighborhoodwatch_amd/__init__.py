@@ -5,4 +5,4 @@ see DESIGN.md for scope and INTEGRATION.md for how the reference binds to it.
 """
 __version__ = "0.1.0"
 
-from .engine import KnnEngine, knn, device_count, mem_info, resolve_metric  # noqa: F401
+from .engine import KnnEngine, ShardedKnnEngine, knn, device_count, mem_info, resolve_metric  # noqa: F401

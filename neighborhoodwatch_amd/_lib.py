@@ -29,6 +29,8 @@ EXPORTS = [
     "nwknn_merge", "nwknn_generate", "nwknn_set_base_columns", "nwknn_search_columns",
     "nwknn_set_base_column_chunks", "nwknn_search_column_chunks",
     "nwknn_maxsim_set_docs", "nwknn_maxsim_search", "nwknn_tile_kernel_name",
+    "nwknn_comm_create", "nwknn_comm_destroy", "nwknn_comm_device_count", "nwknn_comm_engine", "nwknn_comm_set_option",
+    "nwknn_comm_set_base", "nwknn_comm_generate_base", "nwknn_search_sharded", "nwknn_comm_get_stats",
 ]
 
 
@@ -39,6 +41,17 @@ class NwknnStats(ctypes.Structure):
         ("overflowed_queries", c_int32),
         ("tile_ms", c_double), ("compact_ms", c_double), ("prep_ms", c_double), ("total_ms", c_double),
         ("tile_flops", c_double), ("rescore_ms", c_double), ("prescreen", c_int32), ("reserved_", c_int32),
+    ]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class NwknnCommStats(ctypes.Structure):
+    _fields_ = [
+        ("n_devices", c_int32), ("k", c_int32), ("nq", c_int64),
+        ("search_ms", c_double), ("allgather_ms", c_double), ("merge_ms", c_double), ("allgather_bytes_per_device", c_double),
+        ("tile_flops", c_double), ("tile_ms", c_double),
     ]
 
     def as_dict(self) -> dict:
@@ -107,10 +120,20 @@ def load() -> ctypes.CDLL:
     L.nwknn_maxsim_set_docs.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int, c_int]
     L.nwknn_maxsim_search.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int, c_int, c_int32, c_int64, c_void_p, c_void_p, c_int]
     L.nwknn_generate.argtypes = [c_void_p, c_uint64, c_int64, c_int64, c_int32, c_int, c_void_p]
+    L.nwknn_comm_create.argtypes = [POINTER(c_void_p), POINTER(c_int), c_int]
+    L.nwknn_comm_destroy.argtypes = [c_void_p]
+    L.nwknn_comm_device_count.argtypes = [c_void_p]
+    L.nwknn_comm_engine.argtypes = [c_void_p, c_int]
+    L.nwknn_comm_set_option.argtypes = [c_void_p, c_char_p, c_int64]
+    L.nwknn_comm_set_base.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int]
+    L.nwknn_comm_generate_base.argtypes = [c_void_p, c_uint64, c_int64, c_int32, c_int]
+    L.nwknn_search_sharded.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int32, c_int, c_void_p, c_void_p]
+    L.nwknn_comm_get_stats.argtypes = [c_void_p, POINTER(NwknnCommStats)]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ("nwknn_last_error", "nwknn_tile_kernel_name"):
+        if name not in ("nwknn_last_error", "nwknn_tile_kernel_name", "nwknn_comm_engine"):
             fn.restype = c_int
+    L.nwknn_comm_engine.restype = c_void_p
     L.nwknn_tile_kernel_name.restype = c_char_p
     _lib = L
     return L

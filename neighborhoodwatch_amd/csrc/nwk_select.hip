@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void nwk_finalize_kernel(const u64* __restrict
 // merge of n_lists partial top-k lists [n_lists][Q][k_in] by (distance, index)   (merge.py:73-101)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nwk_merge_kernel(const float* __restrict__ dists, const long long* __restrict__ idx, int n_lists,
-                                                         long long nq, int k_in, int k_out, float* __restrict__ out_d,
+                                                         long long list_stride, int k_in, int k_out, float* __restrict__ out_d,
                                                          long long* __restrict__ out_i, int np2)
 {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void nwk_merge_kernel(const float* __restrict_
     for (int i = tid; i < np2; i += 256) {
         if (i < w) {
             const int lst = i / k_in, j = i - lst * k_in;
-            const long long at = ((long long)lst * nq + q) * k_in + j;
+            const long long at = (long long)lst * list_stride + q * k_in + j;        // list_stride: entries between two lists (nq * k_in when they are dense)
             const long long id = idx[at];
             sd[i] = id < 0 ? 0xFFFFFFFFu : sortable_u32(dists[at]);
             si[i] = id < 0 ? 0x7FFFFFFFFFFFFFFFll : id;
@@ -353,15 +353,17 @@ hipError_t nwk_launch_finalize(hipStream_t st, const u64* buf, const u32* cnt, i
     return hipGetLastError();
 }
 
-hipError_t nwk_launch_merge(hipStream_t st, const float* dists, const long long* idx, int n_lists, long long nq, int k_in, int k_out,
-                            float* out_d, long long* out_i)
+// lists l = 0..n_lists-1 start list_stride entries apart (dense [n_lists][nq][k_in]: list_stride = nq * k_in; a slice of the query rows of
+// gathered lists: the stride of the whole lists)
+hipError_t nwk_launch_merge(hipStream_t st, const float* dists, const long long* idx, int n_lists, long long list_stride, long long nq, int k_in,
+                            int k_out, float* out_d, long long* out_i)
 {
     if (nq <= 0) return hipSuccess;
     int np2 = 2;
     while (np2 < n_lists * k_in) np2 <<= 1;
     const size_t lds = (size_t)np2 * 12;
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(nwk_merge_kernel, dim3((unsigned)nq), dim3(256), lds, st, dists, idx, n_lists, nq, k_in, k_out, out_d, out_i, np2);
+    hipLaunchKernelGGL(nwk_merge_kernel, dim3((unsigned)nq), dim3(256), lds, st, dists, idx, n_lists, list_stride, k_in, k_out, out_d, out_i, np2);
     return hipGetLastError();
 }
 

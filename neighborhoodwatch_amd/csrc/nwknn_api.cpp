@@ -48,6 +48,8 @@ static int fail(int code, const char* fmt, ...)
     return code;
 }
 
+int nwknn_internal_fail(int code, const char* msg) { g_err = msg ? msg : ""; return code; }       // for the other translation units of the library
+
 #define HIPCHK(expr)                                                                                             \
     do {                                                                                                         \
         hipError_t e_ = (expr);                                                                                  \
@@ -1311,7 +1313,7 @@ extern "C" int nwknn_merge(nwknn_handle h, const float* dists, const int64_t* id
         HIPCHK(hipMemcpyAsync(h->mrg_i.p, idx, nin * 8, hipMemcpyHostToDevice, h->stream));
         dd = h->mrg_d.as<float>(); di = h->mrg_i.as<long long>(); od = h->out_d.as<float>(); oi = h->out_i.as<long long>();
     }
-    HIPCHK(nwk_launch_merge(h->stream, dd, di, n_lists, nq, k_in, k_out, od, oi));
+    HIPCHK(nwk_launch_merge(h->stream, dd, di, n_lists, (long long)nq * k_in, nq, k_in, k_out, od, oi));
     if (location == NWKNN_HOST) {
         HIPCHK(hipMemcpyAsync(out_dist, od, nout * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(out_idx, oi, nout * 8, hipMemcpyDeviceToHost, h->stream));

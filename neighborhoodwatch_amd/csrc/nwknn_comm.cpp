@@ -1,0 +1,383 @@
+// nwknn_comm.cpp -- the multi-GPU face of the C ABI (include/nwknn.h, "one process, N GPUs of one node"): base rows sharded over the
+// devices, queries replicated, per-shard partial top-k, ONE RCCL all-gather of the [Q,k] partial lists over xGMI, merge by (distance,
+// index).  The reference has nothing to mirror here -- it is pinned to GPU 0 (cu_knn.py:65) and folds per-base-tile partial tables on
+// the CPU (merge.py:56-101); this is SURVEY 8b/8e's design, reachable from any host language, not only through torch.distributed
+// (neighborhoodwatch_amd/distributed.py is the one-process-per-GPU flavour of the same exchange).
+//
+// One host thread per device drives that device's engine handle (nwknn_search blocks on its stream); the collective is issued from the
+// calling thread inside ncclGroupStart/End, one call per device, on the handles' own streams; afterwards device g merges only ITS
+// slice of the query rows (rows [Q g / N, Q (g+1) / N) of every gathered list) and copies that slice to the caller's host buffers.
+// RCCL is bound at run time (dlopen of librccl.so.1: the copy already in the process -- torch ships one -- or the system's), so the
+// library itself carries no link-time dependency on it and single-GPU users never load it... except through this file's entry points.
+#include "../../include/nwknn.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "nwknn_internal.h"
+
+static int cfail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return nwknn_internal_fail(code, buf);
+}
+
+#define CHIP(expr)                                                                                                              \
+    do {                                                                                                                        \
+        hipError_t e_ = (expr);                                                                                                 \
+        if (e_ != hipSuccess)                                                                                                   \
+            return cfail(e_ == hipErrorOutOfMemory ? NWKNN_ENOMEM : NWKNN_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                         __FILE__, __LINE__);                                                                                   \
+    } while (0)
+
+// ---- RCCL, bound at run time ---------------------------------------------------------------------------------------------------------
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+};
+
+static int load_rccl(Rccl* r)
+{
+    static Rccl cached;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void* lib = nullptr;
+        for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (lib) break; }     // a copy already in the process first
+        for (const char* n : names) { if (lib) break; lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); }
+        if (lib) {
+            cached.lib = lib;
+            cached.CommInitAll = (decltype(cached.CommInitAll))dlsym(lib, "ncclCommInitAll");
+            cached.CommDestroy = (decltype(cached.CommDestroy))dlsym(lib, "ncclCommDestroy");
+            cached.AllGather = (decltype(cached.AllGather))dlsym(lib, "ncclAllGather");
+            cached.GroupStart = (decltype(cached.GroupStart))dlsym(lib, "ncclGroupStart");
+            cached.GroupEnd = (decltype(cached.GroupEnd))dlsym(lib, "ncclGroupEnd");
+            cached.GetErrorString = (decltype(cached.GetErrorString))dlsym(lib, "ncclGetErrorString");
+            cached.GetVersion = (decltype(cached.GetVersion))dlsym(lib, "ncclGetVersion");
+        }
+    }
+    if (!cached.lib) return cfail(NWKNN_EHIP, "RCCL is not available: dlopen(librccl.so.1) failed: %s", dlerror());
+    if (!cached.CommInitAll || !cached.CommDestroy || !cached.AllGather || !cached.GroupStart || !cached.GroupEnd || !cached.GetErrorString)
+        return cfail(NWKNN_EHIP, "RCCL library lacks a required symbol (ncclCommInitAll / ncclAllGather / ncclGroupStart ...)");
+    *r = cached;
+    return NWKNN_OK;
+}
+
+#define CNCCL(c, expr)                                                                                              \
+    do {                                                                                                            \
+        ncclResult_t r_ = (expr);                                                                                   \
+        if (r_ != ncclSuccess) return cfail(NWKNN_EHIP, "%s failed: %s (%s:%d)", #expr, (c)->rccl.GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+struct DBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return NWKNN_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) { p = nullptr; return cfail(NWKNN_ENOMEM, "hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(e)); }
+        bytes = need;
+        return NWKNN_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct DevPart {
+    int device = -1;
+    nwknn_handle h = nullptr;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;                 // collective + merge + D2H of this device
+    DBuf b_part_d, b_part_i;                      // [Q][k] this shard's partial lists
+    DBuf b_all_d, b_all_i;                        // [N][Q][k] gathered
+    DBuf b_grp_d, b_grp_i;                        // fold buffer when N * k exceeds one merge (see merge_slice)
+    DBuf b_out_d, b_out_i;                        // [Q slice][k] merged
+    float* part_d = nullptr; long long* part_i = nullptr;
+    float* all_d = nullptr; long long* all_i = nullptr;
+    float* grp_d = nullptr; long long* grp_i = nullptr;
+    float* out_d = nullptr; long long* out_i = nullptr;
+    long long row_lo = 0, row_hi = 0;             // this shard's base rows
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+};
+
+struct nwknn_comm {
+    Rccl rccl;
+    std::vector<DevPart> dev;
+    long long rows = 0;
+    int d = 0;
+    nwknn_comm_stats stats;
+};
+
+static void shard_bounds(long long n, int world, int r, long long* lo, long long* hi)       // distributed.shard_bounds
+{
+    *lo = n * r / world;
+    *hi = n * (r + 1) / world;
+}
+
+template <class F>
+static int on_every_device(nwknn_comm* c, F&& f)
+{
+    // one host thread per device (the engine calls block on their stream); the first failure is reported, its message kept
+    const int n = (int)c->dev.size();
+    std::vector<int> rc((size_t)n, NWKNN_OK);
+    std::vector<std::string> msg((size_t)n);
+    std::vector<std::thread> pool;
+    auto work = [&](int g) {
+        rc[g] = f(g);
+        if (rc[g] != NWKNN_OK) msg[g] = nwknn_last_error();      // thread-local in the worker: carry it over
+    };
+    pool.reserve((size_t)n);
+    for (int g = 1; g < n; ++g) {
+        try { pool.emplace_back(work, g); } catch (...) { work(g); }
+    }
+    work(0);
+    for (auto& t : pool) t.join();
+    for (int g = 0; g < n; ++g)
+        if (rc[g] != NWKNN_OK) return cfail(rc[g], "device %d: %s", c->dev[g].device, msg[g].c_str());
+    return NWKNN_OK;
+}
+
+extern "C" int nwknn_comm_destroy(nwknn_comm_handle c)
+{
+    if (!c) return NWKNN_OK;
+    for (DevPart& p : c->dev) {
+        if (p.device >= 0) (void)hipSetDevice(p.device);
+        if (p.stream) (void)hipStreamSynchronize(p.stream);
+        if (p.comm && c->rccl.CommDestroy) (void)c->rccl.CommDestroy(p.comm);
+        for (DBuf* b : {&p.b_part_d, &p.b_part_i, &p.b_all_d, &p.b_all_i, &p.b_grp_d, &p.b_grp_i, &p.b_out_d, &p.b_out_i}) b->release();
+        for (hipEvent_t e : {p.ev0, p.ev1, p.ev2}) if (e) (void)hipEventDestroy(e);
+        if (p.stream) (void)hipStreamDestroy(p.stream);
+        if (p.h) (void)nwknn_destroy(p.h);
+    }
+    delete c;
+    return NWKNN_OK;
+}
+
+extern "C" int nwknn_comm_create(nwknn_comm_handle* out, const int* devices, int n_dev)
+{
+    if (!out || !devices || n_dev <= 0) return cfail(NWKNN_EINVAL, "nwknn_comm_create: null argument or n_dev <= 0");
+    if (n_dev > 64) return cfail(NWKNN_EINVAL, "nwknn_comm_create: at most 64 devices");
+    for (int a = 0; a < n_dev; ++a)
+        for (int b = a + 1; b < n_dev; ++b)
+            if (devices[a] == devices[b]) return cfail(NWKNN_EINVAL, "nwknn_comm_create: device %d listed twice (one shard per GPU)", devices[a]);
+    nwknn_comm* c = new (std::nothrow) nwknn_comm();
+    if (!c) return cfail(NWKNN_ENOMEM, "out of host memory");
+    memset(&c->stats, 0, sizeof c->stats);
+    int rc = load_rccl(&c->rccl);
+    if (rc != NWKNN_OK) { delete c; return rc; }
+    try { c->dev.resize((size_t)n_dev); } catch (...) { delete c; return cfail(NWKNN_ENOMEM, "out of host memory"); }
+    auto fail_with = [&](int code) { (void)nwknn_comm_destroy(c); return code; };
+    for (int g = 0; g < n_dev; ++g) {
+        DevPart& p = c->dev[g];
+        p.device = devices[g];
+        rc = nwknn_create(&p.h, devices[g]);                  // checks the device is a gfx950
+        if (rc != NWKNN_OK) return fail_with(rc);
+        if (hipSetDevice(devices[g]) != hipSuccess || hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreate(&p.ev0) != hipSuccess || hipEventCreate(&p.ev1) != hipSuccess || hipEventCreate(&p.ev2) != hipSuccess)
+            return fail_with(cfail(NWKNN_EHIP, "nwknn_comm_create: stream / event creation failed on device %d", devices[g]));
+    }
+    std::vector<ncclComm_t> comms((size_t)n_dev, nullptr);
+    ncclResult_t nr = c->rccl.CommInitAll(comms.data(), n_dev, devices);      // one communicator per device, all in this process
+    if (nr != ncclSuccess) return fail_with(cfail(NWKNN_EHIP, "ncclCommInitAll over %d device(s) failed: %s", n_dev, c->rccl.GetErrorString(nr)));
+    for (int g = 0; g < n_dev; ++g) c->dev[g].comm = comms[g];
+    *out = c;
+    return NWKNN_OK;
+}
+
+extern "C" int nwknn_comm_device_count(nwknn_comm_handle c) { return c ? (int)c->dev.size() : 0; }
+
+extern "C" nwknn_handle nwknn_comm_engine(nwknn_comm_handle c, int i)
+{
+    if (!c || i < 0 || i >= (int)c->dev.size()) return nullptr;
+    return c->dev[i].h;
+}
+
+extern "C" int nwknn_comm_set_option(nwknn_comm_handle c, const char* name, int64_t value)
+{
+    if (!c) return cfail(NWKNN_EINVAL, "null communicator");
+    for (DevPart& p : c->dev) {
+        const int rc = nwknn_set_option(p.h, name, value);
+        if (rc != NWKNN_OK) return rc;
+    }
+    return NWKNN_OK;
+}
+
+static int check_shards(nwknn_comm* c, int64_t rows, int32_t d, const char* what)
+{
+    if (!c) return cfail(NWKNN_EINVAL, "%s: null communicator", what);
+    if (rows <= 0 || d <= 0) return cfail(NWKNN_EINVAL, "%s: rows=%lld d=%d must be positive", what, (long long)rows, d);
+    if (rows < (int64_t)c->dev.size()) return cfail(NWKNN_EINVAL, "%s: %lld base rows cannot be sharded over %zu devices", what, (long long)rows, c->dev.size());
+    const int n = (int)c->dev.size();
+    for (int g = 0; g < n; ++g) shard_bounds(rows, n, g, &c->dev[g].row_lo, &c->dev[g].row_hi);
+    c->rows = rows; c->d = d;
+    return NWKNN_OK;
+}
+
+extern "C" int nwknn_comm_set_base(nwknn_comm_handle c, const void* base_host, int64_t rows, int32_t d, int dtype)
+{
+    if (!base_host) return cfail(NWKNN_EINVAL, "nwknn_comm_set_base: null base");
+    if (dtype != NWKNN_DTYPE_F32 && dtype != NWKNN_DTYPE_F16) return cfail(NWKNN_EINVAL, "nwknn_comm_set_base: unsupported dtype %d", dtype);
+    const int rc = check_shards(c, rows, d, "nwknn_comm_set_base");
+    if (rc != NWKNN_OK) return rc;
+    const size_t es = dtype == NWKNN_DTYPE_F16 ? 2 : 4;
+    return on_every_device(c, [&](int g) {
+        DevPart& p = c->dev[g];
+        return nwknn_set_base(p.h, (const char*)base_host + (size_t)p.row_lo * d * es, p.row_hi - p.row_lo, d, dtype, NWKNN_HOST);
+    });
+}
+
+extern "C" int nwknn_comm_generate_base(nwknn_comm_handle c, uint64_t seed, int64_t rows, int32_t d, int dtype)
+{
+    if (dtype != NWKNN_DTYPE_F32 && dtype != NWKNN_DTYPE_F16) return cfail(NWKNN_EINVAL, "nwknn_comm_generate_base: unsupported dtype %d", dtype);
+    const int rc = check_shards(c, rows, d, "nwknn_comm_generate_base");
+    if (rc != NWKNN_OK) return rc;
+    const size_t es = dtype == NWKNN_DTYPE_F16 ? 2 : 4;
+    return on_every_device(c, [&](int g) -> int {
+        DevPart& p = c->dev[g];
+        CHIP(hipSetDevice(p.device));
+        void* raw = nullptr;
+        CHIP(hipMalloc(&raw, (size_t)(p.row_hi - p.row_lo) * d * es));
+        int r = nwknn_generate(p.h, seed, p.row_lo, p.row_hi - p.row_lo, d, dtype, raw);      // rows of the GLOBAL numbering: shard g holds [lo, hi)
+        if (r == NWKNN_OK) r = nwknn_set_base(p.h, raw, p.row_hi - p.row_lo, d, dtype, NWKNN_DEVICE);
+        if (r == NWKNN_OK) r = nwknn_synchronize(p.h);
+        (void)hipFree(raw);
+        return r;
+    });
+}
+
+// device g: the k best of its query slice over the N gathered lists.  One merge sorts at most 4096 (list, rank) entries per query in
+// LDS; more (8 shards x k = 1000) are folded in groups of lists first, which gives the same k smallest.
+static int merge_slice(nwknn_comm* c, DevPart& p, int n, long long nq, int k, long long qlo, long long qn)
+{
+    if (qn <= 0) return NWKNN_OK;
+    const long long stride = nq * k;                                  // entries between two gathered lists
+    const float* src_d = p.all_d + qlo * k;
+    const long long* src_i = p.all_i + qlo * k;
+    if ((long long)n * k <= 4096) {
+        hipError_t e = nwk_launch_merge(p.stream, src_d, src_i, n, stride, qn, k, k, p.out_d, p.out_i);
+        if (e != hipSuccess) return cfail(NWKNN_EHIP, "merge launch failed: %s", hipGetErrorString(e));
+        return NWKNN_OK;
+    }
+    const int per = std::max(1, 4096 / k), groups = (n + per - 1) / per;
+    if ((long long)groups * k > 4096) return cfail(NWKNN_EINVAL, "nwknn_search_sharded: %d devices x k=%d exceeds the two-level merge", n, k);
+    for (int gidx = 0; gidx < groups; ++gidx) {
+        const int l0 = gidx * per, ln = std::min(per, n - l0);
+        hipError_t e = nwk_launch_merge(p.stream, src_d + (long long)l0 * stride, src_i + (long long)l0 * stride, ln, stride, qn, k, k,
+                                        p.grp_d + (long long)gidx * qn * k, p.grp_i + (long long)gidx * qn * k);
+        if (e != hipSuccess) return cfail(NWKNN_EHIP, "merge launch failed: %s", hipGetErrorString(e));
+    }
+    hipError_t e = nwk_launch_merge(p.stream, p.grp_d, p.grp_i, groups, qn * k, qn, k, k, p.out_d, p.out_i);
+    if (e != hipSuccess) return cfail(NWKNN_EHIP, "merge launch failed: %s", hipGetErrorString(e));
+    return NWKNN_OK;
+}
+
+extern "C" int nwknn_search_sharded(nwknn_comm_handle c, const void* queries_host, int64_t nq, int dtype, int32_t k, int metric, float* out_dist,
+                                    int64_t* out_idx)
+{
+    if (!c || !queries_host || !out_dist || !out_idx) return cfail(NWKNN_EINVAL, "nwknn_search_sharded: null argument");
+    if (c->rows <= 0) return cfail(NWKNN_ESTATE, "nwknn_search_sharded: call nwknn_comm_set_base / nwknn_comm_generate_base first");
+    if (nq <= 0) return cfail(NWKNN_EINVAL, "nwknn_search_sharded: nq must be positive");
+    const int n = (int)c->dev.size();
+    for (const DevPart& p : c->dev)
+        if (k <= 0 || k > p.row_hi - p.row_lo)
+            return cfail(NWKNN_EINVAL, "nwknn_search_sharded: k=%d must satisfy 0 < k <= %lld rows of the smallest shard (cu_knn.py:177-178,237)", k,
+                         (long long)(p.row_hi - p.row_lo));
+    const size_t qk = (size_t)nq * k;
+    // buffers
+    for (int g = 0; g < n; ++g) {
+        DevPart& p = c->dev[g];
+        CHIP(hipSetDevice(p.device));
+        long long qlo, qhi;
+        shard_bounds(nq, n, g, &qlo, &qhi);
+        const size_t slice = (size_t)(qhi - qlo) * k + 1;
+        int rc;
+        if ((rc = p.b_part_d.ensure(qk * 4)) || (rc = p.b_part_i.ensure(qk * 8)) || (rc = p.b_all_d.ensure(qk * n * 4)) ||
+            (rc = p.b_all_i.ensure(qk * n * 8)) || (rc = p.b_out_d.ensure(slice * 4)) || (rc = p.b_out_i.ensure(slice * 8)))
+            return rc;
+        if ((long long)n * k > 4096) {
+            const int per = std::max(1, 4096 / k);
+            const size_t grp = slice * (size_t)((n + per - 1) / per);
+            if ((rc = p.b_grp_d.ensure(grp * 4)) || (rc = p.b_grp_i.ensure(grp * 8))) return rc;
+        }
+        p.part_d = (float*)p.b_part_d.p; p.part_i = (long long*)p.b_part_i.p;
+        p.all_d = (float*)p.b_all_d.p; p.all_i = (long long*)p.b_all_i.p;
+        p.grp_d = (float*)p.b_grp_d.p; p.grp_i = (long long*)p.b_grp_i.p;
+        p.out_d = (float*)p.b_out_d.p; p.out_i = (long long*)p.b_out_i.p;
+    }
+    // 1. every device searches its shard; ids are global (index_offset = first row of the shard: "+ batch_offset", cu_knn.py:273)
+    int rc = on_every_device(c, [&](int g) {
+        DevPart& p = c->dev[g];
+        return nwknn_search(p.h, queries_host, nq, dtype, NWKNN_HOST, k, metric, p.row_lo, p.part_d, (int64_t*)p.part_i, NWKNN_DEVICE);
+    });
+    if (rc != NWKNN_OK) return rc;
+    // 2. one all-gather per array over RCCL (xGMI): every device ends up with the N partial lists, in device order == row order
+    for (int g = 0; g < n; ++g) { CHIP(hipSetDevice(c->dev[g].device)); CHIP(hipEventRecord(c->dev[g].ev0, c->dev[g].stream)); }
+    CNCCL(c, c->rccl.GroupStart());
+    for (int g = 0; g < n; ++g) {
+        DevPart& p = c->dev[g];
+        CNCCL(c, c->rccl.AllGather(p.part_d, p.all_d, qk, ncclFloat32, p.comm, p.stream));
+        CNCCL(c, c->rccl.AllGather(p.part_i, p.all_i, qk, ncclInt64, p.comm, p.stream));
+    }
+    CNCCL(c, c->rccl.GroupEnd());
+    // 3. device g merges its slice of the query rows and hands it to the caller
+    for (int g = 0; g < n; ++g) {
+        DevPart& p = c->dev[g];
+        CHIP(hipSetDevice(p.device));
+        CHIP(hipEventRecord(p.ev1, p.stream));
+        long long qlo, qhi;
+        shard_bounds(nq, n, g, &qlo, &qhi);
+        rc = merge_slice(c, p, n, nq, k, qlo, qhi - qlo);
+        if (rc != NWKNN_OK) return rc;
+        CHIP(hipEventRecord(p.ev2, p.stream));
+        if (qhi > qlo) {
+            CHIP(hipMemcpyAsync(out_dist + qlo * k, p.out_d, (size_t)(qhi - qlo) * k * 4, hipMemcpyDeviceToHost, p.stream));
+            CHIP(hipMemcpyAsync(out_idx + qlo * k, p.out_i, (size_t)(qhi - qlo) * k * 8, hipMemcpyDeviceToHost, p.stream));
+        }
+    }
+    double ag = 0.0, mg = 0.0, sr = 0.0, flops = 0.0, tile = 0.0;
+    for (int g = 0; g < n; ++g) {
+        DevPart& p = c->dev[g];
+        CHIP(hipSetDevice(p.device));
+        CHIP(hipStreamSynchronize(p.stream));
+        float a = 0.f, m = 0.f;
+        CHIP(hipEventElapsedTime(&a, p.ev0, p.ev1));
+        CHIP(hipEventElapsedTime(&m, p.ev1, p.ev2));
+        ag = std::max(ag, (double)a); mg = std::max(mg, (double)m);
+        nwknn_stats st;
+        if (nwknn_get_stats(p.h, &st) == NWKNN_OK) { sr = std::max(sr, st.total_ms); flops += st.tile_flops; tile += st.tile_ms; }
+    }
+    c->stats.n_devices = n; c->stats.nq = nq; c->stats.k = k;
+    c->stats.search_ms = sr; c->stats.allgather_ms = ag; c->stats.merge_ms = mg;
+    c->stats.allgather_bytes_per_device = (double)qk * 12.0 * n;
+    c->stats.tile_flops = flops; c->stats.tile_ms = tile;
+    return NWKNN_OK;
+}
+
+extern "C" int nwknn_comm_get_stats(nwknn_comm_handle c, nwknn_comm_stats* out)
+{
+    if (!c || !out) return cfail(NWKNN_EINVAL, "null communicator or output");
+    *out = c->stats;
+    return NWKNN_OK;
+}

@@ -123,5 +123,6 @@ hipError_t nwk_launch_maxsim_pre(hipStream_t st, NwkTileParams p);
 hipError_t nwk_launch_maxsim_bounds(hipStream_t st, const float* norms, long long n_items, int tokens, float eps_half, float a_self, float cst,
                                     int is_doc, float* out);
 hipError_t nwk_launch_maxsim_rescore(hipStream_t st, NwkMsRescoreParams p, long long nq_pad, int slices);
-hipError_t nwk_launch_merge(hipStream_t st, const float* dists, const long long* idx, int n_lists, long long nq, int k_in, int k_out,
-                            float* out_d, long long* out_i);
+hipError_t nwk_launch_merge(hipStream_t st, const float* dists, const long long* idx, int n_lists, long long list_stride, long long nq, int k_in,
+                            int k_out, float* out_d, long long* out_i);
+int nwknn_internal_fail(int code, const char* msg);        // sets the calling thread's nwknn_last_error() message, returns code

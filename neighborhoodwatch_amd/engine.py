@@ -347,6 +347,83 @@ class KnnEngine:
         return out
 
 
+class ShardedKnnEngine:
+    """One process, N GPUs of one node (the C ABI's nwknn_comm_*): the base rows are sharded contiguously over ``devices``, queries are
+    replicated, every GPU searches its shard with global row ids, ONE RCCL all-gather moves the [Q,k] partial lists over xGMI and GPU g
+    merges its slice of the query rows by (distance, index).  The reference is pinned to GPU 0 (cu_knn.py:65); with one device this
+    is ``KnnEngine`` (the exchange is a copy).  Inputs and outputs are host numpy arrays."""
+
+    def __init__(self, devices=(0,), profile: bool = False):
+        self._L = _lib.load()
+        self._c = ctypes.c_void_p()
+        devs = [int(x) for x in devices]
+        arr = (ctypes.c_int * len(devs))(*devs)
+        check(self._L.nwknn_comm_create(ctypes.byref(self._c), arr, len(devs)), "nwknn_comm_create")
+        self.devices = devs
+        self.rows = self.dim = 0
+        if profile:
+            self.set_option("profile", 1)
+
+    def close(self) -> None:
+        if getattr(self, "_c", None) is not None and self._c.value:
+            self._L.nwknn_comm_destroy(self._c)
+            self._c = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_option(self, name: str, value: int) -> None:
+        check(self._L.nwknn_comm_set_option(self._c, name.encode(), int(value)), f"nwknn_comm_set_option({name})")
+
+    def set_prescreen(self, on: bool) -> None:
+        self.set_option("prescreen", 1 if on else 0)
+
+    def set_base(self, dataset) -> None:
+        a = np.asarray(dataset)
+        a = np.ascontiguousarray(a, dtype=np.float16 if a.dtype == np.float16 else np.float32)
+        if a.ndim != 2 or a.shape[0] == 0 or a.shape[1] == 0:
+            raise ValueError(f"dataset must be a non-empty 2-D array, got shape {a.shape}")
+        check(self._L.nwknn_comm_set_base(self._c, ctypes.c_void_p(a.ctypes.data), a.shape[0], a.shape[1],
+                                          DTYPE_F16 if a.dtype == np.float16 else DTYPE_F32), "nwknn_comm_set_base")
+        self.rows, self.dim = a.shape
+
+    def generate_base(self, seed: int, rows: int, dim: int, dtype: str = "f32") -> None:
+        check(self._L.nwknn_comm_generate_base(self._c, ctypes.c_uint64(seed), int(rows), int(dim),
+                                               DTYPE_F16 if dtype in ("f16", "fp16") else DTYPE_F32), "nwknn_comm_generate_base")
+        self.rows, self.dim = int(rows), int(dim)
+
+    def search(self, queries, k: int, metric: str = "sqeuclidean"):
+        metric = resolve_metric(metric)
+        q = np.asarray(queries)
+        q = np.ascontiguousarray(q, dtype=np.float16 if q.dtype == np.float16 else np.float32)
+        if q.ndim != 2 or q.shape[0] == 0:
+            raise ValueError("queries must be a non-empty 2-D array")
+        if self.rows == 0:
+            raise _lib.NwknnError("search before set_base")
+        if q.shape[1] != self.dim:
+            raise ValueError(f"queries have dimension {q.shape[1]}, dataset has {self.dim}")
+        od = np.empty((q.shape[0], k), dtype=np.float32)
+        oi = np.empty((q.shape[0], k), dtype=np.int64)
+        check(self._L.nwknn_search_sharded(self._c, ctypes.c_void_p(q.ctypes.data), q.shape[0], DTYPE_F16 if q.dtype == np.float16 else DTYPE_F32,
+                                           int(k), METRIC_IDS[metric], ctypes.c_void_p(od.ctypes.data), ctypes.c_void_p(oi.ctypes.data)),
+              "nwknn_search_sharded")
+        return od, oi
+
+    def stats(self) -> dict:
+        s = _lib.NwknnCommStats()
+        check(self._L.nwknn_comm_get_stats(self._c, ctypes.byref(s)), "nwknn_comm_get_stats")
+        return s.as_dict()
+
+
 _default_engines: dict = {}
 
 

@@ -43,6 +43,30 @@ def test_stats_struct_matches_header():
     assert fields == [n for n, _ in NwknnStats._fields_]
 
 
+def test_comm_stats_layout_and_argument_errors(tmp_path):
+    """The multi-GPU entry points: struct layout as gcc sees the header == the ctypes mirror; bad arguments are refused before any
+    device or RCCL is touched."""
+    import subprocess
+    from neighborhoodwatch_amd import _lib
+    from neighborhoodwatch_amd._lib import NwknnCommStats
+    fields = [name for name, _ in NwknnCommStats._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "nwknn.h"\nint main(void){printf("%zu", sizeof(nwknn_comm_stats));'
+                   + "".join(f'printf(" %zu", offsetof(nwknn_comm_stats, {f}));' for f in fields) + 'return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == ctypes.sizeof(NwknnCommStats) and out[1:] == [getattr(NwknnCommStats, f).offset for f in fields]
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    assert L.nwknn_comm_create(ctypes.byref(h), None, 1) == -1 and b"null" in L.nwknn_last_error()
+    two = (ctypes.c_int * 2)(0, 0)
+    assert L.nwknn_comm_create(ctypes.byref(h), two, 2) == -1 and b"listed twice" in L.nwknn_last_error()
+    assert L.nwknn_comm_create(ctypes.byref(h), two, 0) == -1
+    assert L.nwknn_search_sharded(None, None, 1, 0, 1, 0, None, None) == -1
+    assert L.nwknn_comm_destroy(None) == 0 and L.nwknn_comm_device_count(None) == 0
+
+
 def test_argument_errors_do_not_need_a_gpu():
     from neighborhoodwatch_amd import _lib
     L = _lib.load()

@@ -400,3 +400,41 @@ def test_very_many_queries_split_a_chunk_into_several_launches(prescreen):
         d_a, i_a = eng.search(q[:300_000], 10)
         d_b, i_b = eng.search(q[300_000:], 10)
     assert torch.equal(i_all, torch.cat([i_a, i_b])) and torch.equal(d_all, torch.cat([d_a, d_b]))
+
+
+@pytest.mark.parametrize("prescreen", [False, True])
+def test_c_abi_collective_on_one_device_equals_the_plain_search(oracle, prescreen):
+    """nwknn_comm_* with one device: RCCL is loaded, ncclCommInitAll / ncclAllGather / the sliced merge all run (the exchange is a copy),
+    and the result is nwknn_search's, i.e. the oracle's bits; the accounting says what moved.  (N > 1 needs N GPUs: RCCL refuses a
+    device listed twice, and so does nwknn_comm_create.)"""
+    from neighborhoodwatch_amd import KnnEngine, ShardedKnnEngine
+    base, queries = oracle.gen(0xAB1, 0, 5003, 72), oracle.gen(0xAB2, 0, 131, 72)
+    rd, ri = oracle.knn_canonical(base, queries, 33, "one_minus_dot")
+    with ShardedKnnEngine([0], profile=True) as se:
+        se.set_prescreen(prescreen)
+        se.set_base(base)
+        d, i = se.search(queries, 33, "one_minus_dot")
+        st = se.stats()
+        assert np.array_equal(i, ri) and _same_bits(d, rd)
+        assert st["n_devices"] == 1 and st["nq"] == 131 and st["k"] == 33 and st["allgather_bytes_per_device"] == 131 * 33 * 12
+        assert st["allgather_ms"] > 0.0 and st["merge_ms"] > 0.0 and st["search_ms"] > 0.0 and st["tile_flops"] > 0.0
+        with pytest.raises(ValueError, match="smallest shard"):
+            se.search(queries, 6000)
+        se.generate_base(oracle.SEED_BASE, 4000, 40)               # synthetic shard rows generated on the device, global numbering
+        q2 = oracle.gen(oracle.SEED_QUERY, 0, 50, 40)
+        d2, i2 = se.search(q2, 10)
+    r2d, r2i = oracle.knn_canonical(oracle.gen(oracle.SEED_BASE, 0, 4000, 40), q2, 10)
+    assert np.array_equal(i2, r2i) and _same_bits(d2, r2d)
+    with KnnEngine(0) as eng:
+        eng.set_prescreen(prescreen)
+        eng.set_base(base)
+        d1, i1 = eng.search(queries, 33, "one_minus_dot")
+    assert np.array_equal(i, i1) and _same_bits(d, d1)
+
+
+def test_c_abi_collective_refuses_bad_device_lists():
+    from neighborhoodwatch_amd import ShardedKnnEngine
+    with pytest.raises(ValueError, match="listed twice"):
+        ShardedKnnEngine([0, 0])
+    with pytest.raises((ValueError, RuntimeError)):
+        ShardedKnnEngine([0, 99])
