@@ -41,6 +41,13 @@
 #include "nwk_f16_common.h"
 
 #define X_BN_BUFS 4                   // column-norm buffers (tile & 3)
+// build-time variants (tools/mk_variant_lib.sh), defaults = what measured fastest
+#ifndef X_PRIO
+#define X_PRIO 1                      // 1: a wave raises its priority for its COMPUTE phase (s_setprio), so its MFMAs win the issue arbitration
+#endif                                //    against the partner's LOAD-phase instructions whichever of the two is the older wave
+#ifndef X_READS_FIRST
+#define X_READS_FIRST 1               // 1: a LOAD phase issues its fragment reads before its LDS-DMA (the reads' latency runs under the DMA
+#endif                                //    issue stalls); 0: DMA first
 
 template <int METRIC, int PRE>
 __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTileParams p)
@@ -135,6 +142,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
     auto compute = [&](auto first_tag) {                          // 64 MFMAs on registers; FIRST: the tile's first slab starts from a zero C
         constexpr bool FIRST = decltype(first_tag)::value;
         const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (X_PRIO) __builtin_amdgcn_s_setprio(2);
         if (diag & 4) {
             if (FIRST) {
 #pragma unroll
@@ -151,6 +159,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ks][m], fb[ks][n], (FIRST && ks == 0) ? zero : acc[m][n], 0, 0, 0);
+        if (X_PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- epilogue of tile t (this wave's 128 x 64 part) ------------------------------------------------------------------------
@@ -235,16 +244,21 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
             // ---- first slab of tile t: LOAD (+ the previous tile's epilogue), COMPUTE from a zero C ------------------------------------
             {
                 const int st = sigma & 1;
-                if (sigma + 1 < S && !(diag & 2)) {                 // wave-uniform: slab sigma + 1 is (t, 1) or, when nk == 1, (t + 1, 0)
-                    const int t2 = nk > 1 ? t : t + 1, k2 = nk > 1 ? 1 : 0;
-                    issue_A(1, st ^ 1, k2); issue_B(st ^ 1, t2, k2); issue_N(t2);
-                }
+                auto dma = [&]() {
+                    if (sigma + 1 < S && !(diag & 2)) {             // wave-uniform: slab sigma + 1 is (t, 1) or, when nk == 1, (t + 1, 0)
+                        const int t2 = nk > 1 ? t : t + 1, k2 = nk > 1 ? 1 : 0;
+                        issue_A(1, st ^ 1, k2); issue_B(st ^ 1, t2, k2); issue_N(t2);
+                    }
+                };
+                if (!X_READS_FIRST) dma();
                 X_STAMP(0);
                 X_FENCE();
                 if (t > 0) epilogue(t - 1);
                 X_STAMP(1);
                 X_FENCE();
                 read_frags(st);
+                X_FENCE();
+                if (X_READS_FIRST) dma();
                 X_BARRIER("s_waitcnt lgkmcnt(0)", 2, 3);
                 compute(std::true_type{});
                 X_STAMP(4);
@@ -253,14 +267,19 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
             }
             for (int kt = 1; kt < nk; ++kt) {
                 const int st = sigma & 1;
-                if (sigma + 1 < S && !(diag & 2)) {
-                    const bool wrap = kt + 1 == nk;
-                    const int t2 = wrap ? t + 1 : t, k2 = wrap ? 0 : kt + 1;
-                    issue_A(1, st ^ 1, k2); issue_B(st ^ 1, t2, k2); issue_N(t2);
-                }
+                auto dma = [&]() {
+                    if (sigma + 1 < S && !(diag & 2)) {
+                        const bool wrap = kt + 1 == nk;
+                        const int t2 = wrap ? t + 1 : t, k2 = wrap ? 0 : kt + 1;
+                        issue_A(1, st ^ 1, k2); issue_B(st ^ 1, t2, k2); issue_N(t2);
+                    }
+                };
+                if (!X_READS_FIRST) dma();
                 X_STAMP(0);
                 X_FENCE();
                 read_frags(st);
+                X_FENCE();
+                if (X_READS_FIRST) dma();
                 X_BARRIER("s_waitcnt lgkmcnt(0)", 2, 3);
                 compute(std::false_type{});
                 X_STAMP(4);
@@ -282,14 +301,19 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
         for (int t = 0; t < n_here; ++t) {
             {
                 const int st = sigma & 1;
-                if (!(diag & 2)) issue_A(0, st, sigma + 2 < S ? k2 : nk - 1);        // past the end of the strip: the last slab again (never read)
-                next_k2();
+                auto dma = [&]() {
+                    if (!(diag & 2)) issue_A(0, st, sigma + 2 < S ? k2 : nk - 1);    // past the end of the strip: the last slab again (never read)
+                    next_k2();
+                };
+                if (!X_READS_FIRST) dma();
                 X_STAMP(0);
                 X_FENCE();
                 if (t > 0) epilogue(t - 1);
                 X_STAMP(1);
                 X_FENCE();
                 read_frags(st);
+                X_FENCE();
+                if (X_READS_FIRST) dma();
                 if (diag & 2) X_BARRIER("s_waitcnt vmcnt(0) lgkmcnt(0)", 2, 3); else X_BARRIER("s_waitcnt vmcnt(4) lgkmcnt(0)", 2, 3);
                 compute(std::true_type{});
                 X_STAMP(4);
@@ -298,11 +322,16 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
             }
             for (int kt = 1; kt < nk; ++kt) {
                 const int st = sigma & 1;
-                if (!(diag & 2)) issue_A(0, st, sigma + 2 < S ? k2 : nk - 1);
-                next_k2();
+                auto dma = [&]() {
+                    if (!(diag & 2)) issue_A(0, st, sigma + 2 < S ? k2 : nk - 1);
+                    next_k2();
+                };
+                if (!X_READS_FIRST) dma();
                 X_STAMP(0);
                 X_FENCE();
                 read_frags(st);
+                X_FENCE();
+                if (X_READS_FIRST) dma();
                 if (diag & 2) X_BARRIER("s_waitcnt vmcnt(0) lgkmcnt(0)", 2, 3); else X_BARRIER("s_waitcnt vmcnt(4) lgkmcnt(0)", 2, 3);
                 compute(std::false_type{});
                 X_STAMP(4);

@@ -126,7 +126,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 4, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 0, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -302,8 +302,8 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
     } else if (!strcmp(name, "f16_exact")) {
         h->opt_f16_exact = value ? 1 : 0;   // fp16 compute path: 1 (default) rescoring to the canonical fp32 chain over the fp16 values, 0 raw MFMA sums
     } else if (!strcmp(name, "f16_strip")) {
-        if (value < 1 || value > 64) return fail(NWKNN_EINVAL, "f16_strip must be 1..64");
-        h->opt_f16_strip = value;           // base tiles a workgroup of the 16x16x32 fp16 kernel walks in a row (default 4)
+        if (value < 0 || value > 64) return fail(NWKNN_EINVAL, "f16_strip must be 0 (auto) or 1..64");
+        h->opt_f16_strip = value;           // base tiles a workgroup of the fp16 kernels walks in a row (auto: 2 for the ping-pong form, 4 for the others)
     } else if (!strcmp(name, "chunk_growth")) {
         if (value < 0 || value > 7) return fail(NWKNN_EINVAL, "chunk_growth must be 0 (auto) or 1..7");
         h->opt_chunk_growth = value;        // a filtered chunk holds up to chunk_growth x the rows seen so far (1: chunks double)
@@ -722,11 +722,15 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
 {
     NwkTileParams tp = tile_params(h, pl, nq_pad);
     const bool prescreen = pl.pre && (!dense || pl.native16);   // fp32 data: the dense first chunk runs the fp32 kernel
-    // fp16 kernel build.  Auto: the streaming form up to 2048 halves per row (+0..4 % over the burst form, it gains at tile
-    // boundaries), the burst form (one barrier per slab) beyond, where the K loop is everything and four barriers per slab cost 1.6 %
+    // fp16 kernel build.  Auto (round 3, same-box A/B on 32k x 2-4M, tools/f16_forms.py): the ping-pong form from 1024 halves per row
+    // on (d = 1024: +3.7 % over the streaming form at its best strip length, +5.5 % over round 2's default; 1536 fp16 input: +4.2 %;
+    // 2048: +6.3 % / +1.0 % over streaming / burst; 4096: +8.3 % / +3.4 %), the streaming form below (d = 768: equal; 384: the
+    // ping-pong form is 6 % behind, 128: 19 % -- its tile boundaries cost two phases); dense chunks run the burst form (the launcher
+    // sees to that).  Strips: 2 tiles for the ping-pong form (1-3: equal within noise; 4: -2.5 %, 16: -5 %), 4 for the others.
     const int row_halves = (prescreen && pl.copies16) ? h->dp16 : h->dp;
-    const int f16_shape = h->opt_f16_shape >= 0 ? (int)h->opt_f16_shape : (row_halves <= 2048 ? 3 : 1);
+    const int f16_shape = h->opt_f16_shape >= 0 ? (int)h->opt_f16_shape : (row_halves >= 1024 ? 4 : 3);
     tp.f16_shape = f16_shape;
+    tp.tiles_per_wg = h->opt_f16_strip > 0 ? (int)h->opt_f16_strip : (f16_shape == 4 ? 2 : 4);
     // super-tile shape and walk order (see tile_from_block).  Auto = the fastest setting measured, base tile index fastest in both:
     // fp32 kernel 8 x 8 (same-box A/B on C3: 0.27 % faster than 2 x 32 / query fastest, which moves 38 % fewer bytes over the
     // fabric); fp16 kernels 16 x 4 (C3 pre-screen tile kernel: +1.4 % over 8 x 8, +0.7 % over 32 x 2; 4 x 16 / query fastest moves

@@ -7,7 +7,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 from neighborhoodwatch_amd import KnnEngine
 
-forms = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "3 4").split()]
+forms = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "3 4").replace(",", " ").split()]
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 2_000_000
 Q = int(sys.argv[4]) if len(sys.argv) > 4 else 32_768
