@@ -163,14 +163,16 @@ extern "C" int nwknn_comm_destroy(nwknn_comm_handle c)
 {
     if (!c) return NWKNN_OK;
     for (DevPart& p : c->dev) {
-        if (p.device >= 0) (void)hipSetDevice(p.device);
+        if (!p.h) continue;                                   // never created (nwknn_create refused the device): nothing to release
+        (void)hipSetDevice(p.device);
         if (p.stream) (void)hipStreamSynchronize(p.stream);
         if (p.comm && c->rccl.CommDestroy) (void)c->rccl.CommDestroy(p.comm);
         for (DBuf* b : {&p.b_part_d, &p.b_part_i, &p.b_all_d, &p.b_all_i, &p.b_grp_d, &p.b_grp_i, &p.b_out_d, &p.b_out_i}) b->release();
         for (hipEvent_t e : {p.ev0, p.ev1, p.ev2}) if (e) (void)hipEventDestroy(e);
         if (p.stream) (void)hipStreamDestroy(p.stream);
-        if (p.h) (void)nwknn_destroy(p.h);
+        (void)nwknn_destroy(p.h);
     }
+    (void)hipGetLastError();                                  // HIP's last-error slot is sticky: leave none behind for the next launch check
     delete c;
     return NWKNN_OK;
 }
@@ -191,9 +193,9 @@ extern "C" int nwknn_comm_create(nwknn_comm_handle* out, const int* devices, int
     auto fail_with = [&](int code) { (void)nwknn_comm_destroy(c); return code; };
     for (int g = 0; g < n_dev; ++g) {
         DevPart& p = c->dev[g];
+        rc = nwknn_create(&p.h, devices[g]);                  // checks the ordinal and that the device is a gfx950
+        if (rc != NWKNN_OK) { p.h = nullptr; return fail_with(rc); }
         p.device = devices[g];
-        rc = nwknn_create(&p.h, devices[g]);                  // checks the device is a gfx950
-        if (rc != NWKNN_OK) return fail_with(rc);
         if (hipSetDevice(devices[g]) != hipSuccess || hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreate(&p.ev0) != hipSuccess || hipEventCreate(&p.ev1) != hipSuccess || hipEventCreate(&p.ev2) != hipSuccess)
             return fail_with(cfail(NWKNN_EHIP, "nwknn_comm_create: stream / event creation failed on device %d", devices[g]));

@@ -90,6 +90,46 @@ def get_embedding_count(table):
     return sum(1 for name in table.schema.names if name.startswith("embedding_"))
 
 
+def list_embedding_field(schema, prefix: str = "embedding_"):
+    """The single ``FixedSizeList<float, d>`` embedding column of a schema (named like the per-dimension columns without the
+    index: ``embedding`` / ``token_embedding``), or None.  SURVEY N2's optional layout: the values buffer of such a column IS the
+    row-major [rows, d] matrix, so nothing has to be gathered from d columns."""
+    name = prefix.rstrip("_")
+    if name in schema.names:
+        t = schema.field(name).type
+        if pa.types.is_fixed_size_list(t) and pa.types.is_floating(t.value_type):
+            return schema.field(name)
+    return None
+
+
+def float_row_bytes(fields) -> int:
+    """Bytes one row of the float columns occupies (the footprint tune_memory reasons about): scalar float columns plus
+    FixedSizeList<float, d> columns."""
+    total = 0
+    for f in fields:
+        if pa.types.is_floating(f.type):
+            total += f.type.bit_width // 8
+        elif pa.types.is_fixed_size_list(f.type) and pa.types.is_floating(f.type.value_type):
+            total += f.type.list_size * (f.type.value_type.bit_width // 8)
+    return total or 4
+
+
+def table_list_matrix(table, field) -> np.ndarray:
+    """Row-major float [rows, d] view of a FixedSizeList column: zero-copy for a one-chunk table, one concatenation otherwise."""
+    d = field.type.list_size
+    parts = []
+    for ch in table.column(field.name).chunks:
+        if len(ch) == 0:
+            continue
+        if ch.null_count:
+            raise ValueError(f"column {field.name!r} holds null embeddings")
+        flat = ch.flatten().to_numpy(zero_copy_only=False)        # the chunk's own rows only (offset-aware)
+        parts.append(flat.reshape(len(ch), d))
+    if not parts:
+        return np.empty((0, d), dtype=np.float32)
+    return parts[0] if len(parts) == 1 else np.concatenate(parts)
+
+
 def prep_table(data_dir, model_name, filename, count, dimension, lazy: bool = False):
     """Load, slice to ``count`` rows, check the number of embedding_* columns, keep only those (cu_knn.py:132-148).
     ``lazy=True`` (how compute_knn opens the BASE file) reads the file's metadata only and returns a ``ParquetRows`` window with the
@@ -99,10 +139,11 @@ def prep_table(data_dir, model_name, filename, count, dimension, lazy: bool = Fa
         table = ParquetRows(get_full_filename(data_dir, filename), count)
     else:
         table = load_table(data_dir, filename, 0, count)
-    total_dimensions = sum("embedding_" in c for c in table.column_names)
+    lst = list_embedding_field(table.schema)
+    total_dimensions = lst.type.list_size if lst is not None else sum("embedding_" in c for c in table.column_names)
     assert output_dimension_validity_check(model_name, dimension, total_dimensions), \
         f"Expected {dimension} values, got {total_dimensions} for model {model_name} [filename: {filename}]"
-    keep = [f"embedding_{i}" for i in range(total_dimensions)]
+    keep = [lst.name] if lst is not None else [f"embedding_{i}" for i in range(total_dimensions)]
     if lazy:
         return table.select([name for name in table.column_names if name in set(keep)])
     return drop_columns(table, keep)
@@ -120,6 +161,27 @@ def table_to_matrix(table) -> np.ndarray:
         cols = [table.column(f.name).to_numpy() for f in fields[j0:j0 + block]]
         out[:, j0:j0 + len(cols)] = np.stack(cols, axis=1)
     return out
+
+
+def table_input(table):
+    """What the engine is handed for an arrow table: ``("matrix", row-major [rows, d] array)`` for the FixedSizeList layout,
+    ``("columns", per-dimension views)`` (table_columns) for the reference's one-column-per-dimension layout."""
+    lst = list_embedding_field(table.schema) or list_embedding_field(table.schema, "token_embedding_")
+    if lst is not None:
+        return "matrix", table_list_matrix(table, lst)
+    return "columns", table_columns(table)
+
+
+def engine_set_base(eng, kind_data):
+    kind, data = kind_data
+    eng.set_base(data) if kind == "matrix" else eng.set_base_columns(data)
+
+
+def engine_search(eng, kind_data, k, metric, index_offset=0, out_device=False):
+    kind, data = kind_data
+    if kind == "matrix":
+        return eng.search(data, k, metric, index_offset=index_offset, out_device=out_device)
+    return eng.search_columns(data, k, metric, index_offset=index_offset, out_device=out_device)
 
 
 def table_columns(table):
@@ -156,7 +218,7 @@ def tune_memory(table, batch_size, max_memory_threshold, rmm=None, device: int =
     print(f"Tuning memory settings (num rows: {num_rows}; initial batch size: {batch_size}) ...")
     _, total_gpu_memory = mem_info(device)
     print("-- total memory:", total_gpu_memory)
-    row_bytes = sum(f.type.bit_width // 8 for f in table.schema if pa.types.is_floating(f.type)) or 4
+    row_bytes = float_row_bytes(table.schema)
     memory_used = min(batch_size, num_rows) * row_bytes
     print(f"-- memory_used {memory_used}")
     factor = math.ceil((total_gpu_memory * .2) / memory_used)
@@ -268,7 +330,7 @@ def process_batches(data_dir,
     """One partial (distances, indices) parquet pair per base tile (cu_knn.py:193-287)."""
     metric = resolve_metric(metric, engine)
     devices = list(devices) if devices else [device]
-    queries = table_columns(query_table)                        # zero-copy views of the arrow columns
+    queries = table_input(query_table)                          # zero-copy views of the arrow columns (or of the one list column)
 
     def run_tiles(slot: int):
         # tiles slot, slot+n, slot+2n, ... on GPU devices[slot]; engines are per (device, slot) so that two slots may share a device
@@ -287,7 +349,7 @@ def process_batches(data_dir,
                     print(f"-- base tile {start}: partial files of the same metric/dtype/tile present, skipped")
                     continue
                 tile = base_table.slice(batch_offset, batch_length)
-                yield start, batch_offset, batch_length, tag, table_columns(tile), tile
+                yield start, batch_offset, batch_length, tag, table_input(tile), tile
 
         def write_pair(start, distances, indices, tag):
             stream_cudf_to_parquet(get_partial_distances_filename(data_dir, start), distances, PARQUET_ROW_GROUP, tag)
@@ -298,9 +360,10 @@ def process_batches(data_dir,
             with Prefetch(tiles, slots=2) as feed, ThreadPoolExecutor(max_workers=1) as writer:      # the pair of tile i is written while tile i+1 is searched
                 for start, batch_offset, batch_length, tag, dataset, tile in feed:
                     assert (k <= batch_length)                              # cu_knn.py:237
-                    print(f"Dataset shape: ({batch_length}, {len(dataset)}), Query shape: ({len(query_table)}, {len(queries)})")
-                    eng.set_base_columns(dataset)
-                    distances, indices = eng.search_columns(queries, k, metric, index_offset=batch_offset)   # + batch_offset, cu_knn.py:273
+                    dims = dataset[1].shape[1] if dataset[0] == "matrix" else len(dataset[1])
+                    print(f"Dataset shape: ({batch_length}, {dims}), Query shape: ({len(query_table)}, {dims})")
+                    engine_set_base(eng, dataset)
+                    distances, indices = engine_search(eng, queries, k, metric, index_offset=batch_offset)   # + batch_offset, cu_knn.py:273
                     assert (len(distances) == len(query_table))             # cu_knn.py:281-282
                     assert (len(indices) == len(query_table))
                     writes.append(writer.submit(write_pair, start, distances, indices, tag))

@@ -23,7 +23,8 @@ import pyarrow as pa
 import pyarrow.dataset as ds
 import pyarrow.parquet as pq
 
-from .cu_knn import PARQUET_ROW_GROUP, cleanup, stream_cudf_to_parquet, table_columns
+from .cu_knn import (PARQUET_ROW_GROUP, cleanup, engine_search, engine_set_base, float_row_bytes, list_embedding_field, stream_cudf_to_parquet,
+                     table_columns, table_input)
 from .engine import default_engine, mem_info, resolve_metric
 from .nw_utils import get_full_filename, get_partial_distances_filename, get_partial_indices_filename
 from .parquet_stream import ParquetRows, Prefetch
@@ -59,6 +60,10 @@ def get_dataset_columns(dataset, n):
     only the float columns reach the GPU."""
     names = dataset.schema.names
     cols = [c for c in ("text", "question") if c in names][-1:]
+    lst = list_embedding_field(dataset.schema)
+    if lst is not None:                                           # the one-column FixedSizeList layout (SURVEY N2)
+        assert lst.type.list_size == n, f"Expected {n} values, got {lst.type.list_size}"
+        return cols + [lst.name]
     return cols + [f"embedding_{i}" for i in range(n)]
 
 
@@ -69,7 +74,7 @@ def tune_memory(dataset, batch_size, max_memory_threshold, rmm, column_names, de
     total = get_gpu_memory(device)
     print("-- total memory per GPU:", total)
     fields = [dataset.schema.field(c) for c in column_names if c in dataset.schema.names]
-    row_bytes = sum(f.type.bit_width // 8 for f in fields if pa.types.is_floating(f.type)) or 4
+    row_bytes = float_row_bytes(fields)
     used = min(batch_size, num_rows) * row_bytes
     factor = math.ceil((total * max_memory_threshold) / used)
     print(f"-- batch processing adjustment factor (per GPU): {factor}")
@@ -113,7 +118,7 @@ def compute_knn_ds(data_dir,
 
 
 def _embedding_columns(names):
-    return [c for c in names if c.startswith("embedding_")]
+    return [c for c in names if c.startswith("embedding_") or c == "embedding"]
 
 
 def _as_rows(dataset, column_names) -> ParquetRows:
@@ -190,7 +195,7 @@ def process_dataset_batches(data_dir,
     eng = default_engine(device)
     eng.set_prescreen(prescreen)
     query_table = _as_rows(query_dataset, query_column_names).to_table()
-    queries = table_columns(query_table)
+    queries = table_input(query_table)
     assert len(query_table) == query_count                                        # cu_knn_ds.py:229-230
     base_rows = _as_rows(base_dataset, base_column_names)
     n_base = len(base_rows)
@@ -211,15 +216,15 @@ def process_dataset_batches(data_dir,
         """(first row, rows, column views, arrow table) per base batch, decoded on the reader thread one batch ahead of the GPU."""
         for off in range(start_row, n_base, batch_size):
             t = base_rows.slice(off, batch_size)
-            yield off, len(t), table_columns(t), t
+            yield off, len(t), table_input(t), t
 
     pending_write = None
     try:
         with Prefetch(batches, slots=2) as feed, ThreadPoolExecutor(max_workers=1) as writer:
             for batch_offset, rows, base, table in feed:
                 assert (k <= rows)                                                # cu_knn_ds.py:203
-                eng.set_base_columns(base)
-                d, i = eng.search_columns(queries, k, metric, index_offset=batch_offset, out_device=True)   # + batch_offset, cu_knn_ds.py:216
+                engine_set_base(eng, base)
+                d, i = engine_search(eng, queries, k, metric, index_offset=batch_offset, out_device=True)   # + batch_offset, cu_knn_ds.py:216
                 if run_d is None:
                     run_d, run_i = d, i
                 else:                                                             # fold on the device: [2,Q,k] -> [Q,k]

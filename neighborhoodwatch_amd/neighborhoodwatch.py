@@ -70,6 +70,9 @@ Some example commands:\n
     parser.add_argument('--synthetic-seed', type=lambda s: int(s, 0), default=None,
                         help='seed of the synthetic embeddings written when the source parquet files do not exist')
     parser.add_argument('--normalize', action='store_true', help='synthetic rows are scaled to unit L2 norm')
+    parser.add_argument('--embedding-layout', choices=['columns', 'list'], default='columns',
+                        help="synthetic source files: 'columns' = embedding_0..d-1 (the reference's schema), "
+                             "'list' = one FixedSizeList<float32, d> column 'embedding' (row-major; the kNN stage reads either)")
     parser.add_argument('--engine', choices=['raft', 'cuvs', 'torch'], default='raft',
                         help="distance of the reference engine of that name: sqeuclidean | cosine | 1-dot")
     parser.add_argument('--device', type=int, default=0)
@@ -100,14 +103,14 @@ def main(argv=None):
     query_filename = get_source_query_dataset_filename(data_dir, args.model_name, args.query_count, output_dimension, output_dtype)
     if not os.path.exists(query_filename):
         seed = synth.SEED_QUERY if args.synthetic_seed is None else args.synthetic_seed + 1
-        synth.write_source_parquet(query_filename, seed, args.query_count, output_dimension, args.normalize)
+        synth.write_source_parquet(query_filename, seed, args.query_count, output_dimension, args.normalize, layout=args.embedding_layout)
     print(f"(Query source file: {query_filename}) ({time.time() - section:.2f} s)")
 
     section = time.time()
     base_filename = get_source_base_dataset_filename(data_dir, args.model_name, args.base_count, output_dimension, output_dtype)
     if not os.path.exists(base_filename):
         seed = synth.SEED_BASE if args.synthetic_seed is None else args.synthetic_seed
-        synth.write_source_parquet(base_filename, seed, args.base_count, output_dimension, args.normalize)
+        synth.write_source_parquet(base_filename, seed, args.base_count, output_dimension, args.normalize, layout=args.embedding_layout)
     print(f"(Base source file: {base_filename}) ({time.time() - section:.2f} s)")
 
     if not args.resume:

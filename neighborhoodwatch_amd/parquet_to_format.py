@@ -16,6 +16,7 @@ import os
 import struct
 
 import numpy as np
+import pyarrow as pa
 import pyarrow.parquet as pq
 
 from .nw_utils import get_full_filename, output_dimension_validity_check
@@ -123,6 +124,9 @@ def read_parquet_to_dataframe(data_dir, filename):
 
 def read_and_extract(data_dir, input_parquet, rowcount, dimensions, column_names=None):
     table = pq.read_table(get_full_filename(data_dir, input_parquet)).slice(0, rowcount)
+    if column_names is None and "embedding" in table.schema.names and pa.types.is_fixed_size_list(table.schema.field("embedding").type):
+        from .cu_knn import table_list_matrix                                     # the one-column FixedSizeList layout
+        return table_list_matrix(table, table.schema.field("embedding"))
     if column_names is None:
         keep = {f"embedding_{i}" for i in range(dimensions)}
         table = table.select([n for n in table.schema.names if n in keep])      # parquet_to_format.py:97-105

@@ -53,9 +53,11 @@ def gen_unit_rows(seed: int, row0: int, rows: int, d: int) -> np.ndarray:
 
 
 def write_source_parquet(filename: str, seed: int, rows: int, d: int, normalize: bool = False, chunk_rows: int = 50000,
-                         column_prefix: str = "embedding_", metadata_columns: bool = True) -> str:
+                         column_prefix: str = "embedding_", metadata_columns: bool = True, layout: str = "columns") -> str:
     """One parquet file, metadata columns first (unless ``metadata_columns=False``: the ``ck`` source files hold the token
-    columns only, colbert_knn.py:229-233) then ``<prefix>0..d-1`` as float32, written in row groups."""
+    columns only, colbert_knn.py:229-233) then ``<prefix>0..d-1`` as float32, written in row groups.  ``layout="list"`` writes ONE
+    ``FixedSizeList<float32, d>`` column named ``<prefix without the trailing underscore>`` instead (row-major values, so a
+    tile goes to the GPU with no column gather at all); the kNN stage reads either."""
     os.makedirs(os.path.dirname(os.path.abspath(filename)), exist_ok=True)
     writer = None
     try:
@@ -68,8 +70,13 @@ def write_source_parquet(filename: str, seed: int, rows: int, d: int, normalize:
                 "title": pa.array(["synthetic"] * n),
                 "document_id": pa.array(np.arange(r0, r0 + n, dtype=np.int64)),
             } if metadata_columns else {}
-            for j in range(d):
-                cols[f"{column_prefix}{j}"] = pa.array(np.ascontiguousarray(x[:, j]))
+            if layout == "list":
+                cols[column_prefix.rstrip("_")] = pa.FixedSizeListArray.from_arrays(pa.array(np.ascontiguousarray(x).reshape(-1)), d)
+            elif layout == "columns":
+                for j in range(d):
+                    cols[f"{column_prefix}{j}"] = pa.array(np.ascontiguousarray(x[:, j]))
+            else:
+                raise ValueError(f"layout must be 'columns' or 'list', got {layout!r}")
             table = pa.table(cols)
             if writer is None:
                 writer = pq.ParquetWriter(filename, table.schema)

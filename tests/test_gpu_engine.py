@@ -432,9 +432,15 @@ def test_c_abi_collective_on_one_device_equals_the_plain_search(oracle, prescree
     assert np.array_equal(i, i1) and _same_bits(d, d1)
 
 
-def test_c_abi_collective_refuses_bad_device_lists():
+def test_c_abi_collective_refuses_bad_device_lists(engine, oracle):
+    """A refused device list leaves nothing behind -- in particular no stale HIP error for the next launch check to trip over."""
     from neighborhoodwatch_amd import ShardedKnnEngine
     with pytest.raises(ValueError, match="listed twice"):
         ShardedKnnEngine([0, 0])
-    with pytest.raises((ValueError, RuntimeError)):
+    with pytest.raises(ValueError, match="out of range"):
         ShardedKnnEngine([0, 99])
+    base, queries = oracle.gen(0xAC1, 0, 700, 24), oracle.gen(0xAC2, 0, 11, 24)
+    engine.set_base(base)
+    d, i = engine.search(queries, 7)
+    rd, ri = oracle.knn_canonical(base, queries, 7)
+    assert np.array_equal(i, ri) and _same_bits(d, rd)

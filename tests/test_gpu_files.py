@@ -168,6 +168,27 @@ def test_compute_knn_reads_tiles_lazily_and_overlaps(dataset, oracle, monkeypatc
     assert np.array_equal(_arr(fi, np.int64), ri) and np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
 
 
+@pytest.mark.parametrize("api", ["table", "dataset"])
+def test_fixed_size_list_layout_end_to_end(tmp_path, oracle, api):
+    """Source files holding ONE FixedSizeList<float32, 384> column through both drivers: same partial / final files, the
+    oracle's bits."""
+    data_dir = nw_utils.setup_model_output_folder(str(tmp_path), "intfloat/e5-small-v2", 150, 2100, 10)
+    qf = nw_utils.get_source_query_dataset_filename(data_dir, "intfloat/e5-small-v2", 150, 384)
+    bf = nw_utils.get_source_base_dataset_filename(data_dir, "intfloat/e5-small-v2", 2100, 384)
+    synth.write_source_parquet(qf, 0x81, 150, 384, normalize=True, layout="list")
+    synth.write_source_parquet(bf, 0x82, 2100, 384, normalize=True, chunk_rows=600, layout="list")
+    if api == "table":
+        cu_knn.compute_knn(data_dir, "intfloat/e5-small-v2", 384, qf, 150, bf, 2100, False, 10, 800)     # tiles 800, 800, 500
+        assert merge.get_file_count(f"{data_dir}/partial") == 3
+        merge.merge_indices_and_distances(data_dir, k=10)
+    else:
+        cu_knn_ds.compute_knn_ds(data_dir, 384, qf, 150, bf, 2100, False, 10, 800)
+    fd, fi = _final(data_dir)
+    base = synth.gen_unit_rows(0x82, 0, 2100, 384); queries = synth.gen_unit_rows(0x81, 0, 150, 384)
+    rd, ri = oracle.knn_canonical(base, queries, 10)
+    assert np.array_equal(_arr(fi, np.int64), ri) and np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
+
+
 def test_merge_drops_rownum_and_handles_many_lists(tmp_path, oracle):
     """tests/test_03_merge.py:14-24 writes a RowNum column next to the k columns."""
     import pandas as pd
@@ -189,7 +210,7 @@ def test_merge_drops_rownum_and_handles_many_lists(tmp_path, oracle):
     assert np.array_equal(_arr(fi, np.int64), ri) and np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
 
 
-@pytest.mark.parametrize("extra", [[], ["--prescreen"]])
+@pytest.mark.parametrize("extra", [[], ["--prescreen"], ["--embedding-layout", "list", "--use-dataset-api"]])
 def test_cli_end_to_end(tmp_path, oracle, extra):
     from neighborhoodwatch_amd.neighborhoodwatch import main
     assert main(["200", "3000", "-k", "20", "-m", "intfloat/e5-small-v2", "--data-dir", str(tmp_path), "--disable-memory-tuning"] + extra) == 0

@@ -316,3 +316,26 @@ def test_slice_dataset_is_lazy_and_checkpoints_round_trip(tmp_path):
     assert merge.get_file_count(str(tmp_path / "partial")) == 0                             # checkpoints are not partial pairs
     cu_knn_ds._drop_checkpoint(str(tmp_path))
     assert cu_knn_ds._load_checkpoint(str(tmp_path), "sqeuclidean", 5, 12, 1000) is None
+
+
+def test_fixed_size_list_embedding_column(tmp_path):
+    """SURVEY N2's optional layout: ONE FixedSizeList<float32, d> column instead of d float columns.  prep_table validates d from the
+    list size, keeps only that column (eager or lazy), table_input hands the engine the row-major values -- a zero-copy view for a
+    one-chunk tile, one concatenation across row groups -- and tune_memory's footprint counts d floats per row."""
+    f = synth.write_source_parquet(str(tmp_path / "m_8_base_vector_data_50.parquet"), 5, 50, 8, chunk_rows=16, layout="list")
+    assert pq.read_schema(f).names[-1] == "embedding" and pa.types.is_fixed_size_list(pq.read_schema(f).field("embedding").type)
+    ref = synth.gen_rows(5, 0, 50, 8)
+    for lazy in (False, True):
+        t = cu_knn.prep_table(str(tmp_path), "m", "m_8_base_vector_data_50.parquet", 45, 8, lazy=lazy)
+        assert len(t) == 45 and list(t.schema.names) == ["embedding"] and cu_knn.float_row_bytes(t.schema) == 32
+        kind, m = cu_knn.table_input(t.slice(10, 30))
+        assert kind == "matrix" and m.dtype == np.float32 and np.array_equal(m, ref[10:40])
+        kind, m1 = cu_knn.table_input(t.slice(17, 9))                              # inside one row group
+        assert np.array_equal(m1, ref[17:26])
+    with pytest.raises(AssertionError, match="Expected 9 values, got 8"):
+        cu_knn.prep_table(str(tmp_path), "m", "m_8_base_vector_data_50.parquet", 45, 9)
+    w = cu_knn_ds.slice_dataset(cu_knn_ds.load_dataset(str(tmp_path), "m_8_base_vector_data_50.parquet"), 0, 40)
+    assert cu_knn_ds.get_dataset_columns(w, 8) == ["text", "embedding"]
+    kind, cols = cu_knn.table_input(pq.read_table(synth.write_source_parquet(str(tmp_path / "c.parquet"), 5, 20, 8)).select(
+        [f"embedding_{i}" for i in range(8)]))
+    assert kind == "columns" and len(cols) == 8                                    # the reference's layout still takes the column path
