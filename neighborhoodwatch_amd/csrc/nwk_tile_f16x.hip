@@ -23,16 +23,24 @@
 // form: four).
 //
 // LDS-DMA shares (one instruction = 8 rows x 128 B = 1 KiB; a stage = A rows 0-255 | B rows 0-255 of one slab).  A piece of LDS may be
-// refilled once its last reader has passed a barrier:
-//     group 1, in phase 2s+1 (its LOAD of slab s):  A rows   0-127 of slab s+2 -> stage s&1       (read by group 0 in phase 2s;  4 per wave)
-//     group 0, in phase 2s   (its LOAD of slab s):  A rows 128-255, B and the tile's column norms of slab s+1 -> stage (s+1)&1
-//                                                    (read by group 1 in phase 2s-1; 4 + 8 + 1 per wave)
-// i.e. a piece has one (B, lower A) to one and a half (upper A) slab periods to arrive.  Waits: a wave can only wait for its own
-// DMA, so each group waits for what it issued and the barrier that follows publishes it to the other:
-//     group 0: s_waitcnt vmcnt(0) at the end of its COMPUTE phase (its share of slab s+1, issued a phase earlier);
-//     group 1: s_waitcnt vmcnt(4) at the end of its LOAD phase -- all but the four instructions just issued, i.e. upper A of slab s+1
-//              (past the end of the strip the four are still issued, source clamped, into a piece nobody reads again: the count
-//              stays a constant).
+// refilled once its last reader has finished with it, and the stream is dealt out so that (i) both groups issue about the same number of
+// instructions per LOAD phase (the issuing wave sits in the texture unit's queue ~70 cycles per instruction: the L2 -> L1 path moves
+// 64 B per clock and CU, so a slab's 64 KiB are ~1000 cycles of it however they are issued), and (ii) NO barrier ever waits for data in
+// flight -- a wave waits for its own DMA in its LOAD phase, behind the partner's MFMAs:
+//     group 0, LOAD of slab s (phase 2s):    A rows 128-255 of slab s+1, the LOWER half of ITS OWN 64 B rows (wave (0,c): rows 64c..64c+31)
+//                                            of slab s+1 and the tile's column norms -> stage (s+1)&1   (4 + 4 + 1 per wave)
+//     group 1, LOAD of slab s (phase 2s+1):  A rows 0-127 of slab s+2, and -- once ITS OWN reads of slab s have landed -- the UPPER half of
+//                                            its own B rows (wave (1,c): rows 64c+32..64c+63) of slab s+2 -> stage s&1   (4 + 4 per wave)
+//   B rows 64c..64c+63 are read by exactly two waves, (0,c) in phase 2s and (1,c) in phase 2s+1: when (1,c)'s reads have landed the rows are
+//   dead, and (1,c) itself may refill them without asking anyone; what a wave brought for itself it may read after its own s_waitcnt.
+// Waits (a wave can only wait for its own DMA; what OTHER waves read of it is published by the barrier that follows the wait):
+//     group 0, LOAD of slab s:  A fragments first (upper A of slab s: group 1 waited for it a phase ago), then the DMA of slab s+1, then
+//              s_waitcnt vmcnt(9) -- all but the nine just issued, i.e. its share of slab s, requested a whole slab period ago -- then the
+//              B fragments (its own lower half: that wait; the upper half: group 1's wait a phase ago);
+//     group 1, LOAD of slab s:  all fragment reads, upper A of slab s+2 behind them, s_waitcnt lgkmcnt(0), its B half of slab s+2, then
+//              s_waitcnt vmcnt(8): all but the eight just issued, i.e. its share of slab s+1 (requested a slab period ago).
+//   Past the end of the strip group 1 still issues (source clamped, into pieces nobody reads again) so that its count stays a constant;
+//   group 0 skips and waits for vmcnt(0).  Every piece has at least a slab period to arrive, two slabs' worth of DMA are in flight.
 // Epilogue inputs as in the streaming form: query norms | thresholds | row terms staged once per strip, column norms by DMA.
 // Survivors are staged in the LDS list and flushed once at the end of the strip (an entry that finds the list full goes out
 // directly); the first slab of a tile takes a zero C operand instead of cleared accumulators.
@@ -41,13 +49,16 @@
 #include "nwk_f16_common.h"
 
 #define X_BN_BUFS 4                   // column-norm buffers (tile & 3)
+#ifndef X_DIAG
+#define X_DIAG 0
+#endif
+#ifndef X_G0_WAIT_FIRST
+#define X_G0_WAIT_FIRST 1             // group 0's LOAD phase: wait for its own DMA of this slab first, then all reads, then the next slab's DMA
+#endif
 // build-time variants (tools/mk_variant_lib.sh), defaults = what measured fastest
 #ifndef X_PRIO
 #define X_PRIO 1                      // 1: a wave raises its priority for its COMPUTE phase (s_setprio), so its MFMAs win the issue arbitration
 #endif                                //    against the partner's LOAD-phase instructions whichever of the two is the older wave
-#ifndef X_READS_FIRST
-#define X_READS_FIRST 1               // 1: a LOAD phase issues its fragment reads before its LDS-DMA (the reads' latency runs under the DMA
-#endif                                //    issue stalls); 0: DMA first
 
 template <int METRIC, int PRE>
 __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTileParams p)
@@ -63,11 +74,10 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
 
     const TileCoord tc = tile_from_block(p);
     if (!tc.ok) return;
-#ifdef NWKNN_DEV
-    const int diag = p.diag;              // timing ablations (wrong results): 1 no fragment reads, 2 no LDS-DMA inside the loop, 4 no MFMAs, 8 no epilogue
-#else
-    constexpr int diag = 0;
-#endif
+    // timing ablations (wrong results by construction): 1 no fragment reads, 2 no LDS-DMA inside the loop, 4 no MFMAs, 8 no epilogue, 16 DMA
+    // waits one slab late (what a third LDS stage would allow).  A
+    // BUILD-time constant, 0 in every library the package builds (tools/mk_variant_lib.sh makes the ablated ones, under ab/)
+    constexpr int diag = X_DIAG;
 
     const int tid = threadIdx.x;
     const int w = tid >> 6, l = tid & 63;
@@ -90,24 +100,28 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
     // the swizzle term ((row >> 1) & 7) = (4 (pi & 1) + l / 16) & 7 of row 8 pi + l / 8: one per-lane offset for all of them.
     const int wu = __builtin_amdgcn_readfirstlane(w);
     const int grp = wu >> 2, u = wu & 3;
-    const unsigned voff = (unsigned)((l >> 3) * dp * 2 + (((l & 7) ^ ((4 * (u & 1) + (l >> 4)) & 7)) << 4));
+    const unsigned voff0 = (unsigned)((l >> 3) * dp * 2 + (((l & 7) ^ ((l >> 4) & 7)) << 4));               // pieces of even pi
+    const unsigned voff1 = (unsigned)((l >> 3) * dp * 2 + (((l & 7) ^ ((4 + (l >> 4)) & 7)) << 4));         // odd pi
+    const unsigned voffA = (u & 1) ? voff1 : voff0;               // this wave's A pieces u + 4 j share the parity of u
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(qp + q0 * dp), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(bp + b_first * dp), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bn + b_first), 0, 0x7FFFFFFF, 0x00020000);
+    auto issue_A1 = [&](int half, int stage, int k, int j) __attribute__((always_inline)) {      // piece j (0..3) of this wave's share of an A half
+        const int pi = 16 * half + u + 4 * j;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(smem + stage * H_STAGE + pi * 1024), 16, voffA, k * 128 + pi * 8 * dp * 2, 0, 0);
+    };
+    auto issue_B1 = [&](int half, int stage, int t, int k, int j) __attribute__((always_inline)) {
+        const int pi = 8 * u + 4 * half + j;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(smem + stage * H_STAGE + 32768 + pi * 1024), 16, (j & 1) ? voff1 : voff0,
+                                                 k * 128 + (t * H_TN + pi * 8) * dp * 2, 0, 0);
+    };
     auto issue_A = [&](int half, int stage, int k) {              // half 0: rows 0-127 (group 1 issues), 1: rows 128-255 (group 0)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int pi = 16 * half + u + 4 * j;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(smem + stage * H_STAGE + pi * 1024), 16, voff, k * 128 + pi * 8 * dp * 2, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j) issue_A1(half, stage, k, j);
     };
-    auto issue_B = [&](int stage, int t, int k) {
+    auto issue_Bhalf = [&](int half, int stage, int t, int k) {   // the wave's OWN columns: B rows 64 u + 32 half .. + 31 = pieces 8 u + 4 half + j
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int pi = u + 4 * j;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(smem + stage * H_STAGE + 32768 + pi * 1024), 16, voff,
-                                                     k * 128 + (t * H_TN + pi * 8) * dp * 2, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j) issue_B1(half, stage, t, k, j);
     };
     auto issue_N = [&](int t) {                                   // wave u brings the 64 column norms of columns 64 u .. of tile t
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsN, (LDS_AS void*)(smem + OFF_BN + (t & (X_BN_BUFS - 1)) * H_TN * 4 + u * 256), 4, (unsigned)(l * 4),
@@ -120,30 +134,44 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
     const int offB0 = 32768 + (wc * 64 + c16) * 128 + ((g ^ swz) << 4);
     f32x4 acc[8][4];
     f16x8 fa[2][8], fb[2][4];                                     // [k-step][row block] / [k-step][column block] of ONE slab
-    auto read_frags = [&](int stage) {
+    auto read_A = [&](int stage) {
         if (diag & 1) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int n = 0; n < 4; ++n) asm volatile("" : "+v"(fb[ks][n]));
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int m = 0; m < 8; ++m) asm volatile("" : "+v"(fa[ks][m]));
-            }
             return;
         }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int n = 0; n < 4; ++n) fb[ks][n] = *(const f16x8*)(smem + stage * H_STAGE + (offB0 ^ (ks << 6)) + n * 2048);
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int m = 0; m < 8; ++m) fa[ks][m] = *(const f16x8*)(smem + stage * H_STAGE + (offA0 ^ (ks << 6)) + m * 2048);
-        }
     };
-    auto compute = [&](auto first_tag) {                          // 64 MFMAs on registers; FIRST: the tile's first slab starts from a zero C
+    auto read_B = [&](int stage) {
+        if (diag & 1) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) asm volatile("" : "+v"(fb[ks][n]));
+            return;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) fb[ks][n] = *(const f16x8*)(smem + stage * H_STAGE + (offB0 ^ (ks << 6)) + n * 2048);
+    };
+    auto compute = [&](auto first_tag) __attribute__((always_inline)) {                        // 64 MFMAs on registers; FIRST: the tile's first slab starts from a zero C
         constexpr bool FIRST = decltype(first_tag)::value;
         const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
         if (X_PRIO) __builtin_amdgcn_s_setprio(2);
         if (diag & 4) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {                        // keep the fragments (and so the reads) alive
+#pragma unroll
+                for (int m = 0; m < 8; ++m) asm volatile("" :: "v"(fa[ks][m]));
+#pragma unroll
+                for (int n = 0; n < 4; ++n) asm volatile("" :: "v"(fb[ks][n]));
+            }
             if (FIRST) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m)
@@ -163,8 +191,18 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
     };
 
     // ---- epilogue of tile t (this wave's 128 x 64 part) ------------------------------------------------------------------------
-    auto epilogue = [&](int t) {
-        if (diag & 8) return;
+#define X_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // (Tried and dropped: issuing a tile-boundary phase's LDS-DMA instructions one at a time between the blocks of the first-pass test, so
+    // that their ~70 cycles each in the queue hide under the epilogue's vector work -- 2.5 % SLOWER on C3 and the C4 slice: 13 spilled
+    // registers instead of 5 and a first pass the compiler could no longer schedule freely.)
+    auto epilogue = [&](int t) __attribute__((always_inline)) {
+        if (diag & 8) {                                             // keep the accumulators (and so the MFMAs) alive
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) asm volatile("" :: "v"(acc[m][n]));
+            return;
+        }
         const long long col0 = b_first + (long long)t * H_TN + wc * 64 + c16;
         const float* s_bn = (const float*)(smem + OFF_BN + (t & (X_BN_BUFS - 1)) * H_TN * 4);
         float bnv[4], cpre[4];
@@ -192,19 +230,38 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
                 pmin[m] = fminf(fminf(r4[0], r4[1]), fminf(r4[2], r4[3]));
             }
             blocks = prescreen_block_mask(acc, pmin, fminf(fminf(cpre[0], cpre[1]), fminf(cpre[2], cpre[3])));
+#ifdef NWKNN_DEV
+            if (NWK_DBG(p) && (p.diag & 64)) {                      // dev census: how selective are the epilogue's tests?  (tools/f16x_census.py)
+                float rmin = pmin[0], mx = -__builtin_inff();
+#pragma unroll
+                for (int m = 1; m < 8; ++m) rmin = fminf(rmin, pmin[m]);
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) mx = fmaxf(mx, acc[m][n][i]);
+                const bool coarse = __ballot(!(mx < rmin + fminf(fminf(cpre[0], cpre[1]), fminf(cpre[2], cpre[3])))) != 0;
+                if (l == 0) {
+                    unsigned long long* c = NWK_DBG(p) + (size_t)(1u << 23);      // behind the stamp area
+                    atomicAdd(c + 0, 1ull); atomicAdd(c + 1, blocks ? 1ull : 0ull); atomicAdd(c + 2, coarse ? 1ull : 0ull);
+                    atomicAdd(c + 3, (unsigned long long)__popc(blocks));
+                }
+            }
+#endif
         }
         if (blocks)
             tile_epilogue16<METRIC, false, PRE, SC>(p, acc, (const float*)epi, (const u64*)(epi + H_TM * 4), (const float*)(epi + H_TM * 12), bnv,
                                                     colv, colok, cpre, q0, wr * 128, g_here, c_here, s_cnt, s_key, s_row, blocks);
     };
 
-#define X_FENCE() __builtin_amdgcn_sched_barrier(0)
+
     // developer builds: per-wave cycle sums of the pieces of a phase (tools/f16x_stamps.py).  Slots: 0 DMA issue, 1 epilogue, 2 fragment
     // reads until they have landed, 3 wait at the barrier that ends the LOAD phase, 4 MFMA issue, 5 wait for this wave's DMA, 6 wait at
     // the barrier that ends the COMPUTE phase.  The product compiles none of it.
 #ifdef NWKNN_DEV
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool stamp_on = NWK_DBG(p) != nullptr;
+    const bool stamp_on = NWK_DBG(p) != nullptr && !(p.diag & 64);    // diag 64: the buffer takes the census counters instead
     unsigned long long tlast = stamp_on ? __builtin_amdgcn_s_memtime() : 0;
 #define X_STAMP(I)                                                     \
     do {                                                               \
@@ -234,109 +291,112 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
         float my_qn = p.qn[q0 + tid];                             // tid < 256 here: one query row per thread
         u64 my_tau = p.tau[q0 + tid];
         X_FENCE();
-        issue_A(1, 0, 0); issue_B(0, 0, 0); issue_N(0);           // this group's share of slab 0 -> stage 0
+        issue_A(1, 0, 0); issue_Bhalf(0, 0, 0, 0); issue_N(0);    // this group's share of slab 0 -> stage 0
         X_FENCE();
         stage_query_side<METRIC, false, PRE>(epi, H_TM, tid, my_qn, my_tau, p, q0);
         if (tid == 0) *s_cnt = 0;
         X_BARRIER("s_waitcnt vmcnt(0) lgkmcnt(0)", 7, 7);         // [pre] slab 0 complete (group 1 waited for its part), epilogue inputs staged
         int sigma = 0;
-        for (int t = 0; t < n_here; ++t) {
-            // ---- first slab of tile t: LOAD (+ the previous tile's epilogue), COMPUTE from a zero C ------------------------------------
-            {
-                const int st = sigma & 1;
-                auto dma = [&]() {
-                    if (sigma + 1 < S && !(diag & 2)) {             // wave-uniform: slab sigma + 1 is (t, 1) or, when nk == 1, (t + 1, 0)
-                        const int t2 = nk > 1 ? t : t + 1, k2 = nk > 1 ? 1 : 0;
-                        issue_A(1, st ^ 1, k2); issue_B(st ^ 1, t2, k2); issue_N(t2);
-                    }
-                };
-                if (!X_READS_FIRST) dma();
-                X_STAMP(0);
-                X_FENCE();
-                if (t > 0) epilogue(t - 1);
-                X_STAMP(1);
-                X_FENCE();
-                read_frags(st);
-                X_FENCE();
-                if (X_READS_FIRST) dma();
-                X_BARRIER("s_waitcnt lgkmcnt(0)", 2, 3);
-                compute(std::true_type{});
-                X_STAMP(4);
-                X_BARRIER("s_waitcnt vmcnt(0)", 5, 6);
-                ++sigma;
+        // one LOAD phase: A fragments, this group's DMA for the NEXT slab, the wait for its DMA of THIS slab, B fragments
+        auto load = [&](int t, int kt, bool with_epilogue) __attribute__((always_inline)) {
+            const int st = sigma & 1;
+            if (with_epilogue) { epilogue(t - 1); X_STAMP(1); X_FENCE(); }
+#if X_G0_WAIT_FIRST
+            // this group's share of slab sigma was requested a whole slab period ago: wait for it FIRST (nothing younger is outstanding), put
+            // all 24 fragment reads in flight, and let them return under the ~70 cycles each of the nine DMA instructions sits in the queue
+            if (!(diag & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            X_STAMP(5);
+            X_FENCE();
+            read_A(st);
+            read_B(st);
+            X_FENCE();
+            if (sigma + 1 < S && !(diag & 2)) {                     // wave-uniform
+                const bool wrap = kt + 1 == nk;
+                const int t2 = wrap ? t + 1 : t, k2 = wrap ? 0 : kt + 1;
+                issue_A(1, st ^ 1, k2); issue_Bhalf(0, st ^ 1, t2, k2); issue_N(t2);
             }
-            for (int kt = 1; kt < nk; ++kt) {
-                const int st = sigma & 1;
-                auto dma = [&]() {
-                    if (sigma + 1 < S && !(diag & 2)) {
-                        const bool wrap = kt + 1 == nk;
-                        const int t2 = wrap ? t + 1 : t, k2 = wrap ? 0 : kt + 1;
-                        issue_A(1, st ^ 1, k2); issue_B(st ^ 1, t2, k2); issue_N(t2);
-                    }
-                };
-                if (!X_READS_FIRST) dma();
+            X_STAMP(0);
+#else
+            read_A(st);
+            X_FENCE();
+            if (sigma + 1 < S && !(diag & 2)) {                     // wave-uniform
+                const bool wrap = kt + 1 == nk;
+                const int t2 = wrap ? t + 1 : t, k2 = wrap ? 0 : kt + 1;
+                issue_A(1, st ^ 1, k2); issue_Bhalf(0, st ^ 1, t2, k2); issue_N(t2);
                 X_STAMP(0);
-                X_FENCE();
-                read_frags(st);
-                X_FENCE();
-                if (X_READS_FIRST) dma();
-                X_BARRIER("s_waitcnt lgkmcnt(0)", 2, 3);
+                if (diag & 16) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");    // timing experiment (WRONG results): as if there were a third stage
+                else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");    // everything older than these nine: this group's share of slab sigma
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            X_STAMP(5);
+            X_FENCE();
+            read_B(st);
+#endif
+            X_BARRIER("s_waitcnt lgkmcnt(0)", 2, 3);
+        };
+        for (int t = 0; t < n_here; ++t) {
+            load(t, 0, t > 0);                                      // first slab of tile t: + the previous tile's epilogue, COMPUTE from a zero C
+            compute(std::true_type{});
+            X_STAMP(4);
+            X_BARRIER("s_nop 0", 6, 6);
+            ++sigma;
+            for (int kt = 1; kt < nk; ++kt) {
+                load(t, kt, false);
                 compute(std::false_type{});
                 X_STAMP(4);
-                X_BARRIER("s_waitcnt vmcnt(0)", 5, 6);
+                X_BARRIER("s_nop 0", 6, 6);
                 ++sigma;
             }
         }
         epilogue(n_here - 1);                                       // while group 1 computes the strip's last slab
     } else {
         // =========================================================== group 1 ===========================================================
+        int t2 = 0, k2 = 0;                                         // (tile, k-slab) of slab sigma + 2, kept incrementally
+        auto advance2 = [&]() { if (++k2 == nk) { k2 = 0; ++t2; } };
         X_FENCE();
-        issue_A(0, 0, 0);                                           // upper A of slab 0 -> stage 0
-        issue_A(0, 1, S > 1 ? (nk > 1 ? 1 : 0) : 0);                // upper A of slab 1 -> stage 1 (a one-slab strip: a copy nobody reads)
-        X_BARRIER("s_waitcnt vmcnt(4)", 7, 7);                      // [pre] slab 0's part has landed
+        issue_A(0, 0, 0); issue_Bhalf(1, 0, 0, 0);                  // upper A and this wave's B half of slab 0 -> stage 0
+        advance2();                                                 // -> slab 1 (a one-slab strip: slab 0 again, a copy nobody reads)
+        {
+            const bool has1 = S > 1;
+            issue_A(0, 1, has1 ? k2 : 0); issue_Bhalf(1, 1, has1 ? t2 : 0, has1 ? k2 : 0);
+        }
+        advance2();                                                 // -> slab 2
+        X_BARRIER("s_waitcnt vmcnt(8)", 7, 7);                      // [pre] slab 0's part has landed
         X_BARRIER("s_nop 0", 7, 7);                                 // end of phase 0 (group 0 loaded slab 0; nothing to compute yet)
         int sigma = 0;
-        int k2 = nk > 2 ? 2 : 0;                                    // k-slab index of slab sigma + 2 (2 mod nk), kept incrementally
-        auto next_k2 = [&]() { k2 = (k2 + 1 == nk) ? 0 : k2 + 1; };
+        auto load = [&](int t, bool with_epilogue) __attribute__((always_inline)) {
+            const int st = sigma & 1;
+            const bool real = sigma + 2 < S;                        // past the end of the strip: the last slab again, into pieces nobody reads
+            const int tt = real ? t2 : n_here - 1, kk = real ? k2 : nk - 1;
+            if (with_epilogue) { epilogue(t - 1); X_STAMP(1); X_FENCE(); }
+            read_A(st);
+            read_B(st);
+            X_FENCE();
+            if (!(diag & 2)) issue_A(0, st, kk);                    // upper A of slab sigma + 2 (group 0 read this stage's a phase ago)
+            X_STAMP(0);
+            X_FENCE();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads have landed: its B rows of slab sigma are dead
+            X_STAMP(2);
+            X_FENCE();
+            if (!(diag & 2)) issue_Bhalf(1, st, tt, kk);
+            advance2();
+            if (diag & 2) X_BARRIER("s_waitcnt vmcnt(0)", 5, 3);
+            else if (diag & 16) X_BARRIER("s_waitcnt vmcnt(16)", 5, 3);      // timing experiment (WRONG results)
+            else X_BARRIER("s_waitcnt vmcnt(8)", 5, 3);
+        };
         for (int t = 0; t < n_here; ++t) {
-            {
-                const int st = sigma & 1;
-                auto dma = [&]() {
-                    if (!(diag & 2)) issue_A(0, st, sigma + 2 < S ? k2 : nk - 1);    // past the end of the strip: the last slab again (never read)
-                    next_k2();
-                };
-                if (!X_READS_FIRST) dma();
-                X_STAMP(0);
-                X_FENCE();
-                if (t > 0) epilogue(t - 1);
-                X_STAMP(1);
-                X_FENCE();
-                read_frags(st);
-                X_FENCE();
-                if (X_READS_FIRST) dma();
-                if (diag & 2) X_BARRIER("s_waitcnt vmcnt(0) lgkmcnt(0)", 2, 3); else X_BARRIER("s_waitcnt vmcnt(4) lgkmcnt(0)", 2, 3);
-                compute(std::true_type{});
-                X_STAMP(4);
-                ++sigma;
-                if (sigma < S) X_BARRIER("s_nop 0", 5, 6);
-            }
+            load(t, t > 0);
+            compute(std::true_type{});
+            X_STAMP(4);
+            ++sigma;
+            if (sigma < S) X_BARRIER("s_nop 0", 6, 6);
             for (int kt = 1; kt < nk; ++kt) {
-                const int st = sigma & 1;
-                auto dma = [&]() {
-                    if (!(diag & 2)) issue_A(0, st, sigma + 2 < S ? k2 : nk - 1);
-                    next_k2();
-                };
-                if (!X_READS_FIRST) dma();
-                X_STAMP(0);
-                X_FENCE();
-                read_frags(st);
-                X_FENCE();
-                if (X_READS_FIRST) dma();
-                if (diag & 2) X_BARRIER("s_waitcnt vmcnt(0) lgkmcnt(0)", 2, 3); else X_BARRIER("s_waitcnt vmcnt(4) lgkmcnt(0)", 2, 3);
+                load(t, false);
                 compute(std::false_type{});
                 X_STAMP(4);
                 ++sigma;
-                if (sigma < S) X_BARRIER("s_nop 0", 5, 6);
+                if (sigma < S) X_BARRIER("s_nop 0", 6, 6);
             }
         }
         epilogue(n_here - 1);

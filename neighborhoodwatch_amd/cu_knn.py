@@ -41,6 +41,7 @@ from .nw_utils import (get_full_filename, get_partial_distances_filename, get_pa
 from .parquet_stream import ParquetRows, Prefetch
 
 PARQUET_ROW_GROUP = 100000          # cu_knn.py:284-285
+PREFETCH_SLOTS = 2                  # base tiles alive on the host at once per GPU: the one being searched + the one being decoded
 
 
 # ---- parquet out ---------------------------------------------------------------------------------------
@@ -357,7 +358,7 @@ def process_batches(data_dir,
 
         writes = []
         try:
-            with Prefetch(tiles, slots=2) as feed, ThreadPoolExecutor(max_workers=1) as writer:      # the pair of tile i is written while tile i+1 is searched
+            with Prefetch(tiles, slots=PREFETCH_SLOTS) as feed, ThreadPoolExecutor(max_workers=1) as writer:      # the pair of tile i is written while tile i+1 is searched
                 for start, batch_offset, batch_length, tag, dataset, tile in feed:
                     assert (k <= batch_length)                              # cu_knn.py:237
                     dims = dataset[1].shape[1] if dataset[0] == "matrix" else len(dataset[1])

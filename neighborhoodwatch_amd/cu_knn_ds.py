@@ -30,6 +30,9 @@ from .nw_utils import get_full_filename, get_partial_distances_filename, get_par
 from .parquet_stream import ParquetRows, Prefetch
 
 
+PREFETCH_SLOTS = 2                  # base batches alive on the host at once: the one on the GPU + the one being decoded (1 = no overlap)
+
+
 def get_gpu_memory(device: int = 0):
     """Total HBM bytes of one GPU (cu_knn_ds.py:30-36 asks NVML for card 0)."""
     return mem_info(device)[1]
@@ -220,7 +223,7 @@ def process_dataset_batches(data_dir,
 
     pending_write = None
     try:
-        with Prefetch(batches, slots=2) as feed, ThreadPoolExecutor(max_workers=1) as writer:
+        with Prefetch(batches, slots=PREFETCH_SLOTS) as feed, ThreadPoolExecutor(max_workers=1) as writer:
             for batch_offset, rows, base, table in feed:
                 assert (k <= rows)                                                # cu_knn_ds.py:203
                 engine_set_base(eng, base)

@@ -285,8 +285,34 @@ class KnnEngine:
         return od, oi
 
     # -- MaxSim late interaction (extension; not in the reference) -------------------------------------------
+    MAXSIM_DOC_TOKENS = 64
+    MAXSIM_QUERY_TOKENS = 32
+
+    @staticmethod
+    def pad_tokens(items, tokens: int, repeat_last: bool) -> np.ndarray:
+        """Ragged token matrices (a sequence of [t_i, d] arrays, 1 <= t_i <= tokens; float16/32/64) -> dense float32 [n, tokens, d].
+        Documents are padded by REPEATING their last token (a duplicate never changes max_j <q_i, d_j>); queries by ZERO tokens
+        (max_j <0, d_j> = +0 adds nothing to the sum).  The kernels' tile shape fixes 64 tokens per document and 32 per query; this
+        is how shorter ones are fed to them -- the score is then the canonical arithmetic on the padded matrices."""
+        items = list(items)
+        if not items:
+            raise ValueError("no token matrices")
+        d = int(np.asarray(items[0]).shape[-1])
+        out = np.zeros((len(items), tokens, d), dtype=np.float32)
+        for n, x in enumerate(items):
+            a = np.asarray(x, dtype=np.float32)
+            if a.ndim != 2 or a.shape[1] != d or not (1 <= a.shape[0] <= tokens):
+                raise ValueError(f"item {n}: expected [1..{tokens}, {d}] tokens, got shape {a.shape}")
+            out[n, :a.shape[0]] = a
+            if repeat_last and a.shape[0] < tokens:
+                out[n, a.shape[0]:] = a[-1]
+        return out
+
     def maxsim_set_docs(self, doc_tokens) -> None:
-        """doc_tokens: [n_docs, 64, d] float32 (numpy or torch CUDA)."""
+        """doc_tokens: [n_docs, 64, d] float32 (numpy or torch CUDA), or a sequence of ragged [t_i <= 64, d] matrices (padded by
+        repeating the last token, see pad_tokens)."""
+        if isinstance(doc_tokens, (list, tuple)):
+            doc_tokens = self.pad_tokens(doc_tokens, self.MAXSIM_DOC_TOKENS, repeat_last=True)
         if _is_torch(doc_tokens):
             import torch
             t = doc_tokens.to(torch.float32).contiguous()
@@ -307,7 +333,10 @@ class KnnEngine:
         del keep
 
     def maxsim_search(self, query_tokens, k: int, doc_offset: int = 0):
-        """query_tokens: [n_queries, 32, d] float32 -> (scores float32 [q,k] descending, doc ids int64 [q,k])."""
+        """query_tokens: [n_queries, 32, d] float32, or a sequence of ragged [t_i <= 32, d] matrices (zero-padded, see pad_tokens)
+        -> (scores float32 [q,k] descending, doc ids int64 [q,k])."""
+        if isinstance(query_tokens, (list, tuple)):
+            query_tokens = self.pad_tokens(query_tokens, self.MAXSIM_QUERY_TOKENS, repeat_last=False)
         dev = _is_torch(query_tokens) and query_tokens.is_cuda
         if _is_torch(query_tokens):
             import torch

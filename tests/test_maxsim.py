@@ -147,3 +147,29 @@ def test_hip_maxsim_many_queries_chunks_stay_launchable():
             assert eng.stats()["prescreen"] == int(pre)
             res.append((s.clone(), i.clone()))
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][0], res[1][0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prescreen", [False, True])
+def test_hip_maxsim_ragged_documents_and_queries(oracle, prescreen):
+    """Documents of 1..64 tokens and queries of 1..32 tokens (float16 or float32) through the fixed 64 x 32 tile shape: documents are
+    padded by repeating their last token, queries by zero tokens (KnnEngine.pad_tokens).  Bits equal the oracle on the padded
+    matrices, and the scores equal the float64 MaxSim of the UNPADDED data within fp32 tolerance (padding changes nothing)."""
+    from neighborhoodwatch_amd import KnnEngine
+    rng = np.random.default_rng(17)
+    d = 96
+    docs = [rng.standard_normal((int(t), d)).astype(np.float16 if n % 3 == 0 else np.float32) for n, t in enumerate(rng.integers(1, 65, 700))]
+    qs = [rng.standard_normal((int(t), d)).astype(np.float32) for t in rng.integers(1, 33, 19)]
+    with KnnEngine(0) as eng:
+        eng.set_prescreen(prescreen)
+        eng.maxsim_set_docs(docs)
+        s, i = eng.maxsim_search(qs, 25)
+    pd_, pq_ = KnnEngine.pad_tokens(docs, 64, True), KnnEngine.pad_tokens(qs, 32, False)
+    rs, ri = oracle.maxsim_canonical(pd_, pq_, 25)
+    assert np.array_equal(i, ri) and np.array_equal(s.view(np.uint32), rs.view(np.uint32))
+    for q in (0, 7, 18):                                           # float64 MaxSim of the ragged originals
+        exact = np.array([(qs[q].astype(np.float64) @ x.astype(np.float64).T).max(axis=1).sum() for x in docs])
+        assert np.allclose(s[q], exact[i[q]], rtol=1e-5, atol=1e-4)
+        assert np.allclose(np.sort(exact)[::-1][:25], s[q], rtol=1e-5, atol=1e-4)
+    with pytest.raises(ValueError, match="tokens"):
+        KnnEngine.pad_tokens([np.zeros((65, d), np.float32)], 64, True)

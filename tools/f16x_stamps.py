@@ -16,7 +16,9 @@ eng.set_prescreen(True)
 eng.set_option("f16_mfma", 4)
 eng.set_base(base)
 eng.search(qs, 100)
-grid = 1 << 17                                               # more workgroups than any launch here has
+grid = 1 << 20                                               # more workgroups than any launch here has (checked below)
+# the biggest launch: a chunk of <= 2^20 base rows = 4096 tiles in strips of >= 1, query tiles of 256 rows, super-tiles of 64 padded to 8
+assert ((Q + 255) // 256 + 15) // 16 * 16 * 4096 * 2 <= grid * 8, "debug buffer too small for this shape"
 dbg = torch.zeros((grid * 8, 8), dtype=torch.int64, device="cuda")
 eng.set_option("dbg_ptr", dbg.data_ptr())
 eng.search(qs, 100)

@@ -8,9 +8,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 benc
 echo "trace done" 
 for grp in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES"; do
   n=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_direct_$n -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-prescreen > $O/pmc_direct_$n.json 2> $O/pmc_direct_$n.err || exit 1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_direct_$n -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-prescreen --no-secondary > $O/pmc_direct_$n.json 2> $O/pmc_direct_$n.err || exit 1
   echo "direct $n done"
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_pre_$n -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --opt prescreen=1 > $O/pmc_pre_$n.json 2> $O/pmc_pre_$n.err || exit 1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $O/pmc_pre_$n -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --opt prescreen=1 > $O/pmc_pre_$n.json 2> $O/pmc_pre_$n.err || exit 1
   echo "prescreen $n done"
 done
 python3 tools/pmc_summary.py $O $T
