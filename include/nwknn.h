@@ -95,7 +95,7 @@ int nwknn_set_stream(nwknn_handle h, void* hip_stream);
  * search used it: non-finite or extreme-magnitude inputs fall back to the direct kernel),
  * "f16_exact" (fp16 compute path, default 1: results are the canonical fp32 arithmetic applied to the
  * fp16 values, bit for bit -- the fp16 MFMA kernel pre-screens, listed pairs are rescored; 0: raw fp16-MFMA sums),
- * "f16_mfma" (fp16 tile kernel build, all on v_mfma_f32_16x16x32_f16: -1 = auto, default: 4 from 1024 halves per row on, else 3;
+ * "f16_mfma" (fp16 tile kernel build, all on v_mfma_f32_16x16x32_f16: -1 = auto, default: 4 from 768 halves per row on, else 3;
  * 4 = ping-pong form: the two waves of a SIMD alternate between loading a slab's fragments and running its MFMAs; 3 = streaming form;
  * 1 = burst form, one burst of LDS-DMA per slab -- the form every dense first chunk runs), "f16_strip" (base tiles a workgroup of the
  * fp16 kernels walks in a row: 0 = auto, default),

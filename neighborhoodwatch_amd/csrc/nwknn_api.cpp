@@ -722,13 +722,14 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
 {
     NwkTileParams tp = tile_params(h, pl, nq_pad);
     const bool prescreen = pl.pre && (!dense || pl.native16);   // fp32 data: the dense first chunk runs the fp32 kernel
-    // fp16 kernel build.  Auto (round 3, same-box A/B on 32k x 2-4M, tools/f16_forms.py): the ping-pong form from 1024 halves per row
-    // on (d = 1024: +3.7 % over the streaming form at its best strip length, +5.5 % over round 2's default; 1536 fp16 input: +4.2 %;
-    // 2048: +6.3 % / +1.0 % over streaming / burst; 4096: +8.3 % / +3.4 %), the streaming form below (d = 768: equal; 384: the
-    // ping-pong form is 6 % behind, 128: 19 % -- its tile boundaries cost two phases); dense chunks run the burst form (the launcher
-    // sees to that).  Strips: 2 tiles for the ping-pong form (1-3: equal within noise; 4: -2.5 %, 16: -5 %), 4 for the others.
+    // fp16 kernel build.  Auto (round 3, same-box A/B on 32k x 4M, tools/f16_forms.py, strips of 2 / 4 tiles): the ping-pong form from
+    // 768 halves per row on (d = 768: 1 129 vs 1 084 TF for the streaming form, +4.2 %; 1024: +5.5 % over round 2's default; 1536 fp16
+    // input: +4.2 % with the first version of the form; 2048: +6.3 % / +1.0 % over streaming / burst; 4096: +8.3 % / +3.4 %), the
+    // streaming form below (d = 512: 1 005 vs 1 023; 384: 913 vs 953; 128: 461 vs 569 -- a tile is only a few slabs there and the
+    // ping-pong form pays two phases per tile boundary); dense chunks run the burst form (the launcher sees to that).  Strips: 2 tiles
+    // for the ping-pong form (1-3: equal within noise; 4: -2.5 %, 16: -5 %), 4 for the others.
     const int row_halves = (prescreen && pl.copies16) ? h->dp16 : h->dp;
-    const int f16_shape = h->opt_f16_shape >= 0 ? (int)h->opt_f16_shape : (row_halves >= 1024 ? 4 : 3);
+    const int f16_shape = h->opt_f16_shape >= 0 ? (int)h->opt_f16_shape : (row_halves >= 768 ? 4 : 3);
     tp.f16_shape = f16_shape;
     tp.tiles_per_wg = h->opt_f16_strip > 0 ? (int)h->opt_f16_strip : (f16_shape == 4 ? 2 : 4);
     // super-tile shape and walk order (see tile_from_block).  Auto = the fastest setting measured, base tile index fastest in both:

@@ -174,7 +174,7 @@ def test_k_1000(pre_engine, oracle):
 
 @pytest.mark.parametrize("shape_opt", [1, 3, 4])
 def test_both_fp16_kernel_forms(oracle, shape_opt):
-    """f16_mfma = 1: the burst form, 3: the streaming form (the default below 1024 halves per row), 4: the ping-pong form (the default from there on), all on v_mfma_f32_16x16x32_f16 --
+    """f16_mfma = 1: the burst form, 3: the streaming form (the default below 768 halves per row), 4: the ping-pong form (the default from there on), all on v_mfma_f32_16x16x32_f16 --
     pre-screened results are the same bits; the raw fp16 sums are checked against the float64 truth with a tolerance.  (Round 3 removed
     the superseded 32x32x16 and two-workgroup builds: nwknn_set_option refuses their numbers.)"""
     from neighborhoodwatch_amd import KnnEngine
