@@ -28,19 +28,19 @@
 // 64 B per clock and CU, so a slab's 64 KiB are ~1000 cycles of it however they are issued), and (ii) NO barrier ever waits for data in
 // flight -- a wave waits for its own DMA in its LOAD phase, behind the partner's MFMAs:
 //     group 0, LOAD of slab s (phase 2s):    A rows 128-255 of slab s+1, the LOWER half of ITS OWN 64 B rows (wave (0,c): rows 64c..64c+31)
-//                                            of slab s+1 and the tile's column norms -> stage (s+1)&1   (4 + 4 + 1 per wave)
+//                                            of slab s+1 -> stage (s+1)&1 (4 + 4 per wave), and once per tile the next tile's column norms
 //     group 1, LOAD of slab s (phase 2s+1):  A rows 0-127 of slab s+2, and -- once ITS OWN reads of slab s have landed -- the UPPER half of
 //                                            its own B rows (wave (1,c): rows 64c+32..64c+63) of slab s+2 -> stage s&1   (4 + 4 per wave)
 //   B rows 64c..64c+63 are read by exactly two waves, (0,c) in phase 2s and (1,c) in phase 2s+1: when (1,c)'s reads have landed the rows are
 //   dead, and (1,c) itself may refill them without asking anyone; what a wave brought for itself it may read after its own s_waitcnt.
 // Waits (a wave can only wait for its own DMA; what OTHER waves read of it is published by the barrier that follows the wait):
-//     group 0, LOAD of slab s:  A fragments first (upper A of slab s: group 1 waited for it a phase ago), then the DMA of slab s+1, then
-//              s_waitcnt vmcnt(9) -- all but the nine just issued, i.e. its share of slab s, requested a whole slab period ago -- then the
-//              B fragments (its own lower half: that wait; the upper half: group 1's wait a phase ago);
+//     group 0, LOAD of slab s:  s_waitcnt vmcnt(0) FIRST -- its share of slab s, requested a whole slab period ago, nothing younger is
+//              outstanding -- then all 24 fragment reads (upper A and the upper B half: group 1 waited for them a phase ago; its own lower
+//              B half: the wait just made), then the DMA of slab s+1, under whose queue time the reads return;
 //     group 1, LOAD of slab s:  all fragment reads, upper A of slab s+2 behind them, s_waitcnt lgkmcnt(0), its B half of slab s+2, then
 //              s_waitcnt vmcnt(8): all but the eight just issued, i.e. its share of slab s+1 (requested a slab period ago).
 //   Past the end of the strip group 1 still issues (source clamped, into pieces nobody reads again) so that its count stays a constant;
-//   group 0 skips and waits for vmcnt(0).  Every piece has at least a slab period to arrive, two slabs' worth of DMA are in flight.
+//   group 0 simply skips.  Every piece has at least a slab period to arrive, two slabs' worth of DMA are in flight.
 // Epilogue inputs as in the streaming form: query norms | thresholds | row terms staged once per strip, column norms by DMA.
 // Survivors are staged in the LDS list and flushed once at the end of the strip (an entry that finds the list full goes out
 // directly); the first slab of a tile takes a zero C operand instead of cleared accumulators.
@@ -51,9 +51,6 @@
 #define X_BN_BUFS 4                   // column-norm buffers (tile & 3)
 #ifndef X_DIAG
 #define X_DIAG 0
-#endif
-#ifndef X_G0_WAIT_FIRST
-#define X_G0_WAIT_FIRST 1             // group 0's LOAD phase: wait for its own DMA of this slab first, then all reads, then the next slab's DMA
 #endif
 // build-time variants (tools/mk_variant_lib.sh), defaults = what measured fastest
 #ifndef X_PRIO
@@ -301,9 +298,11 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
         auto load = [&](int t, int kt, bool with_epilogue) __attribute__((always_inline)) {
             const int st = sigma & 1;
             if (with_epilogue) { epilogue(t - 1); X_STAMP(1); X_FENCE(); }
-#if X_G0_WAIT_FIRST
             // this group's share of slab sigma was requested a whole slab period ago: wait for it FIRST (nothing younger is outstanding), put
-            // all 24 fragment reads in flight, and let them return under the ~70 cycles each of the nine DMA instructions sits in the queue
+            // all 24 fragment reads in flight, and let them return under the ~70 cycles each of the DMA instructions sits in the queue.
+            // (The other order -- A reads, DMA, vmcnt(9), B reads -- measured 0.5 % slower.)  The column norms are requested once per tile,
+            // with its first slab (round 3's first version re-requested them with every slab to keep a count constant: 15 of 16 instructions
+            // for nothing).
             if (!(diag & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             X_STAMP(5);
             X_FENCE();
@@ -313,26 +312,10 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
             if (sigma + 1 < S && !(diag & 2)) {                     // wave-uniform
                 const bool wrap = kt + 1 == nk;
                 const int t2 = wrap ? t + 1 : t, k2 = wrap ? 0 : kt + 1;
-                issue_A(1, st ^ 1, k2); issue_Bhalf(0, st ^ 1, t2, k2); issue_N(t2);
+                issue_A(1, st ^ 1, k2); issue_Bhalf(0, st ^ 1, t2, k2);
+                if (wrap) issue_N(t2);
             }
             X_STAMP(0);
-#else
-            read_A(st);
-            X_FENCE();
-            if (sigma + 1 < S && !(diag & 2)) {                     // wave-uniform
-                const bool wrap = kt + 1 == nk;
-                const int t2 = wrap ? t + 1 : t, k2 = wrap ? 0 : kt + 1;
-                issue_A(1, st ^ 1, k2); issue_Bhalf(0, st ^ 1, t2, k2); issue_N(t2);
-                X_STAMP(0);
-                if (diag & 16) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");    // timing experiment (WRONG results): as if there were a third stage
-                else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");    // everything older than these nine: this group's share of slab sigma
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            X_STAMP(5);
-            X_FENCE();
-            read_B(st);
-#endif
             X_BARRIER("s_waitcnt lgkmcnt(0)", 2, 3);
         };
         for (int t = 0; t < n_here; ++t) {

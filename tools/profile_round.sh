@@ -4,7 +4,7 @@
 #    on the direct fp32 tile kernel   3. the same on the pre-screened path.  Everything lands in gpurun_out/prof_TAG/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 T=$1; O=gpurun_out/prof_$T; rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 3 --warmup 1 --no-secondary > $O/bench.json 2> $O/bench.err || exit 1     # (the secondary block would put C2 / shard launches of the same kernel into the per-kernel averages)
 echo "trace done" 
 for grp in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES"; do
   n=$(echo $grp | cut -d' ' -f1)

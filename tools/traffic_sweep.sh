@@ -1,11 +1,12 @@
 #!/bin/bash
 # FETCH_SIZE of the tile kernel for several super-tile shapes and walk orders (one rocprofv3 --pmc pass each): traffic_sweep.sh WORKLOAD [extra --opt]
+# (pre-screened path: NOPRE= tools/traffic_sweep.sh c3 prescreen=1)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 w=${1:-c2}; extra=${2:-profile=1}
 for cfg in ${CFGS:-3:0 3:4 4:0 4:4 2:4 1:4 5:0 2:0}; do
   sh=${cfg%%:*}; fl=${cfg##*:}
   rm -rf gpurun_out/sweep_${sh}_$fl
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/sweep_${sh}_$fl -- python3 bench.py --workload $w --steps 1 --warmup 0 --no-cpu-baseline --no-prescreen --opt super_q_shift=$sh,super_walk_q=$((fl>0)),$extra > gpurun_out/sweep_${sh}_$fl.json 2> gpurun_out/sweep_${sh}_$fl.err
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/sweep_${sh}_$fl -- python3 bench.py --workload $w --steps 1 --warmup 0 --no-cpu-baseline --no-secondary ${NOPRE---no-prescreen} --opt super_q_shift=$sh,super_walk_q=$((fl>0)),$extra > gpurun_out/sweep_${sh}_$fl.json 2> gpurun_out/sweep_${sh}_$fl.err
   python3 - <<PY
 import csv, glob, json
 f = glob.glob("gpurun_out/sweep_${sh}_$fl/*/*_counter_collection.csv")[0]
