@@ -157,7 +157,10 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
 #pragma unroll
             for (int n = 0; n < 4; ++n) fb[ks][n] = *(const f16x8*)(smem + stage * H_STAGE + (offB0 ^ (ks << 6)) + n * 2048);
     };
-    auto compute = [&](auto first_tag) __attribute__((always_inline)) {                        // 64 MFMAs on registers; FIRST: the tile's first slab starts from a zero C
+    // 64 MFMAs on registers; FIRST: the tile's first slab starts from a zero C.  (Accumulators in the AGPR half of the register file --
+    // inline-asm MFMAs with "a" constraints, 128 + 128 registers -- were tried to take the C / D traffic off the VGPR ports the partner's LDS
+    // returns use: the K loop alone ran 4.5 % SLOWER, the whole kernel 7 %.)
+    auto compute = [&](auto first_tag) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
         if (X_PRIO) __builtin_amdgcn_s_setprio(2);
