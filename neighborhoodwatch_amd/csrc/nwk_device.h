@@ -29,7 +29,9 @@
 // XCD-aware block -> tile mapping, and the filter epilogue of the 32x32-accumulator kernels.  The kernels live in
 //   nwk_prep.hip       seeded generator, layout/norm preparation, max|x| and the scaled fp16 copies of the pre-screen
 //   nwk_tile_f32.hip   fp32 distance tile (v_mfma_f32_32x32x2_f32) fused with the running top-k filter
-//   nwk_tile_f16p.hip  fp16 distance tile, streaming form (v_mfma_f32_16x16x32_f16): the default up to 2048 halves per row
+//   nwk_tile_f16x.h    fp16 distance tile, ping-pong form (v_mfma_f32_16x16x32_f16; instantiated by nwk_tile_f16x_pre.hip / _raw.hip): the
+//                      default from 768 halves per row on
+//   nwk_tile_f16p.hip  fp16 distance tile, streaming form: the default below
 //   nwk_tile_f16.hip   fp16 distance tile, burst form (the build with a dense mode; rows beyond 2048 halves), direct and pre-screen (PRE = 1)
 //   nwk_select.hip     rescoring of pre-screened pairs, list compaction, finalize, partial-list merge
 //   nwk_maxsim.hip     MaxSim late interaction (extension)

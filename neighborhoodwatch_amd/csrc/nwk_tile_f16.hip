@@ -267,7 +267,7 @@ hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool
     const long long grid = supers * 64;
     if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
     if (p.f16_shape == 3) return nwk_launch_tile_f16p(st, p, metric, pre, (unsigned)grid);
-    if (p.f16_shape == 4) return nwk_launch_tile_f16x(st, p, metric, pre, (unsigned)grid);
+    if (p.f16_shape == 4) return pre ? nwk_launch_tile_f16x_pre(st, p, metric, (unsigned)grid) : nwk_launch_tile_f16x_raw(st, p, metric, (unsigned)grid);
     if (p.f16_shape != 1) return hipErrorInvalidValue;
     return pre ? launch_f16s<1>(st, p, metric, dense, (unsigned)grid) : launch_f16s<0>(st, p, metric, dense, (unsigned)grid);
 }

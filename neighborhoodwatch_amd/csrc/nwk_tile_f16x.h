@@ -1,5 +1,5 @@
-// nwk_tile_f16x.hip -- fp16 distance tile + filter, "ping-pong" form (option f16_mfma = 4).  (gfx950 only; shared pieces: nwk_device.h,
-// nwk_f16_common.h)
+// nwk_tile_f16x.h -- fp16 distance tile + filter, "ping-pong" form (option f16_mfma = 4): the kernel template, compiled by
+// nwk_tile_f16x_pre.hip and nwk_tile_f16x_raw.hip.  (gfx950 only; shared pieces: nwk_device.h, nwk_f16_common.h)
 //
 // Same workgroup tile as the burst and the streaming form (256 queries x 256 base rows, 8 waves 2 x 4, a wave owns 128 x 64 = 8 x 4
 // accumulators of v_mfma_f32_16x16x32_f16), same LDS image (two 64 KiB stages of 128-B rows, 16-B chunk c of row r in slot
@@ -404,17 +404,19 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
 }
 
 // ------------------------------------------------------------------------------------------------
-// launcher (host side, called from nwk_launch_tile_f16 in nwk_tile_f16.hip)
+// launcher (host side, called from nwk_launch_tile_f16 in nwk_tile_f16.hip).  The kernel is instantiated in two translation units,
+// nwk_tile_f16x_pre.hip (PRE = 1: pre-screen) and nwk_tile_f16x_raw.hip (PRE = 0: raw fp16 sums), so that the two halves of the ~60 s
+// this template costs hipcc compile side by side; each defines X_PRE_INSTANCE before including this file.
 // ------------------------------------------------------------------------------------------------
 extern "C++" {
 
-hipError_t nwk_launch_tile_f16x(hipStream_t st, const NwkTileParams& p, int metric, int pre, unsigned grid)
+#if X_PRE_INSTANCE
+hipError_t nwk_launch_tile_f16x_pre(hipStream_t st, const NwkTileParams& p, int metric, unsigned grid)
+#else
+hipError_t nwk_launch_tile_f16x_raw(hipStream_t st, const NwkTileParams& p, int metric, unsigned grid)
+#endif
 {
-#define NWK_X(M)                                                                                                  \
-    do {                                                                                                           \
-        if (pre) hipLaunchKernelGGL((nwk_tile_kernel_f16x<M, 1>), dim3(grid), dim3(512), 0, st, p);                \
-        else hipLaunchKernelGGL((nwk_tile_kernel_f16x<M, 0>), dim3(grid), dim3(512), 0, st, p);                    \
-    } while (0)
+#define NWK_X(M) hipLaunchKernelGGL((nwk_tile_kernel_f16x<M, X_PRE_INSTANCE>), dim3(grid), dim3(512), 0, st, p)
     if (metric == NWKNN_METRIC_SQEUCLIDEAN) NWK_X(NWKNN_METRIC_SQEUCLIDEAN);
     else if (metric == NWKNN_METRIC_ONE_MINUS_DOT) NWK_X(NWKNN_METRIC_ONE_MINUS_DOT);
     else if (metric == NWKNN_METRIC_COSINE) NWK_X(NWKNN_METRIC_COSINE);

@@ -102,7 +102,8 @@ hipError_t nwk_launch_gen_f16(hipStream_t st, uint64_t seed, long long row0, lon
 hipError_t nwk_launch_prep_f16(hipStream_t st, const void* raw, int raw_is_f16, long long rows, int d, long long rows_pad, int dp, void* prepared, float* norms);
 hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool dense, int pre);   // every fp16 tile launch: raw sums (pre = 0) or pre-screen (pre = 1)
 hipError_t nwk_launch_tile_f16p(hipStream_t st, const NwkTileParams& p, int metric, int pre, unsigned grid);   // streaming form (f16_mfma = 3)
-hipError_t nwk_launch_tile_f16x(hipStream_t st, const NwkTileParams& p, int metric, int pre, unsigned grid);   // ping-pong form (f16_mfma = 4)
+hipError_t nwk_launch_tile_f16x_pre(hipStream_t st, const NwkTileParams& p, int metric, unsigned grid);          // ping-pong form (f16_mfma = 4), pre-screen
+hipError_t nwk_launch_tile_f16x_raw(hipStream_t st, const NwkTileParams& p, int metric, unsigned grid);          // ... raw fp16 sums
 hipError_t nwk_launch_prep_strided(hipStream_t st, const void* raw, int in_dtype, long long rs, long long ks, long long rows, int d,
                                    long long rows_pad, int dp, int out_f16, void* prepared, float* norms);
 hipError_t nwk_launch_prep(hipStream_t st, const float* raw, long long rows, int d, long long rows_pad, int dp, float* prepared, float* norms);
