@@ -76,15 +76,16 @@ def self_launch(n: int) -> int:
 
 
 def recorded_traffic(workload):
-    """HBM/fabric bytes per launch of the tile kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
-    gfx950 correction + WRITE_SIZE, separate passes; profiles/traffic_<workload>.json).  PMC cannot be sampled from inside
-    this process, so the figure is the recorded one for this workload (its `source` says which round's build), or None."""
+    """(HBM/fabric bytes per launch of the tile kernel, which kernel it was measured on) from the committed rocprofv3 PMC passes (FETCH_SIZE
+    doubled per the gfx950 correction + WRITE_SIZE, separate passes; profiles/traffic_<workload>.json, written by tools/profile_round.sh).
+    PMC cannot be sampled from inside this process, so the figure is the recorded one for this workload, or (None, None)."""
     f = ROOT / "profiles" / f"traffic_{workload}.json"
     try:
         rec = json.loads(f.read_text())
-        return float(rec.get("tile", rec)["hbm_fabric_bytes_per_launch"])
+        tile = rec.get("tile", rec)
+        return float(tile["hbm_fabric_bytes_per_launch"]), str(tile.get("kernel", ""))
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(base_dev, queries_dev, k, metric, full_b, flop_budget=0.7e13):
@@ -245,6 +246,7 @@ class Bench:
             fence()
             elapsed = time.perf_counter() - t0
             kernel = eng.tile_kernel_name()
+            my_search_ms = agg["tile_ms"] + agg["compact_ms"] + agg["prep_ms"] + agg["rescore_ms"]      # this rank's kernel time over the timed steps
             if world > 1:
                 t = torch.tensor([elapsed], dtype=torch.float64, device=self.red_dev)
                 td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -254,7 +256,10 @@ class Bench:
                 sum_flops, sum_ms = float(fl[0]), float(fl[1])
                 cm = torch.tensor([coll.get("allgather_ms", 0.0), coll.get("merge_ms", 0.0)], dtype=torch.float64, device=self.red_dev)
                 td.all_reduce(cm, op=td.ReduceOp.MAX)
+                per_rank = [None] * world
+                td.all_gather_object(per_rank, round(my_search_ms / n_steps, 3))
                 coll = {"backend": self.backend, "allgather_ms": float(cm[0]) / n_steps, "merge_ms": float(cm[1]) / n_steps,
+                        "rank_kernel_ms_per_step": per_rank,             # shard searches, rank by rank: the load balance behind the max-over-ranks time
                         "allgather_bytes_per_rank": coll.get("allgather_bytes", 0),
                         "timing": "per step, max over ranks; all-gather: HIP events on the rank's current stream (RCCL) or host clock "
                                   "around the host-staged gloo exchange; merge: host clock around the blocking merge call"}
@@ -263,13 +268,17 @@ class Bench:
                 coll = None
             return elapsed, agg, sum_flops, sum_ms, last, kernel, coll
 
-        def roofline(agg_, flops_, ms_, n_steps, kernel, pk, traffic):
+        def roofline(agg_, flops_, ms_, n_steps, kernel, pk, traffic_rec):
+            traffic, traffic_kernel = traffic_rec
+            # a recorded figure is only quoted for the kernel it was measured on (a later build may run another one)
+            if traffic is not None and kernel.split("<")[0] not in traffic_kernel:
+                traffic = None
             ach = (flops_ / 1e12) / (ms_ / 1e3) if ms_ > 0 else 0.0      # FLOPs summed over ranks / kernel time summed over ranks = per-GPU rate
             # one launch per search is the dense first chunk (cap/2 base rows, a different template instance in the
             # rocprofv3 stats, ~1 ms): the per-launch figures are over the filtered launches that carry the work
             n_l = max(agg_["tile_launches"] - n_steps, 1)
             return {"bound": "mfma", "achieved": ach, "peak": pk, "unit": "TFLOP/s", "frac": ach / pk, "traffic": traffic,
-                    "traffic_note": "bytes per launch, rocprofv3 PMC passes recorded in profiles/ (not sampled live)",
+                    "traffic_note": "bytes per launch, rocprofv3 PMC passes recorded in profiles/ (not sampled live; quoted only when recorded on this kernel)",
                     "kernel": kernel, "launches": n_l, "avg_launch_ms": agg_["tile_ms"] / n_l, "flops_per_launch": agg_["tile_flops"] / n_l}
 
         elapsed, agg, sum_flops, sum_ms, last, kernel, coll = measure(steps, warmup)         # exactly K timed steps after W warm-up steps
@@ -291,7 +300,7 @@ class Bench:
                     "identical_to_direct": bool(torch.equal(direct[0], p_last[0])) and bool(torch.equal(direct[1], p_last[1])),
                     "prescreen_searches": p_agg["prescreen"],
                     "roofline": roofline(p_agg, p_flops, p_ms, pre_steps, p_kernel, MFMA_PEAK_TFLOPS["f16"],
-                                         recorded_traffic(name + "_prescreen") if world == 1 else None),
+                                         recorded_traffic(name + "_prescreen") if world == 1 else (None, None)),
                     "breakdown_ms_per_step": {"tile": p_agg["tile_ms"] / pre_steps, "rescore": p_agg["rescore_ms"] / pre_steps,
                                               "compact": p_agg["compact_ms"] / pre_steps, "prep": p_agg["prep_ms"] / pre_steps,
                                               "rescan_launches": p_agg["rescan_launches"], "overflowed_queries": p_agg["overflowed_queries"]},
@@ -305,7 +314,7 @@ class Bench:
                 "config": {"workload": desc, "queries": Q, "base_rows": B, "dim": d, "k": k, "metric": metric,
                            "parallelism": (f"query rows sharded x{world}, base replicated + RCCL all-gather of the [Q/N,k] slices" if by_query else
                                            f"base rows sharded x{world}" + (" + RCCL all-gather of [Q,k] partials + merge" if world > 1 else ""))},
-                "roofline": roofline(agg, sum_flops, sum_ms, steps, kernel, peak, recorded_traffic(name) if world == 1 else None),
+                "roofline": roofline(agg, sum_flops, sum_ms, steps, kernel, peak, recorded_traffic(name) if world == 1 else (None, None)),
                 "breakdown_ms_per_step": {"tile": agg["tile_ms"] / steps, "compact": agg["compact_ms"] / steps,
                                           "prep": agg["prep_ms"] / steps, "rescore": agg["rescore_ms"] / steps, "rescan_launches": agg["rescan_launches"],
                                           "overflowed_queries": agg["overflowed_queries"]},

@@ -108,6 +108,7 @@ def test_bench_starts_its_own_ranks_when_typed_as_the_driver_types_it():
     assert all("gfx950" in d["gcn_arch"] for d in b["devices"])
     c = b["collective"]
     assert c["backend"] == "gloo" and c["allgather_ms"] > 0.0 and c["merge_ms"] > 0.0 and c["allgather_bytes_per_rank"] == 2 * 4096 * 100 * 12
+    assert len(c["rank_kernel_ms_per_step"]) == 2 and all(x > 0.0 for x in c["rank_kernel_ms_per_step"])
     assert "torch.distributed.run" in r.stderr                     # the parent said what it started
 
 
