@@ -46,4 +46,6 @@ for name, fn in (("compute_knn_ds", ds), ("compute_knn (+ partial pairs)", tb)):
     for rnd in range(2):
         serial, overlapped = run(fn, 1), run(fn, 2)
         print(f"{name}: serial read -> search {serial:.2f} s | reader one batch ahead {overlapped:.2f} s   (prescreen={int(pre)}, round {rnd})", flush=True)
-print(f"peak host RSS of this process: {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6:.2f} GB (base file decoded: {B * d * 4 / 1e9:.2f} GB)")
+import pyarrow as pa
+print(f"arrow memory pool high-water mark over the whole script: {pa.default_memory_pool().max_memory() / 1e9:.2f} GB with {batch * d * 4 / 1e9:.2f} GB per decoded batch "
+      f"(base file decoded: {B * d * 4 / 1e9:.2f} GB; the process's peak RSS, {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6:.2f} GB, is set by writing the source files)")
