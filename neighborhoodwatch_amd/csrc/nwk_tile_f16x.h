@@ -203,6 +203,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
                 for (int n = 0; n < 4; ++n) asm volatile("" :: "v"(acc[m][n]));
             return;
         }
+        // (Raising this wave's issue priority for the epilogue -- the partner's MFMAs have slack in a boundary phase -- changes nothing: +-0.2 %.)
         const long long col0 = b_first + (long long)t * H_TN + wc * 64 + c16;
         const float* s_bn = (const float*)(smem + OFF_BN + (t & (X_BN_BUFS - 1)) * H_TN * 4);
         float bnv[4], cpre[4];

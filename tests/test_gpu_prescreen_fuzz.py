@@ -60,7 +60,8 @@ def test_prescreened_search_equals_direct_search(seed):
         eng.set_base(tb)
         for m in METRICS:
             dist, idx = eng.search(tq, k, m)
-            assert eng.stats()["prescreen"] == 1, (family, m)
+            if eng.stats()["prescreen"] != 1:                      # the engine may only decline when a side has no usable magnitude
+                assert float(np.abs(queries).max()) == 0.0 or float(np.abs(base).max()) == 0.0, (family, m)      # (soak seed 14755: d = 1, all-zero queries)
             dd, di = direct[m]
             assert torch.equal(idx, di), f"seed {seed} {family} {m} Q={Q} B={B} d={d} k={k}: indices differ at {(idx != di).sum().item()} positions"
             assert torch.equal(dist.view(torch.int32), dd.view(torch.int32)), f"seed {seed} {family} {m}: distances differ"
