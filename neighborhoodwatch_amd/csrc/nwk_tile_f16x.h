@@ -57,6 +57,10 @@
 #define X_PRIO 1                      // 1: a wave raises its priority for its COMPUTE phase (s_setprio), so its MFMAs win the issue arbitration
 #endif                                //    against the partner's LOAD-phase instructions whichever of the two is the older wave
 
+// (Tried: the `nt` cache-policy bit on the LDS-DMA loads of the base rows, or of the query rows, so that the streamed operand does not push the
+// re-used one out of L2: fabric bytes per launch 49 -> 82 GB / 66 GB and 8 % SLOWER -- a line marked non-temporal leaves L2 before the other
+// workgroups of the super-tile have read it.  Bound for anything of the kind: with every operand L2-resident, X_DIAG=32, the kernel is 4.3 % faster.)
+
 template <int METRIC, int PRE>
 __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTileParams p)
 {
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
     const TileCoord tc = tile_from_block(p);
     if (!tc.ok) return;
     // timing ablations (wrong results by construction): 1 no fragment reads, 2 no LDS-DMA inside the loop, 4 no MFMAs, 8 no epilogue, 16 DMA
-    // waits one slab late (what a third LDS stage would allow).  A
+    // waits one slab late (what a third LDS stage would allow), 32 all operands L2-resident.  A
     // BUILD-time constant, 0 in every library the package builds (tools/mk_variant_lib.sh makes the ablated ones, under ab/)
     constexpr int diag = X_DIAG;
 
@@ -100,8 +104,10 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
     const unsigned voff0 = (unsigned)((l >> 3) * dp * 2 + (((l & 7) ^ ((l >> 4) & 7)) << 4));               // pieces of even pi
     const unsigned voff1 = (unsigned)((l >> 3) * dp * 2 + (((l & 7) ^ ((4 + (l >> 4)) & 7)) << 4));         // odd pi
     const unsigned voffA = (u & 1) ? voff1 : voff0;               // this wave's A pieces u + 4 j share the parity of u
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(qp + q0 * dp), 0, 0x7FFFFFFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(bp + b_first * dp), 0, 0x7FFFFFFF, 0x00020000);
+    // (diag & 32: every workgroup streams the same few tiles -- 4 query tiles, one strip of base tiles -- so that nothing comes from beyond L2)
+    const __amdgpu_buffer_rsrc_t rsA =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(qp + ((diag & 32) ? (long long)(tc.qt & 3) * H_TM : q0) * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(bp + ((diag & 32) ? 0ll : b_first) * dp), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bn + b_first), 0, 0x7FFFFFFF, 0x00020000);
     auto issue_A1 = [&](int half, int stage, int k, int j) __attribute__((always_inline)) {      // piece j (0..3) of this wave's share of an A half
         const int pi = 16 * half + u + 4 * j;
