@@ -98,7 +98,8 @@ int nwknn_set_stream(nwknn_handle h, void* hip_stream);
  * "f16_mfma" (fp16 tile kernel build, all on v_mfma_f32_16x16x32_f16: -1 = auto, default: 4 from 768 halves per row on, else 3;
  * 4 = ping-pong form: the two waves of a SIMD alternate between loading a slab's fragments and running its MFMAs; 3 = streaming form;
  * 1 = burst form, one burst of LDS-DMA per slab -- the form every dense first chunk runs), "f16_strip" (base tiles a workgroup of the
- * fp16 kernels walks in a row: 0 = auto, default),
+ * fp16 kernels walks in a row: 0 = auto, default), "f16_agg" (which filtered chunks run the build of the streaming kernel that reserves
+ * list slots per query row instead of per pair: -1 = auto, default: the loose-threshold chunks at the start of a walk unless "f16_mfma" names a form; 0 never; 1 all),
  * "tile_occ" (workgroups per CU of the fp32 tile kernel, 3 default | 2), "chunk_growth" (0 = auto), "super_q_shift" / "super_walk_q"
  * (shape and walk order of an XCD's super-tile), "upload_threads" (host threads of the column upload pipeline, default 8),
  * "upload_slab_mib" (slab size of that pipeline, default 128),

@@ -18,20 +18,51 @@
 // once per strip, all lanes at once, one round trip in total (flush_survivors).  An entry that finds the LDS list full takes the
 // old direct route, so the capacity is a speed matter only.
 #define H_SC 1024                     // LDS survivor slots per workgroup (12 KiB)
+#define H_DENSE_BLOCK 24              // a wave's 16 x 64 block with more survivors than this bypasses the LDS list (see tile_epilogue16)
 
 __device__ __forceinline__ void append_direct(const NwkTileParams& p, long long qrow, u64 key)
 {
+#if defined(H_DIAG_ATOMIC) && H_DIAG_ATOMIC == 1     // timing ablations (tools/mk_variant_lib.sh; wrong results): no list-length atomic at all ...
+    const u32 pos = (u32)key & 511u;
+#elif defined(H_DIAG_ATOMIC) && H_DIAG_ATOMIC == 2   // ... or one whose counters lie 8 KiB apart (a cache line each) instead of 32 to a line
+    const u32 pos = atomicAdd((u32*)(p.buf + qrow * p.cap), 1u) & 511u;
+#else
     const u32 pos = atomicAdd(p.cnt + qrow, 1u);
+#endif
     if (pos < (u32)p.cap) p.buf[qrow * p.cap + pos] = key;
 }
 
-// every lane of the workgroup calls this after a barrier that follows the last append; the caller resets *s_cnt behind another barrier
-__device__ __forceinline__ void flush_survivors(const NwkTileParams& p, LDS_AS const u32* s_cnt, LDS_AS const u64* s_key, LDS_AS const u32* s_row,
-                                                long long q0, int tid, int nthreads)
+// every lane of the workgroup calls this after a barrier that follows the last append; the caller resets *s_cnt behind another barrier.
+// s_rc (optional): H_TM words of LDS that nothing else uses during the call.  With it, a list of H_FLUSH_BY_ROW entries or more goes
+// out with ONE list-length atomic per query row instead of one per entry: a device-scope atomic on p.cnt is resolved beyond L2, ~5 G/s for
+// the whole chip, and in the early chunks of a walk (loose thresholds, hundreds of survivors per query and chunk) the tile kernel
+// waited for nothing else -- C2 pre-screened: 0.8 ms for a chunk whose MFMAs take 0.02 ms (tools/chunk_trace.sh).
+#define H_FLUSH_BY_ROW 96
+__device__ __forceinline__ void flush_survivors(const NwkTileParams& p, LDS_AS const u32* s_cnt, LDS_AS const u64* s_key, LDS_AS u32* s_row,
+                                                long long q0, int tid, int nthreads, LDS_AS u32* s_rc = nullptr)
 {
     u32 n = *s_cnt;
     if (n > H_SC) n = H_SC;
-    for (u32 e = (u32)tid; e < n; e += (u32)nthreads) append_direct(p, q0 + s_row[e], s_key[e]);
+    if (s_rc == nullptr || n < H_FLUSH_BY_ROW) {                     // workgroup-uniform
+        for (u32 e = (u32)tid; e < n; e += (u32)nthreads) append_direct(p, q0 + s_row[e], s_key[e]);
+        return;
+    }
+    for (int r = tid; r < H_TM; r += nthreads) s_rc[r] = 0;
+    __syncthreads();
+    for (u32 e = (u32)tid; e < n; e += (u32)nthreads) {              // rank of the entry among those of its row, kept in the entry's own word
+        const u32 r = s_row[e];
+        s_row[e] = r | (__hip_atomic_fetch_add(s_rc + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) << 8);
+    }
+    __syncthreads();
+    for (int r = tid; r < H_TM; r += nthreads) {
+        const u32 c = s_rc[r];
+        if (c) s_rc[r] = atomicAdd(p.cnt + q0 + r, c);
+    }
+    __syncthreads();
+    for (u32 e = (u32)tid; e < n; e += (u32)nthreads) {
+        const u32 r = s_row[e] & 255u, pos = s_rc[r] + (s_row[e] >> 8);
+        if (pos < (u32)p.cap) p.buf[(q0 + r) * p.cap + pos] = s_key[e];
+    }
 }
 
 // Pre-screen, first pass over a finished tile (round 2): which of the wave's eight 16-row blocks can hold a survivor at all?
@@ -59,7 +90,7 @@ __device__ __forceinline__ u32 prescreen_block_mask(const f32x4 (&acc)[8][4], co
     return fired;
 }
 
-template <int METRIC, bool DENSE, int PRE, int SC = 0>
+template <int METRIC, bool DENSE, int PRE, int SC = 0, int AGG = 0>
 __device__ __forceinline__ void tile_epilogue16(const NwkTileParams& p, const f32x4 (&acc)[8][4], const float* s_qn, const u64* s_tau,
                                                 const float* s_pre, const float (&bnv)[4], const u32 (&colv)[4], const bool (&colok)[4],
                                                 const float (&cpre)[4], long long q0, int wrow0, int g, int c16,
@@ -124,6 +155,69 @@ __device__ __forceinline__ void tile_epilogue16(const NwkTileParams& p, const f3
         const f32x4 qn4 = *(const f32x4*)(s_qn + rb);
         const u64x2 tl = *(const u64x2*)(s_tau + rb);
         const u64x2 th = *(const u64x2*)(s_tau + rb + 2);
+        if (PRE && SC > 0 && AGG) {
+            // (AGG: the streaming form, which has the registers for it.)  The block's 16 pass masks first, then ONE reservation for all of its survivors: in the LDS list (one ds_add_rtn per block), or
+            // -- a block of a loose-threshold chunk, more survivors than the list is sized for -- straight in the queries' lists with one
+            // list-length atomic per query ROW (the row's survivors of all four column blocks counted together).
+            // (the lane keeps its own 16 pass bits in one register; the wave masks are re-made from them where needed, not held)
+            u32 bits = 0, total = 0;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ps = !(acc[m][n][i] < pre4[i] + cpre[n]) & colok[n];
+                    bits |= ps ? (1u << (4 * n + i)) : 0u;
+                    total += (u32)__popcll(__ballot(ps));
+                }
+            if (!total) continue;
+            const int lane = (g << 4) | c16;
+            auto key_of = [&](int n, int i) {                          // see tile_epilogue: the key carries the fp16 estimate
+                const float sdot = acc[m][n][i];                       // S * dot16 (this kernel's accumulators start at zero)
+                const float est = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? __fmaf_rn(-2.0f * p.pre_inv_scale, sdot, qn4[i] + bnv[n])
+                                                                       : 1.0f - sdot * p.pre_inv_scale;
+                return ((u64)__float_as_uint(est) << 32) | colv[n];
+            };
+            if (total > H_DENSE_BLOCK) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    u32 mq[4], c = 0;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        mq[n] = (u32)(__ballot((bits >> (4 * n + i)) & 1u) >> (16 * g)) & 0xFFFFu;
+                        c += (u32)__popc(mq[n]);
+                    }
+                    u32 base = 0;
+                    if (c && c16 == 0) base = atomicAdd(p.cnt + q0 + rb + i, c);
+                    base = __shfl(base, g << 4);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        if ((bits >> (4 * n + i)) & 1u) {
+                            const u32 pos = base + (u32)__popc(mq[n] & ((1u << c16) - 1u));
+                            if (pos < (u32)cap) p.buf[(q0 + rb + i) * cap + pos] = key_of(n, i);
+                        }
+                        base += (u32)__popc(mq[n]);
+                    }
+                }
+            } else {
+                u32 base = 0;
+                if (lane == 0) base = __hip_atomic_fetch_add(s_cnt, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const bool ps = (bits >> (4 * n + i)) & 1u;
+                        const u64 mk = __ballot(ps);
+                        if (ps) {
+                            const u32 pos = base + (u32)__popcll(mk & ((1ull << lane) - 1ull));
+                            if (pos < (u32)SC) { s_key[pos] = key_of(n, i); s_row[pos] = (u32)(rb + i); }
+                            else append_direct(p, q0 + rb + i, key_of(n, i));
+                        }
+                        base += (u32)__popcll(mk);
+                    }
+            }
+            continue;
+        }
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             u64 key[4];

@@ -35,17 +35,19 @@
 
 #define P_BN_BUFS 4                   // column-norm buffers (tile & 3): the DMA for tile t+2 may run while tile t is in its epilogue
 
-template <int METRIC, int PRE>
+template <int METRIC, int PRE, int AGG>
 __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16p(const NwkTileParams p)
 {
     constexpr int SC = H_SC;
     constexpr int OFF_EPI = 2 * H_STAGE, OFF_BN = OFF_EPI + H_TM * 16, OFF_KEY = OFF_BN + P_BN_BUFS * H_TN * 4, OFF_ROW = OFF_KEY + SC * 8,
                   OFF_CNT = OFF_ROW + SC * 4;
-    __shared__ __attribute__((aligned(16))) char smem[OFF_CNT + 16];
+    constexpr int OFF_RC = OFF_CNT + 16;                           // AGG: row counters of the aggregated flush (flush_survivors)
+    __shared__ __attribute__((aligned(16))) char smem[OFF_RC + (AGG ? H_TM * 4 : 0)];
     char* const epi = smem + OFF_EPI;
     LDS_AS u64* const s_key = (LDS_AS u64*)(smem + OFF_KEY);
     LDS_AS u32* const s_row = (LDS_AS u32*)(smem + OFF_ROW);
     LDS_AS u32* const s_cnt = (LDS_AS u32*)(smem + OFF_CNT);
+    LDS_AS u32* const s_rc = AGG ? (LDS_AS u32*)(smem + OFF_RC) : nullptr;
 
     const TileCoord tc = tile_from_block(p);
     if (!tc.ok) return;
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16p(const NwkTilePara
             u32 blocks = 0xFFu;
             if (PRE) blocks = prescreen_block_mask(acc, pmin, fminf(fminf(cpre[0], cpre[1]), fminf(cpre[2], cpre[3])));
             if (blocks)
-                tile_epilogue16<METRIC, false, PRE, SC>(p, acc, (const float*)epi, (const u64*)(epi + H_TM * 4), (const float*)(epi + H_TM * 12), bnv,
+                tile_epilogue16<METRIC, false, PRE, SC, AGG>(p, acc, (const float*)epi, (const u64*)(epi + H_TM * 4), (const float*)(epi + H_TM * 12), bnv,
                                                         colv, colok, cpre, q0, wr * 128, g_here, c_here, s_cnt, s_key, s_row, blocks);
         }
         ++t; kt = 0;
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16p(const NwkTilePara
             __builtin_amdgcn_s_barrier();
             const u32 staged = __builtin_amdgcn_readfirstlane(*s_cnt);
             if (staged > (u32)(SC / 2)) {
-                flush_survivors(p, s_cnt, s_key, s_row, q0, tid, 512);
+                flush_survivors(p, s_cnt, s_key, s_row, q0, tid, 512, s_rc);
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 if (tid == 0) *s_cnt = 0;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16p(const NwkTilePara
 #undef P_FENCE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // no LDS-DMA may still be in flight when the workgroup leaves the CU
     __syncthreads();
-    flush_survivors(p, s_cnt, s_key, s_row, q0, tid, 512);
+    flush_survivors(p, s_cnt, s_key, s_row, q0, tid, 512, s_rc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -252,8 +254,9 @@ hipError_t nwk_launch_tile_f16p(hipStream_t st, const NwkTileParams& p, int metr
 {
 #define NWK_P(M)                                                                                                  \
     do {                                                                                                           \
-        if (pre) hipLaunchKernelGGL((nwk_tile_kernel_f16p<M, 1>), dim3(grid), dim3(512), 0, st, p);                \
-        else hipLaunchKernelGGL((nwk_tile_kernel_f16p<M, 0>), dim3(grid), dim3(512), 0, st, p);                    \
+        if (pre && p.agg) hipLaunchKernelGGL((nwk_tile_kernel_f16p<M, 1, 1>), dim3(grid), dim3(512), 0, st, p);    \
+        else if (pre) hipLaunchKernelGGL((nwk_tile_kernel_f16p<M, 1, 0>), dim3(grid), dim3(512), 0, st, p);        \
+        else hipLaunchKernelGGL((nwk_tile_kernel_f16p<M, 0, 0>), dim3(grid), dim3(512), 0, st, p);                 \
     } while (0)
     if (metric == NWKNN_METRIC_SQEUCLIDEAN) NWK_P(NWKNN_METRIC_SQEUCLIDEAN);
     else if (metric == NWKNN_METRIC_ONE_MINUS_DOT) NWK_P(NWKNN_METRIC_ONE_MINUS_DOT);

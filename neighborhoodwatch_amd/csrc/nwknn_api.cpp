@@ -126,7 +126,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 0, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 0, opt_f16_agg = -1, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -301,6 +301,9 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
         h->opt_prescreen = value ? 1 : 0;   // takes effect at the next nwknn_set_base (it builds the fp16 copy of the base)
     } else if (!strcmp(name, "f16_exact")) {
         h->opt_f16_exact = value ? 1 : 0;   // fp16 compute path: 1 (default) rescoring to the canonical fp32 chain over the fp16 values, 0 raw MFMA sums
+    } else if (!strcmp(name, "f16_agg")) {
+        if (value < -1 || value > 1) return fail(NWKNN_EINVAL, "f16_agg must be -1 (auto), 0 (never) or 1 (every filtered fp16 chunk)");
+        h->opt_f16_agg = value;             // which chunks run the row-aggregating build of the streaming fp16 kernel (auto: the loose-threshold ones)
     } else if (!strcmp(name, "f16_strip")) {
         if (value < 0 || value > 64) return fail(NWKNN_EINVAL, "f16_strip must be 0 (auto) or 1..64");
         h->opt_f16_strip = value;           // base tiles a workgroup of the fp16 kernels walks in a row (auto: 2 for the ping-pong form, 4 for the others)
@@ -729,8 +732,18 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
     // ping-pong form pays two phases per tile boundary); dense chunks run the burst form (the launcher sees to that).  Strips: 2 tiles
     // for the ping-pong form (1-3: equal within noise; 4: -2.5 %, 16: -5 %), 4 for the others.
     const int row_halves = (prescreen && pl.copies16) ? h->dp16 : h->dp;
-    const int f16_shape = h->opt_f16_shape >= 0 ? (int)h->opt_f16_shape : (row_halves >= 768 ? 4 : 3);
+    const int f16_shape_auto = h->opt_f16_shape >= 0 ? (int)h->opt_f16_shape : (row_halves >= 768 ? 4 : 3);
+    // Loose-threshold chunks.  After `lo` rows tau admits ~k / lo of the next ones (x 1.4 pre-screened): 27 % of all pairs in the chunk
+    // that follows the dense one, 7 %, 1.7 %, ... as the walk quadruples.  There the tile kernel is bound by the list-length atomics --
+    // device scope, resolved beyond L2, ~8 G/s for the whole chip whatever the addresses (C2 pre-screened, tools/chunk_trace.sh: 0.82 ms
+    // for a chunk with 0.02 ms of MFMAs; 0.26 ms with the atomic compiled out; 0.65 ms with every counter in a cache line of its own) --
+    // so those chunks run a build of the streaming kernel that reserves slots per query ROW and block (tile_epilogue16, AGG): 0.82 / 0.79 /
+    // 1.03 ms -> 0.38 / 0.39 / 0.84 ms for C2's first three filtered chunks.  That epilogue costs the hot path registers (5 spills, -17 %
+    // on tight-threshold chunks; in the ping-pong kernel -20 %), hence a build of its own and only below a pass rate of ~1 %.
+    const bool agg = prescreen && !dense && !rescan && (h->opt_f16_agg >= 0 ? h->opt_f16_agg == 1 : (h->opt_f16_shape < 0 && lo <= 140ll * k));   // (a forced f16_mfma is honoured)
+    const int f16_shape = agg ? 3 : f16_shape_auto;
     tp.f16_shape = f16_shape;
+    tp.agg = agg ? 1 : 0;
     tp.tiles_per_wg = h->opt_f16_strip > 0 ? (int)h->opt_f16_strip : (f16_shape == 4 ? 2 : 4);
     // super-tile shape and walk order (see tile_from_block).  Auto = the fastest setting measured, base tile index fastest in both:
     // fp32 kernel 8 x 8 (same-box A/B on C3: 0.27 % faster than 2 x 32 / query fastest, which moves 38 % fewer bytes over the
@@ -770,7 +783,8 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         if (!(prescreen || h->f16)) {
             const bool occ3 = pl.tile_rows == 256 && !NWK_DEV_BUILD_DIAG(h) && h->opt_tile_occ >= 3;
             snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel<%d,false,%d,%d,0,%d>", metric, pl.tile_rows, pl.tile_rows == 256 ? 16 : 32, occ3 ? 3 : 2);
-        } else if (f16_shape == 3 || f16_shape == 4) snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel_f16%c<%d,%d>", f16_shape == 3 ? 'p' : 'x', metric, prescreen ? 1 : 0);
+        } else if (f16_shape == 3) snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel_f16p<%d,%d,%d>", metric, prescreen ? 1 : 0, agg ? 1 : 0);
+        else if (f16_shape == 4) snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel_f16x<%d,%d>", metric, prescreen ? 1 : 0);
         else snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel_f16s<%d,false,%d>", metric, prescreen ? 1 : 0);
     }
     if (prescreen) {                                       // listed pairs -> canonical fp32 keys, in place

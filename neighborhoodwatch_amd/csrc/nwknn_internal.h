@@ -45,6 +45,7 @@ struct NwkTileParams {
     const float* ms_rq;            // MaxSim pre-screen: per-query and per-doc parts of the score bound
     const float* ms_cd;
     int walk_q_fastest;            // 1: inside a super-tile the QUERY tile index runs fastest (consecutive blocks share a base tile), 0: the base tile index
+    int agg;                       // streaming fp16 kernel: the build whose epilogue reserves list slots per query ROW (loose-threshold chunks; run_chunk)
     int tiles_per_wg;              // fp16 kernels: consecutive base tiles a workgroup walks (strip); the launcher turns n_btiles into strips
     int n_btiles_real;             // filled in by the launcher: base tiles of this launch
     int diag;                      // -DNWKNN_DEV builds only: timing ablations of nwk_tile_kernel_f16x (1 no fragment reads, 2 no LDS-DMA in the loop, 4 no MFMAs, 8 no epilogue); 0 in the product

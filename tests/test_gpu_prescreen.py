@@ -199,6 +199,48 @@ def test_both_fp16_kernel_forms(oracle, shape_opt):
             assert np.allclose(dist, ed, rtol=2e-3, atol=2e-3 * float(np.abs(ed).max()))
 
 
+@pytest.mark.parametrize("agg", [-1, 0, 1])
+@pytest.mark.parametrize("d", [72, 768])
+def test_row_aggregating_build_for_loose_threshold_chunks(oracle, agg, d):
+    """f16_agg: the chunks that follow the dense one (thresholds still loose: a few percent of all pairs pass) run a build of the
+    streaming kernel that reserves list slots per query row, not per pair (nwknn_api.cpp run_chunk).  -1 = auto (those chunks only),
+    0 = never, 1 = every filtered chunk.  Same bits whichever kernel carried a chunk -- with many queries per tile, duplicated rows
+    (whole blocks pass together), a list capacity small enough to overflow, and fp16 inputs in exact mode."""
+    from neighborhoodwatch_amd import KnnEngine
+    base = oracle.gen(0xA61, 0, 21000, d)
+    base[5000:5600] = base[17]                                   # 600 copies of one row: dense blocks of survivors far into the walk
+    queries = oracle.gen(0xA62, 0, 700, d)
+    queries[100:140] = base[17] + 1e-3 * queries[100:140]
+    with KnnEngine(0) as eng:
+        eng.set_option("f16_agg", agg)
+        eng.set_option("profile", 1)
+        eng.set_prescreen(True)
+        eng.set_base(base)
+        for metric in ADDITIVE:
+            dist, idx = eng.search(queries, 50, metric)
+            rd, ri = oracle.knn_canonical(base, queries, 50, metric)
+            assert eng.stats()["prescreen"] == 1
+            assert np.array_equal(idx, ri) and _bitwise(dist, rd), metric
+        # the LAST filtered chunk of the last search (cosine = metric 2): its thresholds are loose only when forced
+        expect = "nwk_tile_kernel_f16p<2,1,1>" if agg == 1 else ("nwk_tile_kernel_f16p<2,1,0>" if d < 768 else "nwk_tile_kernel_f16x<2,1>")
+        assert eng.tile_kernel_name() == expect
+        eng.set_option("capacity", 512)                          # the 600 copies overflow a list: the repair pass re-walks with the non-aggregating build
+        eng.set_option("first_chunk", 256)
+        eng.set_base(base)
+        dist, idx = eng.search(queries, 50, "sqeuclidean")
+        rd, ri = oracle.knn_canonical(base, queries, 50, "sqeuclidean")
+        assert eng.stats()["overflowed_queries"] > 0
+        assert np.array_equal(idx, ri) and _bitwise(dist, rd)
+    with KnnEngine(0) as eng:                                      # fp16 inputs, exact mode: canonical fp32 chain over the fp16 values
+        eng.set_option("f16_agg", agg)
+        eng.set_compute_dtype("fp16")
+        b16 = base.astype(np.float16); q16 = queries.astype(np.float16)
+        eng.set_base(b16)
+        dist, idx = eng.search(q16, 50, "sqeuclidean")
+        rd, ri = oracle.knn_canonical(b16.astype(np.float32), q16.astype(np.float32), 50, "sqeuclidean")
+        assert np.array_equal(idx, ri) and _bitwise(dist, rd)
+
+
 @pytest.mark.parametrize("d", [256, 1024, 4096])
 def test_fp16_mfma_accumulation_error_is_far_inside_the_allowance(oracle, d):
     """The pre-screen bound allows the fp16 MFMA's (architecturally unspecified) internal summation an error of 4*d*u*sum|products|,
