@@ -90,6 +90,92 @@ __device__ __forceinline__ u32 prescreen_block_mask(const f32x4 (&acc)[8][4], co
     return fired;
 }
 
+// Filtered pre-screen epilogue, the flagged blocks of a tile, COMPACT form (the ping-pong kernel).  tile_epilogue16 below unrolls over the
+// wave's eight 16-row blocks: eight copies of the exact test and of the sixteen append sequences, ~50 KB of code per call site, and the
+// ping-pong kernel has four call sites -- 228 KB of code, 5 spilled registers.  Here the blocks are walked by a scalar loop over the set bits
+// of the mask and a block's sixteen accumulators are copied into fixed registers first (the fragment registers are dead during an
+// epilogue), so there is ONE copy of the test and of the append code per call site: 41 KB, no spills, no scratch, and the file compiles
+// in half the time.  Speed: the same within +-1 % (C3 shard +0.6 %, C4 slice +2.4 %, 32k x 4M -1.1 % / +0.2 % on two boxes) -- the
+// suspicion that the flagged blocks' cost was instruction fetch (a 64 KB instruction cache per two CUs) did not hold: a build in which
+// the flagged blocks are never visited is 17 % faster with either form, so that time is the visits themselves (1.8 per wave-tile on C3,
+// the slowest of a group's four waves decides, in-kernel stamps: ~2 400 cycles of epilogue per tile and wave).  Same tests, same keys as
+// tile_epilogue16<METRIC, false, 1, SC>.
+// Survivors go to a list of the WAVE's own (H_SCW slots of the workgroup's H_SC; its length a scalar the wave carries through the strip):
+// no reservation to make, so no returning LDS atomic, no cross-lane shuffle of its result and no s_waitcnt the compiler puts in front of
+// an LDS atomic while LDS-DMA is in flight -- ~500 cycles per (column block, row) register with a survivor before, on the critical path
+// of a tile-boundary phase (the slowest of a group's four waves decides).  flush_wave_lists empties the eight lists at the end of the strip.
+#define H_SCW (H_SC / 8)
+template <int METRIC>
+__device__ __forceinline__ void tile_epilogue16_flagged(const NwkTileParams& p, const f32x4 (&acc)[8][4], const float* s_qn, const float* s_pre,
+                                                        const float (&bnv)[4], const u32 (&colv)[4], const bool (&colok)[4], const float (&cpre)[4],
+                                                        long long q0, int wrow0, int g, int c16, LDS_AS u64* w_key, LDS_AS u32* w_row, u32& wcnt,
+                                                        u32 block_mask)
+{
+    u32 todo = __builtin_amdgcn_readfirstlane(block_mask);
+#pragma clang loop unroll(disable)
+    while (todo) {
+        const int m = __builtin_ctz(todo);
+        todo &= todo - 1u;
+        f32x4 a[4];
+        switch (m) {
+            // (the empty asm keeps the cases apart: merged into one load at a variable index, they would send the accumulators to scratch)
+#define H_TAKE_BLOCK(M) a[0] = acc[M][0]; a[1] = acc[M][1]; a[2] = acc[M][2]; a[3] = acc[M][3]; asm volatile("; block " #M : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])); break
+            case 0: H_TAKE_BLOCK(0);
+            case 1: H_TAKE_BLOCK(1);
+            case 2: H_TAKE_BLOCK(2);
+            case 3: H_TAKE_BLOCK(3);
+            case 4: H_TAKE_BLOCK(4);
+            case 5: H_TAKE_BLOCK(5);
+            case 6: H_TAKE_BLOCK(6);
+            default: H_TAKE_BLOCK(7);
+#undef H_TAKE_BLOCK
+        }
+        const int rb = wrow0 + m * 16 + 4 * g;                       // this lane's four query rows: rb .. rb+3
+        const f32x4 pre4 = *(const f32x4*)(s_pre + rb);
+        float mx = -__builtin_inff();                                // operands are finite by construction (see tile_epilogue16)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const f32x4 dlt = a[n] - (pre4 + cpre[n]);
+            mx = fmaxf(fmaxf(mx, dlt[0]), dlt[1]);
+            mx = fmaxf(fmaxf(mx, dlt[2]), dlt[3]);
+        }
+        if (!__ballot(!(mx < 0.0f))) continue;                       // the common case: nothing in this 16 x 64 block survives
+#if defined(H_DIAG_FLAGGED) && H_DIAG_FLAGGED == 1                  // timing ablation (wrong results): exact tests only, nothing is ever listed
+        if (p.nb_valid >= 0) continue;
+#endif
+        const f32x4 qn4 = *(const f32x4*)(s_qn + rb);
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float sdot = a[n][i];                          // S * dot16
+                const bool pass = !(sdot < pre4[i] + cpre[n]) & colok[n];
+                const u64 mk = __ballot(pass);
+                if (!mk) continue;                                   // wave-uniform
+                const float est = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? __fmaf_rn(-2.0f * p.pre_inv_scale, sdot, qn4[i] + bnv[n])
+                                                                       : 1.0f - sdot * p.pre_inv_scale;
+                const u64 key = ((u64)__float_as_uint(est) << 32) | colv[n];
+                const int lane = (g << 4) | c16;
+                if (pass) {
+                    const u32 pos = wcnt + (u32)__popcll(mk & ((1ull << lane) - 1ull));
+                    if (pos < (u32)H_SCW) { w_key[pos] = key; w_row[pos] = (u32)(rb + i); }
+                    else append_direct(p, q0 + rb + i, key);
+                }
+                wcnt += (u32)__popcll(mk);                           // wave-uniform
+            }
+    }
+}
+
+// every lane of the workgroup calls this behind a barrier that follows the waves' last appends and their stores of s_wcnt[wave]
+__device__ __forceinline__ void flush_wave_lists(const NwkTileParams& p, LDS_AS const u32* s_wcnt, LDS_AS const u64* s_key, LDS_AS const u32* s_row,
+                                                 long long q0, int tid, int nthreads)
+{
+    for (int e = tid; e < H_SC; e += nthreads) {
+        const u32 n = s_wcnt[e / H_SCW];
+        if ((u32)(e % H_SCW) < (n < (u32)H_SCW ? n : (u32)H_SCW)) append_direct(p, q0 + s_row[e], s_key[e]);
+    }
+}
+
 template <int METRIC, bool DENSE, int PRE, int SC = 0, int AGG = 0>
 __device__ __forceinline__ void tile_epilogue16(const NwkTileParams& p, const f32x4 (&acc)[8][4], const float* s_qn, const u64* s_tau,
                                                 const float* s_pre, const float (&bnv)[4], const u32 (&colv)[4], const bool (&colok)[4],

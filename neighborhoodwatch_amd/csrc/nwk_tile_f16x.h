@@ -53,6 +53,9 @@
 #define X_DIAG 0
 #endif
 // build-time variants (tools/mk_variant_lib.sh), defaults = what measured fastest
+#ifndef X_COMPACT
+#define X_COMPACT 1                   // 1: the flagged blocks of a pre-screen epilogue go through ONE copy of the exact test (tile_epilogue16_flagged)
+#endif
 #ifndef X_PRIO
 #define X_PRIO 1                      // 1: a wave raises its priority for its COMPUTE phase (s_setprio), so its MFMAs win the issue arbitration
 #endif                                //    against the partner's LOAD-phase instructions whichever of the two is the older wave
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
     constexpr int SC = H_SC;
     constexpr int OFF_EPI = 2 * H_STAGE, OFF_BN = OFF_EPI + H_TM * 16, OFF_KEY = OFF_BN + X_BN_BUFS * H_TN * 4, OFF_ROW = OFF_KEY + SC * 8,
                   OFF_CNT = OFF_ROW + SC * 4;
-    __shared__ __attribute__((aligned(16))) char smem[OFF_CNT + 16];
+    __shared__ __attribute__((aligned(16))) char smem[OFF_CNT + 32];    // PRE: eight list lengths (one per wave), else one
     char* const epi = smem + OFF_EPI;
     LDS_AS u64* const s_key = (LDS_AS u64*)(smem + OFF_KEY);
     LDS_AS u32* const s_row = (LDS_AS u32*)(smem + OFF_ROW);
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
     const TileCoord tc = tile_from_block(p);
     if (!tc.ok) return;
     // timing ablations (wrong results by construction): 1 no fragment reads, 2 no LDS-DMA inside the loop, 4 no MFMAs, 8 no epilogue, 16 DMA
-    // waits one slab late (what a third LDS stage would allow), 32 all operands L2-resident.  A
+    // waits one slab late (what a third LDS stage would allow), 32 all operands L2-resident, 128 the epilogue's first pass only (256: the same with the rest compiled in but never taken).  A
     // BUILD-time constant, 0 in every library the package builds (tools/mk_variant_lib.sh makes the ablated ones, under ab/)
     constexpr int diag = X_DIAG;
 
@@ -198,9 +201,10 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
 
     // ---- epilogue of tile t (this wave's 128 x 64 part) ------------------------------------------------------------------------
 #define X_FENCE() __builtin_amdgcn_sched_barrier(0)
-    // (Tried and dropped: issuing a tile-boundary phase's LDS-DMA instructions one at a time between the blocks of the first-pass test, so
-    // that their ~70 cycles each in the queue hide under the epilogue's vector work -- 2.5 % SLOWER on C3 and the C4 slice: 13 spilled
-    // registers instead of 5 and a first pass the compiler could no longer schedule freely.)
+    // (Tried and dropped, twice: issuing a tile-boundary phase's LDS-DMA instructions one at a time between the blocks of the first-pass test, so
+    // that their ~70 cycles each in the queue hide under the epilogue's vector work -- 2.5 % SLOWER on C3 and the C4 slice with the unrolled
+    // epilogue (13 spilled registers instead of 5), 1 % slower with the compact one.)
+    u32 wcnt = 0;                                                   // PRE: length of this wave's survivor list (a scalar)
     auto epilogue = [&](int t) __attribute__((always_inline)) {
         if (diag & 8) {                                             // keep the accumulators (and so the MFMAs) alive
 #pragma unroll
@@ -262,9 +266,16 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
             }
 #endif
         }
-        if (blocks)
-            tile_epilogue16<METRIC, false, PRE, SC>(p, acc, (const float*)epi, (const u64*)(epi + H_TM * 4), (const float*)(epi + H_TM * 12), bnv,
-                                                    colv, colok, cpre, q0, wr * 128, g_here, c_here, s_cnt, s_key, s_row, blocks);
+        if (diag & 128) { asm volatile("" :: "s"(blocks)); blocks = 0; }   // first pass only: no block ever takes the exact test
+        if ((diag & 256) && p.nb_valid >= 0) blocks = 0;            // the same, with the exact test still compiled in (never taken at run time)
+        if (blocks) {
+            if (PRE && X_COMPACT)
+                tile_epilogue16_flagged<METRIC>(p, acc, (const float*)epi, (const float*)(epi + H_TM * 12), bnv, colv, colok, cpre, q0, wr * 128,
+                                                g_here, c_here, s_key + wu * H_SCW, s_row + wu * H_SCW, wcnt, blocks);
+            else
+                tile_epilogue16<METRIC, false, PRE, SC>(p, acc, (const float*)epi, (const u64*)(epi + H_TM * 4), (const float*)(epi + H_TM * 12), bnv,
+                                                        colv, colok, cpre, q0, wr * 128, g_here, c_here, s_cnt, s_key, s_row, blocks);
+        }
     };
 
 
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
                 ++sigma;
             }
         }
-        epilogue(n_here - 1);                                       // while group 1 computes the strip's last slab
+        epilogue(n_here - 1);                           // while group 1 computes the strip's last slab
     } else {
         // =========================================================== group 1 ===========================================================
         int t2 = 0, k2 = 0;                                         // (tile, k-slab) of slab sigma + 2, kept incrementally
@@ -411,8 +422,14 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
 #undef X_STAMP
 #undef X_FENCE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // no LDS-DMA may still be in flight when the workgroup leaves the CU
-    __syncthreads();
-    flush_survivors(p, s_cnt, s_key, s_row, q0, tid, 512);
+    if (PRE && X_COMPACT) {
+        if (l == 0) s_cnt[wu] = wcnt;
+        __syncthreads();
+        flush_wave_lists(p, s_cnt, s_key, s_row, q0, tid, 512);
+    } else {
+        __syncthreads();
+        flush_survivors(p, s_cnt, s_key, s_row, q0, tid, 512);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
