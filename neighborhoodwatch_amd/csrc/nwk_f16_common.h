@@ -92,10 +92,10 @@ __device__ __forceinline__ u32 prescreen_block_mask(const f32x4 (&acc)[8][4], co
 
 // Filtered pre-screen epilogue, the flagged blocks of a tile, COMPACT form (the ping-pong kernel).  tile_epilogue16 below unrolls over the
 // wave's eight 16-row blocks: eight copies of the exact test and of the sixteen append sequences, ~50 KB of code per call site, and the
-// ping-pong kernel has four call sites -- 228 KB of code, 5 spilled registers.  Here the blocks are walked by a scalar loop over the set bits
-// of the mask and a block's sixteen accumulators are copied into fixed registers first (the fragment registers are dead during an
-// epilogue), so there is ONE copy of the test and of the append code per call site: 41 KB, no spills, no scratch, and the file compiles
-// in half the time.  Speed: the same within +-1 % (C3 shard +0.6 %, C4 slice +2.4 %, 32k x 4M -1.1 % / +0.2 % on two boxes) -- the
+// ping-pong kernel has four call sites -- 228 KB of code, 5 spilled registers.  Here only the exact test is unrolled (in place, row terms
+// in registers: no LDS round trip per flagged block); the blocks that hold a survivor are walked by a scalar loop over the set bits of a
+// mask, a block's sixteen accumulators copied into fixed registers first (the fragment registers are dead during an epilogue), so there is
+// ONE copy of the append code per call site: ~45 KB, no spills, no scratch, and the file compiles in half the time.  Speed: the same within +-1 % (C3 shard +0.6 %, C4 slice +2.4 %, 32k x 4M -1.1 % / +0.2 % on two boxes) -- the
 // suspicion that the flagged blocks' cost was instruction fetch (a 64 KB instruction cache per two CUs) did not hold: a build in which
 // the flagged blocks are never visited is 17 % faster with either form, so that time is the visits themselves (1.8 per wave-tile on C3,
 // the slowest of a group's four waves decides, in-kernel stamps: ~2 400 cycles of epilogue per tile and wave).  Same tests, same keys as
@@ -106,20 +106,38 @@ __device__ __forceinline__ u32 prescreen_block_mask(const f32x4 (&acc)[8][4], co
 // of a tile-boundary phase (the slowest of a group's four waves decides).  flush_wave_lists empties the eight lists at the end of the strip.
 #define H_SCW (H_SC / 8)
 template <int METRIC>
-__device__ __forceinline__ void tile_epilogue16_flagged(const NwkTileParams& p, const f32x4 (&acc)[8][4], const float* s_qn, const float* s_pre,
+__device__ __forceinline__ void tile_epilogue16_flagged(const NwkTileParams& p, const f32x4 (&acc)[8][4], const float* s_qn,
                                                         const float (&bnv)[4], const u32 (&colv)[4], const bool (&colok)[4], const float (&cpre)[4],
                                                         long long q0, int wrow0, int g, int c16, LDS_AS u64* w_key, LDS_AS u32* w_row, u32& wcnt,
-                                                        u32 block_mask)
+                                                        const f32x4 (&rowterm)[8], u32 block_mask)
 {
-    u32 todo = __builtin_amdgcn_readfirstlane(block_mask);
+    // the exact test of every flagged block, in place: "does any of the block's 16 x 64 pairs pass?" (1.8 blocks per wave-tile on C3, one
+    // in eight of them holds a survivor).  Row terms come in registers (the first pass loaded them for its minima).
+    u32 real = 0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        if (!((block_mask >> m) & 1u)) continue;                     // wave-uniform
+        float mx = -__builtin_inff();                                // operands are finite by construction (see tile_epilogue16)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const f32x4 dlt = acc[m][n] - (rowterm[m] + cpre[n]);
+            mx = fmaxf(fmaxf(mx, dlt[0]), dlt[1]);
+            mx = fmaxf(fmaxf(mx, dlt[2]), dlt[3]);
+        }
+        if (__ballot(!(mx < 0.0f))) real |= 1u << m;
+    }
+#if defined(H_DIAG_FLAGGED) && H_DIAG_FLAGGED == 1                  // timing ablation (wrong results): exact tests only, nothing is ever listed
+    if (p.nb_valid >= 0) real = 0;
+#endif
+    // the blocks that hold a survivor: ONE copy of the append code, the block's accumulators and row terms copied into fixed registers
 #pragma clang loop unroll(disable)
-    while (todo) {
-        const int m = __builtin_ctz(todo);
-        todo &= todo - 1u;
-        f32x4 a[4];
+    while (real) {
+        const int m = __builtin_ctz(real);
+        real &= real - 1u;
+        f32x4 a[4], pre4;
         switch (m) {
             // (the empty asm keeps the cases apart: merged into one load at a variable index, they would send the accumulators to scratch)
-#define H_TAKE_BLOCK(M) a[0] = acc[M][0]; a[1] = acc[M][1]; a[2] = acc[M][2]; a[3] = acc[M][3]; asm volatile("; block " #M : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])); break
+#define H_TAKE_BLOCK(M) a[0] = acc[M][0]; a[1] = acc[M][1]; a[2] = acc[M][2]; a[3] = acc[M][3]; pre4 = rowterm[M]; asm volatile("; block " #M : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(pre4)); break
             case 0: H_TAKE_BLOCK(0);
             case 1: H_TAKE_BLOCK(1);
             case 2: H_TAKE_BLOCK(2);
@@ -131,18 +149,6 @@ __device__ __forceinline__ void tile_epilogue16_flagged(const NwkTileParams& p, 
 #undef H_TAKE_BLOCK
         }
         const int rb = wrow0 + m * 16 + 4 * g;                       // this lane's four query rows: rb .. rb+3
-        const f32x4 pre4 = *(const f32x4*)(s_pre + rb);
-        float mx = -__builtin_inff();                                // operands are finite by construction (see tile_epilogue16)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const f32x4 dlt = a[n] - (pre4 + cpre[n]);
-            mx = fmaxf(fmaxf(mx, dlt[0]), dlt[1]);
-            mx = fmaxf(fmaxf(mx, dlt[2]), dlt[3]);
-        }
-        if (!__ballot(!(mx < 0.0f))) continue;                       // the common case: nothing in this 16 x 64 block survives
-#if defined(H_DIAG_FLAGGED) && H_DIAG_FLAGGED == 1                  // timing ablation (wrong results): exact tests only, nothing is ever listed
-        if (p.nb_valid >= 0) continue;
-#endif
         const f32x4 qn4 = *(const f32x4*)(s_qn + rb);
 #pragma unroll
         for (int n = 0; n < 4; ++n)

@@ -232,13 +232,14 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
         asm volatile("" : "+v"(g_here));
         asm volatile("" : "+v"(c_here));
         u32 blocks = 0xFFu;
+        f32x4 rowterm[8];                                           // PRE: this lane's row terms, kept for the exact tests of the flagged blocks
         if (PRE) {                                                  // smallest row term of each 16-row block: recomputed per tile (8 LDS reads)
             const float* s_pre = (const float*)(epi + H_TM * 12);   // rather than kept in 8 registers across the K loops
             float pmin[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                const f32x4 r4 = *(const f32x4*)(s_pre + wr * 128 + m * 16 + 4 * g_here);
-                pmin[m] = fminf(fminf(r4[0], r4[1]), fminf(r4[2], r4[3]));
+                rowterm[m] = *(const f32x4*)(s_pre + wr * 128 + m * 16 + 4 * g_here);
+                pmin[m] = fminf(fminf(rowterm[m][0], rowterm[m][1]), fminf(rowterm[m][2], rowterm[m][3]));
             }
             // (Tried: the lane's own column term per column block in this first pass instead of the smallest of its four -- ~10x fewer
             // flagged blocks, 16 instead of 10 VALU per block: 2 % SLOWER on C3, 1 % on the C4 slice; and a column term that costs two
@@ -270,8 +271,8 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
         if ((diag & 256) && p.nb_valid >= 0) blocks = 0;            // the same, with the exact test still compiled in (never taken at run time)
         if (blocks) {
             if (PRE && X_COMPACT)
-                tile_epilogue16_flagged<METRIC>(p, acc, (const float*)epi, (const float*)(epi + H_TM * 12), bnv, colv, colok, cpre, q0, wr * 128,
-                                                g_here, c_here, s_key + wu * H_SCW, s_row + wu * H_SCW, wcnt, blocks);
+                tile_epilogue16_flagged<METRIC>(p, acc, (const float*)epi, bnv, colv, colok, cpre, q0, wr * 128, g_here, c_here, s_key + wu * H_SCW,
+                                                s_row + wu * H_SCW, wcnt, rowterm, blocks);
             else
                 tile_epilogue16<METRIC, false, PRE, SC>(p, acc, (const float*)epi, (const u64*)(epi + H_TM * 4), (const float*)(epi + H_TM * 12), bnv,
                                                         colv, colok, cpre, q0, wr * 128, g_here, c_here, s_cnt, s_key, s_row, blocks);
