@@ -176,6 +176,9 @@ __device__ __forceinline__ void tile_epilogue16_flagged(const NwkTileParams& p, 
 __device__ __forceinline__ void flush_wave_lists(const NwkTileParams& p, LDS_AS const u32* s_wcnt, LDS_AS const u64* s_key, LDS_AS const u32* s_row,
                                                  long long q0, int tid, int nthreads)
 {
+#if defined(H_DIAG_FLAGGED) && H_DIAG_FLAGGED == 2                  // timing ablation (wrong results): the lists are filled but never emptied
+    if (p.nb_valid >= 0) return;
+#endif
     for (int e = tid; e < H_SC; e += nthreads) {
         const u32 n = s_wcnt[e / H_SCW];
         if ((u32)(e % H_SCW) < (n < (u32)H_SCW ? n : (u32)H_SCW)) append_direct(p, q0 + s_row[e], s_key[e]);

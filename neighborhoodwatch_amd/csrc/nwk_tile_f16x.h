@@ -377,21 +377,21 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
         int sigma = 0;
         auto load = [&](int t, bool with_epilogue) __attribute__((always_inline)) {
             const int st = sigma & 1;
-            const bool real = sigma + 2 < S;                        // past the end of the strip: the last slab again, into pieces nobody reads
-            const int tt = real ? t2 : n_here - 1, kk = real ? k2 : nk - 1;
+            const bool real = sigma + 2 < S;                        // (wave-uniform) nothing is requested past the end of the strip
+            const int tt = t2, kk = k2;
             if (with_epilogue) { epilogue(t - 1); X_STAMP(1); X_FENCE(); }
             read_A(st);
             read_B(st);
             X_FENCE();
-            if (!(diag & 2)) issue_A(0, st, kk);                    // upper A of slab sigma + 2 (group 0 read this stage's a phase ago)
+            if (!(diag & 2) && real) issue_A(0, st, kk);            // upper A of slab sigma + 2 (group 0 read this stage's a phase ago)
             X_STAMP(0);
             X_FENCE();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads have landed: its B rows of slab sigma are dead
             X_STAMP(2);
             X_FENCE();
-            if (!(diag & 2)) issue_Bhalf(1, st, tt, kk);
+            if (!(diag & 2) && real) issue_Bhalf(1, st, tt, kk);
             advance2();
-            if (diag & 2) X_BARRIER("s_waitcnt vmcnt(0)", 5, 3);
+            if ((diag & 2) || !real) X_BARRIER("s_waitcnt vmcnt(0)", 5, 3);      // the strip's last two slabs: this group's share of slab sigma + 1 is the youngest there is
             else if (diag & 16) X_BARRIER("s_waitcnt vmcnt(16)", 5, 3);      // timing experiment (WRONG results)
             else X_BARRIER("s_waitcnt vmcnt(8)", 5, 3);
         };
@@ -410,13 +410,14 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
             }
         }
         epilogue(n_here - 1);
+        X_STAMP(1);
     }
 #ifdef NWKNN_DEV
     if (stamp_on && l == 0) {
         unsigned long long* o = NWK_DBG(p) + ((size_t)blockIdx.x * 8 + w) * 8;
 #pragma unroll
         for (int i = 0; i < 7; ++i) o[i] = tsum[i];
-        o[7] = (unsigned long long)S;
+        o[7] = (unsigned long long)S | ((tsum[7] & 0xFFFFFFull) << 16);           // slabs | cycles from kernel entry to the end of the [pre] phase
     }
 #endif
 #undef X_BARRIER
@@ -427,6 +428,10 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
         if (l == 0) s_cnt[wu] = wcnt;
         __syncthreads();
         flush_wave_lists(p, s_cnt, s_key, s_row, q0, tid, 512);
+#ifdef NWKNN_DEV
+        if (stamp_on && l == 0)                                     // the tail of the workgroup: last stamp of the strip -> the lists' stores issued
+            NWK_DBG(p)[((size_t)blockIdx.x * 8 + w) * 8 + 7] |= ((__builtin_amdgcn_s_memtime() - tlast) & 0xFFFFFFull) << 40;
+#endif
     } else {
         __syncthreads();
         flush_survivors(p, s_cnt, s_key, s_row, q0, tid, 512);

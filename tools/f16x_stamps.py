@@ -29,7 +29,11 @@ raw = dbg.cpu().numpy().reshape(grid, 8, 8)                  # [workgroup][wave]
 names = ["DMA issue", "epilogue", "fragment reads (until landed)", "wait @ LOAD barrier", "MFMA issue", "wait own DMA", "wait @ COMPUTE barrier"]
 print(f"d={d} B={B} Q={Q}: tile {s['tile_flops'] / 1e12 / (s['tile_ms'] / 1e3):.0f} TF with stamps on")
 for grp, waves in (("group 0 (waves 0-3)", slice(0, 4)), ("group 1 (waves 4-7)", slice(4, 8))):
-    w = raw[:, waves, :].reshape(-1, 8)
+    w = raw[:, waves, :].reshape(-1, 8).copy()
+    tail = w[:, 7] >> 40                                         # cycles from the last stamp of the strip to the survivor lists emptied
+    head = (w[:, 7] >> 16) & 0xFFFFFF                            # cycles from kernel entry to the end of the [pre] phase (slab 0 landed)
+    w[:, 7] &= 0xFFFF
+    tail = tail[w[:, 7] > 0]; head = head[w[:, 7] > 0]
     w = w[w[:, 7] > 0]
     per_slab = w[:, :7] / w[:, 7:8]
     tot = per_slab.sum(axis=1)
@@ -37,3 +41,7 @@ for grp, waves in (("group 0 (waves 0-3)", slice(0, 4)), ("group 1 (waves 4-7)",
     for i, n in enumerate(names):
         print(f"   {n:32s} {np.median(per_slab[:, i]):8.0f} | {per_slab[:, i].mean():8.0f}")
     print(f"   {'sum':32s} {np.median(tot):8.0f} | {tot.mean():8.0f}")
+    print(f"   tail of the strip (last epilogue stamp -> lists emptied), cycles per STRIP: median {np.median(tail):.0f} | mean {tail.mean():.0f}"
+          f"  = {tail.mean() / (tot.mean() * np.median(w[:, 7])):.1%} of the strip's slab time")
+    print(f"   head of the strip (kernel entry -> slab 0 landed, inputs staged), cycles per STRIP: median {np.median(head):.0f} | mean {head.mean():.0f}"
+          f"  = {head.mean() / (tot.mean() * np.median(w[:, 7])):.1%}")
