@@ -68,7 +68,8 @@ template <int METRIC, int PRE>
 __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTileParams p)
 {
     constexpr int SC = H_SC;
-    constexpr int OFF_EPI = 2 * H_STAGE, OFF_BN = OFF_EPI + H_TM * 16, OFF_KEY = OFF_BN + X_BN_BUFS * H_TN * 4, OFF_ROW = OFF_KEY + SC * 8,
+    constexpr int OFF_EPI = 2 * H_STAGE, OFF_BN = OFF_EPI + H_TM * 16, OFF_TAB = OFF_BN + X_BN_BUFS * H_TN * 4,
+                  OFF_KEY = OFF_TAB + (PRE ? X_BN_BUFS * H_TN * 4 : 0), OFF_ROW = OFF_KEY + SC * 8,
                   OFF_CNT = OFF_ROW + SC * 4;
     __shared__ __attribute__((aligned(16))) char smem[OFF_CNT + 32];    // PRE: eight list lengths (one per wave), else one
     char* const epi = smem + OFF_EPI;
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
         __builtin_amdgcn_make_buffer_rsrc((void*)(qp + ((diag & 32) ? (long long)(tc.qt & 3) * H_TM : q0) * dp), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(bp + ((diag & 32) ? 0ll : b_first) * dp), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bn + b_first), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc((void*)((PRE ? p.ctab : p.bn) + b_first), 0, 0x7FFFFFFF, 0x00020000);
     auto issue_A1 = [&](int half, int stage, int k, int j) __attribute__((always_inline)) {      // piece j (0..3) of this wave's share of an A half
         const int pi = 16 * half + u + 4 * j;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(smem + stage * H_STAGE + pi * 1024), 16, voffA, k * 128 + pi * 8 * dp * 2, 0, 0);
@@ -132,6 +134,9 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
     auto issue_N = [&](int t) {                                   // wave u brings the 64 column norms of columns 64 u .. of tile t
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsN, (LDS_AS void*)(smem + OFF_BN + (t & (X_BN_BUFS - 1)) * H_TN * 4 + u * 256), 4, (unsigned)(l * 4),
                                                  (t * H_TN + u * 64) * 4, 0, 0);
+        if (PRE)                                                    // ... and their column terms of this search (the epilogue's first pass tests against them;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsT, (LDS_AS void*)(smem + OFF_TAB + (t & (X_BN_BUFS - 1)) * H_TN * 4 + u * 256), 4,      // the norms serve the estimates of survivors only)
+                                                     (unsigned)(l * 4), (t * H_TN + u * 64) * 4, 0, 0);
     };
 
     // ---- fragments --------------------------------------------------------------------------------------------------------------------
@@ -225,8 +230,10 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
             bnv[n] = s_bn[wc * 64 + n * 16 + c16];
             colv[n] = (u32)col;
             colok[n] = col < p.nb_valid;
-            const float c = PRE ? prescreen_col<METRIC>(bnv[n], p) : prefilter_col<METRIC>(bnv[n]);
-            cpre[n] = colok[n] ? c : __builtin_inff();
+            // PRE: the column term comes from the table of this search (prescreen_col evaluated once per base row by nwk_col_terms_kernel instead
+            // of per tile and wave here: ~15 vector instructions and a square root per column block; +inf past the last row)
+            if (PRE) cpre[n] = ((const float*)(smem + OFF_TAB + (t & (X_BN_BUFS - 1)) * H_TN * 4))[wc * 64 + n * 16 + c16];
+            else cpre[n] = colok[n] ? prefilter_col<METRIC>(bnv[n]) : __builtin_inff();
         }
         int g_here = g, c_here = c16;                               // opaque per tile (see nwk_tile_kernel_f16s)
         asm volatile("" : "+v"(g_here));
@@ -446,6 +453,27 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
 extern "C++" {
 
 #if X_PRE_INSTANCE
+// the pre-screen's column term of every base row for one search (it depends on the search's scale and error constants): what the ping-pong
+// kernel's epilogue used to evaluate per tile, wave and column block
+template <int METRIC>
+__global__ __launch_bounds__(256) void nwk_col_terms_kernel(const NwkTileParams p, long long rows_pad, float* out)
+{
+    for (long long b = (long long)blockIdx.x * 256 + threadIdx.x; b < rows_pad; b += (long long)gridDim.x * 256)
+        out[b] = b < p.nb_valid ? prescreen_col<METRIC>(p.bn[b], p) : __builtin_inff();
+}
+
+hipError_t nwk_launch_col_terms(hipStream_t st, const NwkTileParams& p, int metric, long long rows_pad, float* out)
+{
+    if (rows_pad <= 0) return hipSuccess;
+    long long blocks = (rows_pad + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (metric == NWKNN_METRIC_SQEUCLIDEAN) hipLaunchKernelGGL(nwk_col_terms_kernel<NWKNN_METRIC_SQEUCLIDEAN>, dim3((unsigned)blocks), dim3(256), 0, st, p, rows_pad, out);
+    else if (metric == NWKNN_METRIC_ONE_MINUS_DOT) hipLaunchKernelGGL(nwk_col_terms_kernel<NWKNN_METRIC_ONE_MINUS_DOT>, dim3((unsigned)blocks), dim3(256), 0, st, p, rows_pad, out);
+    else if (metric == NWKNN_METRIC_COSINE) hipLaunchKernelGGL(nwk_col_terms_kernel<NWKNN_METRIC_COSINE>, dim3((unsigned)blocks), dim3(256), 0, st, p, rows_pad, out);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 hipError_t nwk_launch_tile_f16x_pre(hipStream_t st, const NwkTileParams& p, int metric, unsigned grid)
 #else
 hipError_t nwk_launch_tile_f16x_raw(hipStream_t st, const NwkTileParams& p, int metric, unsigned grid)

@@ -124,7 +124,7 @@ struct nwknn_ctx {
     long long nb_pad_for_copy = 0;
     int dp_for_copy = 0;
     // running top-k state
-    DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i;
+    DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i, ctab;
     // options
     long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 0, opt_f16_agg = -1, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128;
     int num_cu = 256;
@@ -253,7 +253,7 @@ extern "C" int nwknn_destroy(nwknn_handle h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->bp, &h->bn, &h->braw, &h->qraw, &h->qp, &h->qn, &h->tau, &h->cnt, &h->buf, &h->ovf, &h->ovf_any, &h->qtiles,
-                      &h->out_d, &h->out_i, &h->mrg_d, &h->mrg_i, &h->bp16, &h->qp16, &h->cnt0, &h->scal, &h->ms_rq, &h->ms_cd, &h->ms_surv, &h->ms_nsurv})
+                      &h->out_d, &h->out_i, &h->mrg_d, &h->mrg_i, &h->ctab, &h->bp16, &h->qp16, &h->cnt0, &h->scal, &h->ms_rq, &h->ms_cd, &h->ms_surv, &h->ms_nsurv})
         b->release();
     for (EvPair& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (int i = 0; i < 2; ++i) {
@@ -765,6 +765,7 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         if (pl.copies16) { tp.qp = h->qp16.as<float>(); tp.bp = h->bp16.as<float>(); tp.dp = h->dp16; }
         tp.pre_inv_scale = 1.0f / pl.pre_scale;
         tp.pre_scale = pl.pre_scale; tp.pre_eps_half = pl.pre_eps_half; tp.pre_aq = pl.pre_aq; tp.pre_ab = pl.pre_ab; tp.pre_cst = pl.pre_cst;
+        tp.ctab = h->ctab.as<float>();
     }
     {   // HIP refuses a launch of 2^32 threads or more.  A chunk of very many query tiles x base tiles (hundreds of thousands of queries)
         // goes out as several launches over consecutive base-tile ranges: same thresholds, same lists, so the same result
@@ -985,6 +986,15 @@ static int search_common(nwknn_ctx* h, const void* queries, const ColumnSource* 
         } else {
             native16 = false;
         }
+    }
+    if (pl.pre) {                                                  // the column term of every base row under this search's constants (ping-pong kernel)
+        RCCHK(h->ctab.ensure((size_t)h->nb_pad * 4));
+        NwkTileParams tp = tile_params(h, pl, nq_pad);
+        tp.pre_inv_scale = 1.0f / pl.pre_scale;
+        tp.pre_scale = pl.pre_scale; tp.pre_eps_half = pl.pre_eps_half; tp.pre_aq = pl.pre_aq; tp.pre_ab = pl.pre_ab; tp.pre_cst = pl.pre_cst;
+        EvPair* e = ev_begin(h, 2);
+        HIPCHK(nwk_launch_col_terms(h->stream, tp, metric, h->nb_pad, h->ctab.as<float>()));
+        ev_end(h, e);
     }
     h->stats.prescreen = (pre || native16) ? 1 : 0;
     HIPCHK(hipMemsetAsync(h->tau.p, 0xFF, (size_t)nq_pad * 8, h->stream));

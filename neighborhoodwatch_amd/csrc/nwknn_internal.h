@@ -45,6 +45,7 @@ struct NwkTileParams {
     const float* ms_rq;            // MaxSim pre-screen: per-query and per-doc parts of the score bound
     const float* ms_cd;
     int walk_q_fastest;            // 1: inside a super-tile the QUERY tile index runs fastest (consecutive blocks share a base tile), 0: the base tile index
+    const float* ctab;             // ping-pong pre-screen kernel: the column term of every base row for THIS search (nwk_launch_col_terms), +inf past nb_valid
     int agg;                       // streaming fp16 kernel: the build whose epilogue reserves list slots per query ROW (loose-threshold chunks; run_chunk)
     int tiles_per_wg;              // fp16 kernels: consecutive base tiles a workgroup walks (strip); the launcher turns n_btiles into strips
     int n_btiles_real;             // filled in by the launcher: base tiles of this launch
@@ -104,6 +105,7 @@ hipError_t nwk_launch_prep_f16(hipStream_t st, const void* raw, int raw_is_f16, 
 hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool dense, int pre);   // every fp16 tile launch: raw sums (pre = 0) or pre-screen (pre = 1)
 hipError_t nwk_launch_tile_f16p(hipStream_t st, const NwkTileParams& p, int metric, int pre, unsigned grid);   // streaming form (f16_mfma = 3)
 hipError_t nwk_launch_tile_f16x_pre(hipStream_t st, const NwkTileParams& p, int metric, unsigned grid);          // ping-pong form (f16_mfma = 4), pre-screen
+hipError_t nwk_launch_col_terms(hipStream_t st, const NwkTileParams& p, int metric, long long rows_pad, float* out);  // out[b] = the pre-screen's column term of base row b
 hipError_t nwk_launch_tile_f16x_raw(hipStream_t st, const NwkTileParams& p, int metric, unsigned grid);          // ... raw fp16 sums
 hipError_t nwk_launch_prep_strided(hipStream_t st, const void* raw, int in_dtype, long long rs, long long ks, long long rows, int d,
                                    long long rows_pad, int dp, int out_f16, void* prepared, float* norms);

@@ -8,7 +8,10 @@ multi-GPU driver use.  numpy arrays are host buffers; torch CUDA tensors are pas
 """
 from __future__ import annotations
 
+import atexit
 import ctypes
+import sys
+import weakref
 from typing import Optional, Tuple
 
 import numpy as np
@@ -32,6 +35,21 @@ def resolve_metric(metric: Optional[str] = None, engine: Optional[str] = None) -
     return metric
 
 
+# Handles still open when the interpreter exits are destroyed HERE, in an atexit hook -- while the HIP runtime is still up -- and never from
+# a __del__ that runs during interpreter finalization: by then the runtime's own teardown may have run, and nwknn_destroy (stream sync,
+# event destroy, hipFree) segfaulted now and then, after a green test run (the process then exits with a signal instead of 0).
+_live = weakref.WeakSet()
+
+
+@atexit.register
+def _close_live_handles() -> None:
+    for obj in list(_live):
+        try:
+            obj.close()
+        except Exception:
+            pass
+
+
 class KnnEngine:
     """One GPU's share of a brute-force kNN job (the reference uses device 0 only, cu_knn.py:65)."""
 
@@ -39,6 +57,7 @@ class KnnEngine:
         self._L = _lib.load()
         self._h = ctypes.c_void_p()
         check(self._L.nwknn_create(ctypes.byref(self._h), int(device)), "nwknn_create")
+        _live.add(self)
         self.device = int(device)
         self.rows = 0
         self.dim = 0
@@ -52,6 +71,8 @@ class KnnEngine:
             self._h = ctypes.c_void_p()
 
     def __del__(self):
+        if sys.is_finalizing():                                     # too late for HIP calls (see _close_live_handles)
+            return
         try:
             self.close()
         except Exception:
@@ -388,6 +409,7 @@ class ShardedKnnEngine:
         devs = [int(x) for x in devices]
         arr = (ctypes.c_int * len(devs))(*devs)
         check(self._L.nwknn_comm_create(ctypes.byref(self._c), arr, len(devs)), "nwknn_comm_create")
+        _live.add(self)
         self.devices = devs
         self.rows = self.dim = 0
         if profile:
@@ -399,6 +421,8 @@ class ShardedKnnEngine:
             self._c = ctypes.c_void_p()
 
     def __del__(self):
+        if sys.is_finalizing():                                     # too late for HIP calls (see _close_live_handles)
+            return
         try:
             self.close()
         except Exception:

@@ -444,3 +444,24 @@ def test_c_abi_collective_refuses_bad_device_lists(engine, oracle):
     d, i = engine.search(queries, 7)
     rd, ri = oracle.knn_canonical(base, queries, 7)
     assert np.array_equal(i, ri) and _same_bits(d, rd)
+
+
+def test_handles_left_open_are_destroyed_before_the_interpreter_tears_down():
+    """A process that exits with engines still open (the module-level default engine of `knn()`, one in a global, one in a reference
+    cycle) must exit with 0: the handles are destroyed in an atexit hook while the HIP runtime is up, not from __del__ during
+    interpreter finalization (an intermittent segfault after a green run otherwise)."""
+    import subprocess, sys
+    code = (
+        "import numpy as np\n"
+        "from neighborhoodwatch_amd import KnnEngine, knn\n"
+        "b = np.random.default_rng(0).standard_normal((3000, 64)).astype(np.float32)\n"
+        "d, i = knn(b, b[:10], 5)\n"
+        "assert (i[:, 0] == np.arange(10)).all()\n"
+        "G = KnnEngine(0); G.set_prescreen(True); G.set_base(b); G.search(b[:300], 5)\n"
+        "class C: pass\n"
+        "c = C(); c.me = c; c.eng = KnnEngine(0); c.eng.set_base(b)\n"
+        "print('done', flush=True)\n")
+    for _ in range(3):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                           cwd=str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+        assert r.returncode == 0 and "done" in r.stdout, (r.returncode, r.stderr[-2000:])
