@@ -95,11 +95,12 @@ __device__ __forceinline__ u32 prescreen_block_mask(const f32x4 (&acc)[8][4], co
 // ping-pong kernel has four call sites -- 228 KB of code, 5 spilled registers.  Here only the exact test is unrolled (in place, row terms
 // in registers: no LDS round trip per flagged block); the blocks that hold a survivor are walked by a scalar loop over the set bits of a
 // mask, a block's sixteen accumulators copied into fixed registers first (the fragment registers are dead during an epilogue), so there is
-// ONE copy of the append code per call site: ~45 KB, no spills, no scratch, and the file compiles in half the time.  Speed: the same within +-1 % (C3 shard +0.6 %, C4 slice +2.4 %, 32k x 4M -1.1 % / +0.2 % on two boxes) -- the
+// ONE copy of the append code per call site: ~45 KB, no spills, no scratch, and the file compiles in half the time.  Speed of the
+// compact form by itself: the same within +-1 % (C3 shard +0.6 %, C4 slice +2.4 %, 32k x 4M -1.1 % / +0.2 % on two boxes) -- the
 // suspicion that the flagged blocks' cost was instruction fetch (a 64 KB instruction cache per two CUs) did not hold: a build in which
-// the flagged blocks are never visited is 17 % faster with either form, so that time is the visits themselves (1.8 per wave-tile on C3,
-// the slowest of a group's four waves decides, in-kernel stamps: ~2 400 cycles of epilogue per tile and wave).  Same tests, same keys as
-// tile_epilogue16<METRIC, false, 1, SC>.
+// the flagged blocks are never visited is 17 % faster with either form, so that time is the visits themselves, above all the appends
+// (1.8 flagged blocks per wave-tile on C3, the slowest of a group's four waves decides; in-kernel stamps: ~2 400 cycles of epilogue per
+// tile and wave).  Same tests, same keys as tile_epilogue16<METRIC, false, 1, SC>.
 // Survivors go to a list of the WAVE's own (H_SCW slots of the workgroup's H_SC; its length a scalar the wave carries through the strip):
 // no reservation to make, so no returning LDS atomic, no cross-lane shuffle of its result and no s_waitcnt the compiler puts in front of
 // an LDS atomic while LDS-DMA is in flight -- ~500 cycles per (column block, row) register with a survivor before, on the critical path
