@@ -152,7 +152,12 @@ __device__ __forceinline__ void tile_epilogue16_flagged(const NwkTileParams& p, 
         const int rb = wrow0 + m * 16 + 4 * g;                       // this lane's four query rows: rb .. rb+3
         const f32x4 qn4 = *(const f32x4*)(s_qn + rb);
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < 4; ++n) {
+            {   // the block's test once more per column block: a block with a survivor usually has it in one of the four
+                const f32x4 dlt = a[n] - (pre4 + cpre[n]);
+                const float mxn = fmaxf(fmaxf(dlt[0], dlt[1]), fmaxf(dlt[2], dlt[3]));
+                if (!__ballot(!(mxn < 0.0f))) continue;              // wave-uniform
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float sdot = a[n][i];                          // S * dot16
@@ -170,6 +175,7 @@ __device__ __forceinline__ void tile_epilogue16_flagged(const NwkTileParams& p, 
                 }
                 wcnt += (u32)__popcll(mk);                           // wave-uniform
             }
+        }
     }
 }
 
