@@ -22,12 +22,16 @@ The JSON line also carries
                   sklearn.neighbors.NearestNeighbors(algorithm='brute') on a second sample beside it (`cpu_baseline.sklearn`);
   ranks / devices / collective -- what torch.distributed saw: world size, every rank's GPU, backend and the per-step time of the
                   all-gather and of the merge (N > 1);
-  secondary    -- N=1, default workload only: the other BASELINE configs one GPU can hold (C2; one of eight C3 shards; the C4 per-GPU
-                  slice), a few steps each with their own value / ms_per_step / roofline, on the same clock as the headline.
+  secondary    -- N=1, default workload only: the other BASELINE configs one GPU can hold (the C4 per-GPU share: all 1M queries x one
+                  12.5M-row shard; the reference's one published run, 10k x 4M x 1536, in memory and through compute_knn from a parquet
+                  file; C2; one of eight C3 shards), a few steps each with their own value / ms_per_step / roofline, on the same clock as
+                  the headline.  The block is time-boxed (SECONDARY_BUDGET_S of wall clock since process start): a leg that would not fit
+                  is reported as skipped, never silently dropped.
 """
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import socket
@@ -38,6 +42,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+T_PROCESS_START = time.perf_counter()
 
 WORKLOADS = {
     # name: (Q, B, d, k, metric, dtype, description)
@@ -49,16 +54,39 @@ WORKLOADS = {
     "c3shard": (100_000, 1_250_000, 1024, 100, "sqeuclidean", "f32", "one of eight C3 shards: 100k queries x 1.25M base rows, d=1024, k=100, fp32 (not a headline number)"),
     # BASELINE config 4 (fp16 MFMA + L2, 8 GPUs) and the piece of it one GPU sees (its 12.5M-row shard, a tenth of the queries)
     "c4": (1_000_000, 100_000_000, 1536, 100, "sqeuclidean", "f16", "C4: 1M queries x 100M base, d=1536 (ada-002 shape), k=100, fp16 MFMA sqeuclidean"),
-    "c4gpu": (100_000, 12_500_000, 1536, 100, "sqeuclidean", "f16", "C4 per-GPU slice: 100k queries x 12.5M base rows (one of 8 shards), d=1536, k=100, fp16"),
+    # under north_star's base sharding every GPU sees ALL the queries against its shard
+    "c4gpu": (1_000_000, 12_500_000, 1536, 100, "sqeuclidean", "f16", "C4 per-GPU share: all 1M queries x 12.5M base rows (one of 8 shards), d=1536, k=100, fp16 (exact fp16 mode)"),
+    "c4slice": (100_000, 12_500_000, 1536, 100, "sqeuclidean", "f16", "a tenth of the C4 per-GPU share: 100k queries x 12.5M base rows, d=1536, k=100, fp16 (rounds 1-3 quoted this; not a headline number)"),
+    # the one run the reference publishes (docs/cli.png): 10k x 4M, d=1536, k=100, fp32 sqeuclidean, RTX A5500 laptop GPU
+    "refcli": (10_000, 4_000_000, 1536, 100, "sqeuclidean", "f32", "the reference's published run (docs/cli.png): 10k queries x 4M base, d=1536, k=100, fp32 sqeuclidean"),
     # BASELINE config 5: MaxSim late interaction (an extension -- the reference's `ck` is flat token kNN): Q = queries of 32 tokens,
     # B = docs of 64 tokens, d = 128, k = 1000; FLOPs = 2 * (32 Q) * (64 B) * d
     "c5": (2_048, 1_000_000, 128, 1000, "maxsim", "f32", "C5: MaxSim, 2048 queries x 32 tokens vs 1M docs x 64 tokens, d=128, k=1000, fp32"),
     "dev5": (256, 100_000, 128, 100, "maxsim", "f32", "dev5: MaxSim 256 queries vs 100k docs (not a headline number)"),
     "dev16": (32_768, 1_048_576, 1536, 100, "sqeuclidean", "f16", "dev16: 32k x 1M, d=1536, k=100, fp16 (not a headline number)"),
 }
-SECONDARY = (("c2", 10, 2), ("c3shard", 3, 2), ("c4gpu", 2, 0))     # (workload, timed steps, timed steps of its pre-screened leg); 1 warm-up each
+# (workload, timed steps, timed steps of its pre-screened leg, queries of the one warm-up step (0: all), estimated wall seconds)
+SECONDARY = (("c4gpu", 1, 0, 50_000, 42), ("refcli", 2, 2, 0, 8), ("c2", 10, 2, 0, 4), ("c3shard", 3, 2, 0, 10))
+SECONDARY_BUDGET_S = 465.0          # wall clock since process start after which no further secondary leg is started (the driver allows 600 s)
+REF_PUBLISHED = {"knn_stage_s": 103.46, "queries_per_s": 96.7, "tflops": 1.19, "hardware": "1x NVIDIA RTX A5500 Laptop GPU 16 GB",
+                 "source": "docs/cli.png (BASELINE.md section 1): kNN stage incl. parquet load, 9 x 9 knn() calls"}
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 SEED_BASE, SEED_QUERY = 0x6E770001, 0x6E770002
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0}      # MI355X_MICROARCH.md: dense f32 / f16 MFMA peaks
+
+
+def profiler_preload() -> str:
+    """Non-empty when this process runs under rocprofv3 / rocprofiler-sdk: the tool's preloaded library initialises the GPU before main(),
+    so starting the ranks from here would be an exec from a process that has touched the GPU (forbidden on this pool: it takes the
+    machine down).  Returns what gave it away."""
+    for var in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY", "ROCP_TOOL_LIB", "HSA_TOOLS_LIB"):
+        val = os.environ.get(var, "")
+        if any(t in val.lower() for t in ("rocprof", "roctracer", "rocprofiler")):
+            return f"{var}={val}"
+    for var in os.environ:
+        if var.startswith(("ROCPROF_", "ROCPROFILER_", "ROCPROFV3_")):
+            return f"{var} is set"
+    return ""
 
 
 def self_launch(n: int) -> int:
@@ -88,9 +116,9 @@ def recorded_traffic(workload):
         return None, None
 
 
-def cpu_baseline(base_dev, queries_dev, k, metric, full_b, flop_budget=0.7e13):
+def cpu_baseline(base_dev, queries_dev, k, metric, full_b, flop_budget=0.45e13):
     """Brute force on the host cores over a bounded sample of the same workload: numpy/BLAS (the oracle's sgemm form) and, beside it,
-    scikit-learn's NearestNeighbors(algorithm='brute').  Each leg is sized to ~flop_budget of sgemm (10-20 s on a 16..64-core host)."""
+    scikit-learn's NearestNeighbors(algorithm='brute').  Each leg is sized to ~flop_budget of sgemm (~10 s on a 64-core host)."""
     import numpy as np
     from oracle import cpu_oracle
     cores = len(os.sched_getaffinity(0))
@@ -127,6 +155,72 @@ def cpu_baseline(base_dev, queries_dev, k, metric, full_b, flop_budget=0.7e13):
                                         f"{qs} x {bs} sample in {dts:.2f}s; same scaling"}
         except Exception as e:                                                    # the baseline is a report, never a reason to lose the line
             out["sklearn"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+REF_FILES_EST_S = 75               # the file leg of the reference's published run: write a 24.6 GB parquet file, run compute_knn from it
+REF_FILES_BASE_ROWS = 4_000_000
+
+
+def ref_published_block(value_qps, pre):
+    """The reference's one published figure for this path next to ours -- DIFFERENT hardware (a 16 GB laptop GPU), quoted as context."""
+    out = {"reference": REF_PUBLISHED, "ours_queries_per_s_in_memory": value_qps, "ratio_in_memory": value_qps / REF_PUBLISHED["queries_per_s"],
+           "label": "cross-hardware; the reference's figure includes its parquet load (see through_files for ours with load)"}
+    if pre:
+        out["ours_prescreened_queries_per_s"] = pre["value"]
+    return out
+
+
+def ref_cli_through_files(eng, base_rows=REF_FILES_BASE_ROWS, q_rows=10_000, d=1536, k=100):
+    """The reference's published run as its CLI does it: compute_knn(data_dir, ...) from parquet files with one float32 column per
+    dimension (cu_knn.py:151-180), load included, then merge_indices_and_distances -- what docs/cli.png times at 103.46 s + 2.02 s.
+    The synthetic source files are written first (not timed: the reference's stage 1-2 is not in its figure either), to /dev/shm when it
+    is there (no disk in the picture), 100 000-row row groups, uncompressed."""
+    import shutil
+    import tempfile
+    import numpy as np
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    import torch
+    from neighborhoodwatch_amd import cu_knn, merge
+    root = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    tmp = tempfile.mkdtemp(prefix="nwk_refcli_", dir=root)
+    out = {"data_dir": tmp, "base_rows": base_rows, "queries": q_rows, "dim": d, "k": k}
+    try:
+        t0 = time.perf_counter()
+        names = [f"embedding_{j}" for j in range(d)]
+
+        def write(fname, seed, rows):
+            writer = None
+            for r0 in range(0, rows, 100_000):
+                n = min(100_000, rows - r0)
+                cols = eng.generate(seed, r0, n, d).t().contiguous().cpu().numpy()          # [d, n]: one contiguous array per column
+                t = pa.Table.from_arrays([pa.array(cols[j]) for j in range(d)], names=names)
+                if writer is None:
+                    writer = pq.ParquetWriter(os.path.join(tmp, fname), t.schema, compression="NONE", use_dictionary=False, write_statistics=False)
+                writer.write_table(t)
+            writer.close()
+        write("base.parquet", SEED_BASE, base_rows)
+        write("query.parquet", SEED_QUERY, q_rows)
+        torch.cuda.synchronize()
+        out["write_s_not_timed"] = time.perf_counter() - t0
+        out["file_gb"] = os.path.getsize(os.path.join(tmp, "base.parquet")) / 1e9
+        for label, pre in (("direct", False), ("prescreened", True)):
+            shutil.rmtree(os.path.join(tmp, "partial"), ignore_errors=True)
+            with contextlib.redirect_stdout(sys.stderr):                 # the drivers print progress like the reference; stdout carries the JSON line only
+                t0 = time.perf_counter()
+                cu_knn.compute_knn(tmp, "synthetic", d, "query.parquet", q_rows, "base.parquet", base_rows, mem_tune=True, k=k, prescreen=pre)
+                t1 = time.perf_counter()
+                merge.merge_indices_and_distances(tmp, k)
+                t2 = time.perf_counter()
+            out[label] = {"knn_stage_s": t1 - t0, "merge_s": t2 - t1, "queries_per_s": q_rows / (t1 - t0),
+                          "pairwise_tflops": 2.0 * q_rows * base_rows * d / (t1 - t0) / 1e12,
+                          "vs_reference_knn_stage": REF_PUBLISHED["knn_stage_s"] / (t1 - t0)}
+        out["label"] = "cross-hardware (reference: RTX A5500 laptop GPU); parquet decode + PCIe upload + search + partial files, as the reference's figure"
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     return out
 
 
@@ -181,7 +275,7 @@ class Bench:
         return gathered
 
     # ---- one workload ----------------------------------------------------------------------------------------------------------------
-    def run(self, name, steps, warmup, pre_steps, metric_override=None, shard="base", verify=False, with_cpu=False):
+    def run(self, name, steps, warmup, pre_steps, metric_override=None, shard="base", verify=False, with_cpu=False, warm_queries=0):
         torch, td, eng, world, rank = self.torch, self.td, self.eng, self.world, self.rank
         from neighborhoodwatch_amd.distributed import query_sharded_search, shard_bounds, sharded_search
         Q, B, d, k, metric, dtype, desc = WORKLOADS[name]
@@ -217,33 +311,37 @@ class Bench:
         def measure(n_steps, n_warmup):
             """n_warmup untimed + n_steps timed steps, fenced on both sides; MAX over ranks of the elapsed time, SUM of the kernel accounting."""
             agg = {"tile_ms": 0.0, "tile_flops": 0.0, "tile_launches": 0, "compact_ms": 0.0, "prep_ms": 0.0, "rescan_launches": 0,
-                   "overflowed_queries": 0, "rescore_ms": 0.0, "prescreen": 0}
+                   "overflowed_queries": 0, "rescore_ms": 0.0, "prescreen": 0, "prescreen_checked": 0, "prescreen_violations": 0,
+                   "prescreen_fallbacks": 0}
+            worst = [0.0]
             coll = {}
             last = None
 
-            def step(record):
+            def step(record, qs):
                 tm = coll if record else None
                 if by_query:
-                    dist, idx = query_sharded_search(lambda qs, kk: search_shard(qs, kk, 0), queries, k, None, tm)
+                    dist, idx = query_sharded_search(lambda q_, kk: search_shard(q_, kk, 0), qs, k, None, tm)
                 else:
-                    dist, idx = sharded_search(search_shard, eng.merge, queries, k, lo, None, tm)
+                    dist, idx = sharded_search(search_shard, eng.merge, qs, k, lo, None, tm)
                 if rank == 0:
-                    host_d.copy_(dist, non_blocking=True)
-                    host_i.copy_(idx, non_blocking=True)
+                    host_d[:dist.shape[0]].copy_(dist, non_blocking=True)
+                    host_i[:idx.shape[0]].copy_(idx, non_blocking=True)
                 torch.cuda.synchronize()
                 if record:
                     s = eng.stats()
                     for key in agg:
                         agg[key] += s[key]
+                    worst[0] = max(worst[0], s["prescreen_worst"])
                 return dist, idx
 
-            for _ in range(n_warmup):
-                step(False)
+            for _ in range(n_warmup):                                  # (a warm-up on a slice of the queries, where the caller asks for one, is said so in the line)
+                step(False, queries[:warm_queries] if warm_queries else queries)
             fence()
             t0 = time.perf_counter()
             for _ in range(n_steps):
-                last = step(True)
+                last = step(True, queries)
             fence()
+            agg["prescreen_worst"] = worst[0]
             elapsed = time.perf_counter() - t0
             kernel = eng.tile_kernel_name()
             my_search_ms = agg["tile_ms"] + agg["compact_ms"] + agg["prep_ms"] + agg["rescore_ms"]      # this rank's kernel time over the timed steps
@@ -281,6 +379,25 @@ class Bench:
                     "traffic_note": "bytes per launch, rocprofv3 PMC passes recorded in profiles/ (not sampled live; quoted only when recorded on this kernel)",
                     "kernel": kernel, "launches": n_l, "avg_launch_ms": agg_["tile_ms"] / n_l, "flops_per_launch": agg_["tile_flops"] / n_l}
 
+        def invariant(agg_):
+            """The pre-screen's checked invariant over the timed steps (nwknn_stats.prescreen_*): every rescored pair's fp16 estimate held
+            against its canonical value and the bound it was pruned under."""
+            return {"checked_pairs": agg_["prescreen_checked"], "violations": agg_["prescreen_violations"], "fallbacks": agg_["prescreen_fallbacks"],
+                    "worst_error_over_bound": agg_["prescreen_worst"]}
+
+        def hbm_roofline(agg_, n_steps):
+            """The HBM-bound kernel of the path: the layout + norm pass that streams the raw rows (base shard and queries) once and writes
+            the MFMA-ready copy.  Algorithmic bytes = rows x d x (element in + element out) + 4 per row of norms, over its HIP-event time."""
+            es = 2 if dtype == "f16" else 4
+            rows = (hi - lo) + Q
+            byts = float(rows) * d * 2 * es * flop_rows + 4.0 * rows * flop_rows
+            ms = agg_["prep_ms"] / n_steps
+            ach = byts / 1e9 / (ms / 1e3) if ms > 0 else 0.0
+            return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "kernel": "nwk_prep_tiled_kernel", "bytes_per_step": byts, "ms_per_step": ms,
+                    "what": "streaming read of the raw base shard + queries, write of the prepared layout and norms (per step, HIP events)"}
+
+        flop_rows = (64 if maxsim else 1)                                     # token rows per base item
         elapsed, agg, sum_flops, sum_ms, last, kernel, coll = measure(steps, warmup)         # exactly K timed steps after W warm-up steps
         flop_mult = 32 * 64 if maxsim else 1
 
@@ -298,7 +415,7 @@ class Bench:
                     "value": Q * pre_steps / p_elapsed, "unit": "queries/s", "steps": pre_steps, "warmup": p_warm, "ms_per_step": p_elapsed / pre_steps * 1e3,
                     "pairwise_tflops": 2.0 * Q * B * d * flop_mult * pre_steps / p_elapsed / 1e12,
                     "identical_to_direct": bool(torch.equal(direct[0], p_last[0])) and bool(torch.equal(direct[1], p_last[1])),
-                    "prescreen_searches": p_agg["prescreen"],
+                    "prescreen_searches": p_agg["prescreen"], "invariant": invariant(p_agg),
                     "roofline": roofline(p_agg, p_flops, p_ms, pre_steps, p_kernel, MFMA_PEAK_TFLOPS["f16"],
                                          recorded_traffic(name + "_prescreen") if world == 1 else (None, None)),
                     "breakdown_ms_per_step": {"tile": p_agg["tile_ms"] / pre_steps, "rescore": p_agg["rescore_ms"] / pre_steps,
@@ -315,10 +432,18 @@ class Bench:
                            "parallelism": (f"query rows sharded x{world}, base replicated + RCCL all-gather of the [Q/N,k] slices" if by_query else
                                            f"base rows sharded x{world}" + (" + RCCL all-gather of [Q,k] partials + merge" if world > 1 else ""))},
                 "roofline": roofline(agg, sum_flops, sum_ms, steps, kernel, peak, recorded_traffic(name) if world == 1 else (None, None)),
+                "warmup_note": (f"the warm-up step searched the first {warm_queries} queries only (kernels, allocator and clocks warm; "
+                                f"the timed steps grow the query-side buffers once)") if warm_queries else None,
                 "breakdown_ms_per_step": {"tile": agg["tile_ms"] / steps, "compact": agg["compact_ms"] / steps,
                                           "prep": agg["prep_ms"] / steps, "rescore": agg["rescore_ms"] / steps, "rescan_launches": agg["rescan_launches"],
                                           "overflowed_queries": agg["overflowed_queries"]},
             }
+            if world == 1 and not maxsim and not agg["prescreen"]:
+                out["roofline"]["hbm"] = hbm_roofline(agg, steps)         # direct path: prep_ms is the layout pass alone
+            if agg["prescreen"]:
+                out["invariant"] = invariant(agg)
+            if out["warmup_note"] is None:
+                del out["warmup_note"]
             if coll is not None:
                 out["collective"] = coll
             if pre is not None:
@@ -353,6 +478,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prescreen", action="store_true", help="skip the second measurement (fp16 pre-screen + fp32 rescoring)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary block (C2, one C3 shard, the C4 per-GPU slice) that follows the default workload at N=1")
+    ap.add_argument("--files-base-rows", type=int, default=REF_FILES_BASE_ROWS, help="base rows of the refcli file leg (default: the reference's 4M; tests shrink it)")
+    ap.add_argument("--files", action="store_true", help="--workload refcli: also run the job through compute_knn from a synthetic parquet file (write excluded, load included)")
     ap.add_argument("--verify", action="store_true", help="compare the merged result with a single-engine search of the whole base (small workloads)")
     ap.add_argument("--metric", default=None, choices=["sqeuclidean", "one_minus_dot", "cosine"], help="override the workload's metric (dev)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option (nwknn_set_option), dev use")
@@ -360,6 +487,13 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "RANK" not in os.environ:
+        why = profiler_preload()
+        if why:
+            print(f"bench.py: refusing to start {args.gpus} ranks from under a profiler ({why}): its preloaded library has already initialised "
+                  "the GPU in this process, and starting children from here is the exec-after-GPU-init this pool forbids.  Profile ONE rank "
+                  "(`rocprofv3 ... -- python3 bench.py --gpus 1`), or the per-GPU pieces (`--workload c3shard`, `--workload c4gpu`).",
+                  file=sys.stderr, flush=True)
+            raise SystemExit(4)
         raise SystemExit(self_launch(args.gpus))              # nothing above has imported torch or touched the GPU
 
     b = Bench(args)
@@ -374,17 +508,32 @@ def main():
                 "dtype": out.pop("dtype"), "data": "synthetic (seeded counter-based embeddings in [-1,1), generated on device)",
                 "ranks": td.get_world_size() if world > 1 else 1, "devices": devices}
         line.update(out)
+    if world == 1 and args.workload == "refcli" and rank == 0:
+        line["vs_reference_published"] = ref_published_block(line["value"], line.get("exact_prescreen"))
+        if args.files:
+            line["through_files"] = ref_cli_through_files(b.eng, args.files_base_rows)
     if world == 1 and args.workload == "c3" and not args.no_secondary and not args.opt and not args.metric:
         sec = {}
-        for name, s_steps, s_pre in SECONDARY:
+        for name, s_steps, s_pre, s_warm_q, est_s in SECONDARY:
             t0 = time.perf_counter()
+            if t0 - T_PROCESS_START + est_s > SECONDARY_BUDGET_S:
+                sec[name] = {"skipped": f"time box: {t0 - T_PROCESS_START:.0f} s into the run, this leg needs ~{est_s} s and the block stops at "
+                                        f"{SECONDARY_BUDGET_S:.0f} s; run `python bench.py --workload {name}` for it"}
+                continue
             try:
-                s_out, _ = b.run(name, s_steps, 1, 0 if args.no_prescreen else s_pre)
+                s_out, _ = b.run(name, s_steps, 1, 0 if args.no_prescreen else s_pre, warm_queries=s_warm_q)
+                if name == "refcli":
+                    s_out["vs_reference_published"] = ref_published_block(s_out["value"], s_out.get("exact_prescreen"))
+                    if time.perf_counter() - T_PROCESS_START + REF_FILES_EST_S <= SECONDARY_BUDGET_S:
+                        s_out["through_files"] = ref_cli_through_files(b.eng, args.files_base_rows)
+                    else:
+                        s_out["through_files"] = {"skipped": f"time box ({REF_FILES_EST_S} s needed); run `python bench.py --workload refcli --files`"}
                 s_out["wall_s"] = time.perf_counter() - t0
                 sec[name] = s_out
             except Exception as e:                                  # a secondary figure must never cost the headline line
                 sec[name] = {"error": f"{type(e).__name__}: {e}"}
         line["secondary"] = sec
+        line["wall_s_since_process_start"] = time.perf_counter() - T_PROCESS_START
     if rank == 0:
         print(json.dumps(line), flush=True)
         if args.verify:

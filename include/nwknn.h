@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define NWKNN_ABI_VERSION 1
+#define NWKNN_ABI_VERSION 2        /* 2: nwknn_stats grew the pre-screen invariant fields */
 
 /* error codes */
 #define NWKNN_OK 0
@@ -66,8 +66,15 @@ typedef struct nwknn_stats {
     double total_ms;               /* first launch to last launch of the search */
     double tile_flops;             /* 2 * q_rows * b_rows * d summed over the distance-tile launches */
     double rescore_ms;             /* option "prescreen": sum of the fp32 rescoring kernel durations */
-    int32_t prescreen;             /* 1 when the last search ran the fp16 pre-screen + fp32 rescoring, 0 for the direct kernel */
-    int32_t reserved_;
+    int32_t prescreen;             /* 1 when the RETURNED result came from the fp16 pre-screen + fp32 rescoring, 0 for the direct kernel */
+    int32_t prescreen_fallbacks;   /* times the search was run again because the invariant below failed (fp32 data: on the direct kernel;
+                                      exact fp16 mode: under a 16x wider bound); the discarded attempts leave no trace in the result */
+    /* The pre-screen's invariant, checked on the device for EVERY pair that is rescored: the fp16 estimate a pair was listed under and its
+     * canonical fp32 value differ by no more than the error bound the tile kernel pruned with (that bound allows 4 d u for the fp16 MFMA's
+     * internal summation order, which the ISA leaves undefined -- this is where the allowance is held against the hardware). */
+    int64_t prescreen_checked;     /* pairs compared in the attempt that produced the result */
+    int64_t prescreen_violations;  /* pairs outside the bound, summed over the DISCARDED attempts (the returned result has none by construction) */
+    double prescreen_worst;        /* max |estimate - exact| / bound over the checked pairs of the returned result (< 1; ~0.05-0.3 measured) */
 } nwknn_stats;
 
 /* ---- library / device ------------------------------------------------------------------------------- */
@@ -104,6 +111,9 @@ int nwknn_set_stream(nwknn_handle h, void* hip_stream);
  * (shape and walk order of an XCD's super-tile), "upload_threads" (host threads of the column upload pipeline, default 8),
  * "upload_slab_mib" (slab size of that pipeline, default 128),
  * "pre_eps_pct" (>= 100: percent of the proven pre-screen error bound to apply; larger = more pairs rescored, same result),
+ * "pre_check_pct" (1..100, default 100: the invariant |estimate - exact| <= bound of nwknn_stats is checked against this percentage of the
+ * bound; a violation sends the search down its fallback, whose result is the same bits -- so a small value only costs time; tests use it
+ * to drive the fallback),
  * MaxSim pre-screen tile kernel, d <= 128: "ms_strip" (document tiles a workgroup of the ring kernel walks: 0 = auto, 1 = the any-d
  * kernel), "ms_rescore_valu" (1: rescoring on the vector pipes).
  * No option changes a result: every switch that does (timing ablations, in-kernel stamps, a shrunken error bound) exists only in

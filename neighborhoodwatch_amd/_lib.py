@@ -40,7 +40,8 @@ class NwknnStats(ctypes.Structure):
         ("tile_launches", c_int32), ("compact_launches", c_int32), ("rescan_launches", c_int32),
         ("overflowed_queries", c_int32),
         ("tile_ms", c_double), ("compact_ms", c_double), ("prep_ms", c_double), ("total_ms", c_double),
-        ("tile_flops", c_double), ("rescore_ms", c_double), ("prescreen", c_int32), ("reserved_", c_int32),
+        ("tile_flops", c_double), ("rescore_ms", c_double), ("prescreen", c_int32), ("prescreen_fallbacks", c_int32),
+        ("prescreen_checked", c_int64), ("prescreen_violations", c_int64), ("prescreen_worst", c_double),
     ]
 
     def as_dict(self) -> dict:

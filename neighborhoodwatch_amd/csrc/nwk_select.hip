@@ -11,6 +11,18 @@
 //      (the sentinel compaction already sorts last).
 #define RS_QC 1024                    // query elements staged in LDS at a time (4 KiB per wave)
 
+// |estimate - canonical distance| of a listed pair is at most this: the bound E(q,b) the tile kernel pruned under (DESIGN.md "Bound"),
+// taken to the distance domain, plus the roundings of the estimate and of these lines themselves.
+template <int METRIC>
+__device__ __forceinline__ float rescore_err(const NwkRescoreParams& p, float row_err, float qn, float bn, float est)
+{
+    float err = row_err + p.eps_half * bn + p.aq * __builtin_amdgcn_sqrtf(bn);          // >= |dot16 - dot32|
+    if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) err = 2.0f * err;
+    if (METRIC == NWKNN_METRIC_COSINE) err = err * 1.0001f + 2.0e-6f * (fabsf(est) + 1.0f);
+    else err = err * 1.0001f + 2.0e-6f * (fabsf(est) + qn + bn + 1.0f);                  // roundings of est and of these lines
+    return err;
+}
+
 template <int METRIC, bool ROWS16>
 __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams p)
 {
@@ -29,8 +41,8 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
     u64* list = p.buf + q * p.cap;
 
     u32 nsurv = 0;
+    const float row_err = p.eps_half * qn + p.ab * __builtin_amdgcn_sqrtf(qn) + p.cst;
     if (p.prune && end >= (u32)p.k) {
-        const float row_err = p.eps_half * qn + p.ab * __builtin_amdgcn_sqrtf(qn) + p.cst;
         for (u32 e0 = 0; e0 < end; e0 += 64) {
             const u32 e = e0 + lane;
             if (e < end) {
@@ -40,10 +52,7 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
                 else {
                     const float est = __uint_as_float((u32)(key >> 32));
                     const float bn = p.bn[(u32)key];
-                    float err = row_err + p.eps_half * bn + p.aq * __builtin_amdgcn_sqrtf(bn);          // >= |dot16 - dot32|
-                    if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) err = 2.0f * err;
-                    if (METRIC == NWKNN_METRIC_COSINE) err = err * 1.0001f + 2.0e-6f * (fabsf(est) + 1.0f);
-                    else err = err * 1.0001f + 2.0e-6f * (fabsf(est) + qn + bn + 1.0f);  // roundings of est and of these lines
+                    const float err = rescore_err<METRIC>(p, row_err, qn, bn, est);
                     float ub = est + err;
                     if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ub = fmaxf(ub, 0.0f);       // the canonical distance is clamped at 0
                     u32 sub = sortable_u32(ub), slb = sortable_u32(est - err);
@@ -95,6 +104,11 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
     char* const s_q = (char*)(rs_dyn + (size_t)wpb * 2 * p.cap) + (size_t)wv * RS_QC * 4;
     const char* const qbytes = ROWS16 ? (const char*)qrow16 : (const char*)qrow;
     const int line_elems = 128 / ES;                                    // 32 floats or 64 halves; dp is a multiple of it
+    // The invariant behind the pre-screen, checked on every pair that is rescored: the estimate the tile kernel listed the pair under and
+    // the canonical value computed here differ by no more than the bound the tile kernel pruned with.  The bound allows 4 d u for the fp16
+    // MFMA's internal summation, whose order the ISA does not define; this is where that allowance is held against the hardware.
+    u32 n_chk = 0, n_bad = 0;                                           // wave-uniform
+    float worst = 0.0f;                                                 // per lane: max |estimate - exact| / bound
     for (u32 i0 = 0; i0 < nsurv; i0 += 64) {
         const u32 i = i0 + lane;
         const bool live = i < nsurv;
@@ -153,8 +167,31 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
             }
             if (nl & 1) chain_line(la, (nl - 1) * line_elems);
         }
-        const float dist = distance_epilogue<METRIC>(acc, qn, p.bn[col]);
+        const float bnc = p.bn[col];
+        const float dist = distance_epilogue<METRIC>(acc, qn, bnc);
         if (valid) list[e] = ((u64)sortable_u32(dist) << 32) | col;
+        {
+            const float est = __uint_as_float((u32)(old >> 32));
+            const float err = rescore_err<METRIC>(p, row_err, qn, bnc, est);
+            bool judged = valid;
+            if (METRIC == NWKNN_METRIC_COSINE) judged = judged && cosine_norm_ok(qn) && cosine_norm_ok(bnc);    // degenerate rows carry no estimate
+            const bool clamped = METRIC == NWKNN_METRIC_SQEUCLIDEAN && dist == 0.0f && est < 0.0f;              // the canonical distance is clamped at 0
+            const float dev = clamped ? 0.0f : fabsf(dist - est);
+            const bool bad = judged && !(dev <= err * p.chk_scale);    // NaN counts as a violation
+            n_chk += (u32)__popcll(__ballot(judged));
+            n_bad += (u32)__popcll(__ballot(bad));
+            const float ratio = dev / err;
+            if (judged) worst = fmaxf(worst, ratio == ratio ? ratio : __builtin_inff());
+        }
+    }
+    if (p.chk) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) worst = fmaxf(worst, __shfl_xor(worst, o));
+        if (lane == 0 && n_chk) {
+            atomicAdd(p.chk, (u64)n_chk);
+            if (n_bad) atomicAdd(p.chk + 1, (u64)n_bad);
+            atomicMax((u32*)(p.chk + 2), __float_as_uint(worst));       // non-negative floats order like their bit patterns
+        }
     }
 }
 

@@ -124,9 +124,9 @@ struct nwknn_ctx {
     long long nb_pad_for_copy = 0;
     int dp_for_copy = 0;
     // running top-k state
-    DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i, ctab;
+    DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i, ctab, chk;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 0, opt_f16_agg = -1, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 0, opt_f16_agg = -1, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128, opt_pre_check_pct = 100;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -253,7 +253,7 @@ extern "C" int nwknn_destroy(nwknn_handle h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->bp, &h->bn, &h->braw, &h->qraw, &h->qp, &h->qn, &h->tau, &h->cnt, &h->buf, &h->ovf, &h->ovf_any, &h->qtiles,
-                      &h->out_d, &h->out_i, &h->mrg_d, &h->mrg_i, &h->ctab, &h->bp16, &h->qp16, &h->cnt0, &h->scal, &h->ms_rq, &h->ms_cd, &h->ms_surv, &h->ms_nsurv})
+                      &h->out_d, &h->out_i, &h->mrg_d, &h->mrg_i, &h->ctab, &h->chk, &h->bp16, &h->qp16, &h->cnt0, &h->scal, &h->ms_rq, &h->ms_cd, &h->ms_surv, &h->ms_nsurv})
         b->release();
     for (EvPair& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (int i = 0; i < 2; ++i) {
@@ -331,6 +331,11 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
         // scales the pre-screen error bound.  Results are guaranteed at >= 100 only: smaller values exist in developer builds
         if (value < 0 || value > 100000) return fail(NWKNN_EINVAL, "pre_eps_pct must be 100..100000 (percent of the proven bound)");
         h->opt_pre_eps_pct = value;
+    } else if (!strcmp(name, "pre_check_pct")) {
+        // the invariant |estimate - exact| <= bound is checked against this share of the bound.  No value changes a result: a violation
+        // sends the search down its fallback, which returns the same bits
+        if (value < 1 || value > 100) return fail(NWKNN_EINVAL, "pre_check_pct must be 1..100 (percent of the pre-screen bound the invariant is checked against)");
+        h->opt_pre_check_pct = value;
     } else if (!strcmp(name, "f16_mfma")) {
         if (value != -1 && value != 1 && value != 3 && value != 4) return fail(NWKNN_EINVAL, "f16_mfma must be -1 (auto), 1 (burst form), 3 (streaming form) or 4 (ping-pong form)");
         h->opt_f16_shape = value;
@@ -802,6 +807,8 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         rp.prune = (h->opt_pre_prune && !dedupe && !dense) ? 1 : 0;
         rp.rows16 = pl.native16 ? 1 : 0;
         rp.eps_half = pl.pre_eps_half; rp.aq = pl.pre_aq; rp.ab = pl.pre_ab; rp.cst = pl.pre_cst;
+        rp.chk_scale = (float)h->opt_pre_check_pct / 100.0f;
+        rp.chk = h->chk.as<u64>();
         e = ev_begin(h, 3);
         HIPCHK(nwk_launch_rescore(h->stream, rp, metric, nq_pad));
         ev_end(h, e);
@@ -879,9 +886,13 @@ static int repair(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long lo
     return NWKNN_OK;
 }
 
-static int search_common(nwknn_ctx* h, const void* queries, const ColumnSource* qcolumns, int64_t nq, int dtype, int location, int32_t k, int metric,
-                         int64_t index_offset, float* out_dist, int64_t* out_idx, int out_location)
+// One attempt of a search.  attempt 0 is the search as configured.  A later attempt follows a pre-screened one whose invariant failed
+// (*violations > 0 on return: nothing was written to the outputs): fp32 data then runs the direct kernel; exact fp16 mode, whose
+// rows have no fp32 form, widens its bound 16x per attempt and is checked again.
+static int search_attempt(nwknn_ctx* h, const void* queries, const ColumnSource* qcolumns, int64_t nq, int dtype, int location, int32_t k, int metric,
+                          int64_t index_offset, float* out_dist, int64_t* out_idx, int out_location, int attempt, long long* violations)
 {
+    *violations = 0;
     if (!h || (!queries && !qcolumns) || !out_dist || !out_idx) return fail(NWKNN_EINVAL, "nwknn_search: null argument");
     if (!h->bp.p || h->nb <= 0) return fail(NWKNN_ESTATE, "nwknn_search: call nwknn_set_base first");
     if (h->ms_docs > 0) return fail(NWKNN_ESTATE, "nwknn_search: the handle holds MaxSim documents; call nwknn_set_base for kNN");
@@ -894,7 +905,8 @@ static int search_common(nwknn_ctx* h, const void* queries, const ColumnSource* 
     if ((location != NWKNN_HOST && location != NWKNN_DEVICE) || (out_location != NWKNN_HOST && out_location != NWKNN_DEVICE))
         return fail(NWKNN_EINVAL, "nwknn_search: bad location");
     RCCHK(use_device(h));
-    bool pre = h->pre_ok && !h->f16;
+    bool pre = h->pre_ok && !h->f16 && attempt == 0;
+    const double widen = std::pow(16.0, (double)attempt);        // exact fp16 mode after a failed invariant
     // exact fp16 mode (fp16 compute path, option f16_exact): the fp16 MFMA kernel pre-screens, every listed pair is rescored with
     // the fp32 chain over the fp16 values.  (Cosine pre-screens on unit-row copies of the fp16 rows.)
     bool native16 = h->f16 && h->opt_f16_exact && h->f16_finite;
@@ -967,7 +979,7 @@ static int search_common(nwknn_ctx* h, const void* queries, const ColumnSource* 
             // the canonical chain (d u) and the MFMA's own (allowed 4 d u, measured ~2 u), 2 % slack
             pl.pre = true; pl.native16 = true;
             pl.pre_scale = 1.0f;
-            pl.pre_eps_half = (float)(0.5 * 1.02 * 5.5 * dd * u * (double)h->opt_pre_eps_pct / 100.0);
+            pl.pre_eps_half = (float)(0.5 * 1.02 * 5.5 * dd * u * (double)h->opt_pre_eps_pct / 100.0 * widen);
             pl.pre_aq = pl.pre_ab = pl.pre_cst = 0.0f;
             pl.copies16 = false;
             if (metric == NWKNN_METRIC_COSINE) {           // unit-row copies of both sides; the constant bound of the fp32-data cosine path
@@ -981,13 +993,15 @@ static int search_common(nwknn_ctx* h, const void* queries, const ColumnSource* 
                 pl.pre_scale = NWK_COS_SCALE * NWK_COS_SCALE;
                 pl.pre_eps_half = 0.f;
                 pl.pre_cst = (float)((1.02 * (0x1p-10 * (1.0 + 0x1p-11) + 7.5 * dd * u + 16.0 * u) + 2.02 * a * sd + (double)h->d * a * a)
-                                     * (double)h->opt_pre_eps_pct / 100.0);
+                                     * (double)h->opt_pre_eps_pct / 100.0 * widen);
             }
         } else {
             native16 = false;
         }
     }
     if (pl.pre) {                                                  // the column term of every base row under this search's constants (ping-pong kernel)
+        RCCHK(h->chk.ensure(32));
+        HIPCHK(hipMemsetAsync(h->chk.p, 0, 32, h->stream));
         RCCHK(h->ctab.ensure((size_t)h->nb_pad * 4));
         NwkTileParams tp = tile_params(h, pl, nq_pad);
         tp.pre_inv_scale = 1.0f / pl.pre_scale;
@@ -1020,6 +1034,17 @@ static int search_common(nwknn_ctx* h, const void* queries, const ColumnSource* 
     HIPCHK(hipMemcpyAsync(&any, h->ovf_any.p, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (any) RCCHK(repair(h, pl, metric, k, nq_pad));
+    if (pl.pre) {                                                  // the invariant of the pre-screen, counted by every rescoring launch
+        u64 chk[3] = {0, 0, 0};
+        HIPCHK(hipMemcpyAsync(chk, h->chk.p, sizeof chk, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->stats.prescreen_checked = (int64_t)chk[0];
+        float w;
+        const u32 wb = (u32)chk[2];
+        memcpy(&w, &wb, 4);
+        h->stats.prescreen_worst = (double)w;
+        if (chk[1] != 0) { *violations = (long long)chk[1]; return NWKNN_OK; }      // this attempt is discarded by the caller
+    }
 
     float* od = out_dist;
     long long* oi = (long long*)out_idx;
@@ -1044,6 +1069,26 @@ static int search_common(nwknn_ctx* h, const void* queries, const ColumnSource* 
         h->base_prep_ms = 0.0;
     }
     return NWKNN_OK;
+}
+
+static int search_common(nwknn_ctx* h, const void* queries, const ColumnSource* qcolumns, int64_t nq, int dtype, int location, int32_t k, int metric,
+                         int64_t index_offset, float* out_dist, int64_t* out_idx, int out_location)
+{
+    long long discarded = 0;
+    for (int attempt = 0;; ++attempt) {
+        long long bad = 0;
+        RCCHK(search_attempt(h, queries, qcolumns, nq, dtype, location, k, metric, index_offset, out_dist, out_idx, out_location, attempt, &bad));
+        if (bad == 0) {
+            h->stats.prescreen_fallbacks = attempt;
+            h->stats.prescreen_violations = discarded;
+            return NWKNN_OK;
+        }
+        discarded += bad;
+        fprintf(stderr, "libnwknn: pre-screen invariant failed on %lld of %lld rescored pairs (|estimate - exact| above %lld %% of the bound): "
+                        "attempt %d discarded, searching again %s\n", bad, (long long)h->stats.prescreen_checked, (long long)h->opt_pre_check_pct,
+                attempt, h->f16 ? "under a 16x wider bound" : "on the direct fp32 kernel");                                  // never silent
+        if (attempt >= 3) return fail(NWKNN_EHIP, "pre-screen invariant still violated after widening the bound %d times (%lld pairs)", attempt, bad);
+    }
 }
 
 extern "C" int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int dtype, int location, int32_t k, int metric, int64_t index_offset,

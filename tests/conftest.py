@@ -13,6 +13,28 @@ GOLDEN = Path(__file__).resolve().parent / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "drives_fallback: the test provokes the pre-screen's fallback on purpose (the invariant hook below stands aside)")
+
+
+@pytest.fixture(autouse=True)
+def _prescreen_invariant_holds_after_every_search(request, monkeypatch):
+    """Every kNN search of every GPU test: the invariant behind the fp16 pre-screen (|estimate - exact| <= the bound pairs were pruned
+    under, counted on the device over all rescored pairs: nwknn_stats.prescreen_*) must have held -- no violation, no fallback."""
+    if "gpu" not in request.keywords or request.node.get_closest_marker("drives_fallback"):
+        yield
+        return
+    from neighborhoodwatch_amd import engine as E
+
+    def checked(orig):
+        def call(self, *a, **kw):
+            out = orig(self, *a, **kw)
+            st = self.stats()
+            assert st["prescreen_violations"] == 0 and st["prescreen_fallbacks"] == 0 and st["prescreen_worst"] < 1.0, st
+            return out
+        return call
+    monkeypatch.setattr(E.KnnEngine, "search", checked(E.KnnEngine.search))
+    monkeypatch.setattr(E.KnnEngine, "search_columns", checked(E.KnnEngine.search_columns))
+    yield
 
 
 @pytest.fixture(scope="session")

@@ -23,7 +23,7 @@ def test_header_and_library_agree():
     for name in names:
         assert hasattr(L, name), f"{name} declared in include/nwknn.h but not exported by libnwknn.so"
     assert sorted(_lib.EXPORTS) == names
-    assert L.nwknn_version() == 1
+    assert L.nwknn_version() == 2
     out = ctypes.string_at(L.nwknn_last_error())
     assert isinstance(out, bytes)
 

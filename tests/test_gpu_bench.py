@@ -43,13 +43,19 @@ def test_bench_line_has_the_contract_fields():
     assert pre["roofline"]["kernel"] == "nwk_tile_kernel_f16p<0,1,0>"
     assert b["ranks"] == 1 and len(b["devices"]) == 1 and b["devices"][0]["rank"] == 0 and "gfx950" in b["devices"][0]["gcn_arch"]
     assert "collective" not in b and "secondary" not in b                  # N = 1, not the default workload
+    hbm = rf["hbm"]                                                         # north_star: achieved HBM GB/s on the streaming base read (the layout pass)
+    assert hbm["bound"] == "hbm" and hbm["unit"] == "GB/s" and hbm["peak"] == 8000.0 and 0.0 < hbm["frac"] < 1.0 and hbm["kernel"] == "nwk_prep_tiled_kernel"
+    inv = pre["invariant"]                                                  # every rescored pair held against the bound it was pruned under
+    assert inv["violations"] == 0 and inv["fallbacks"] == 0 and inv["checked_pairs"] > 0 and 0.0 < inv["worst_error_over_bound"] < 1.0
 
 
 @pytest.mark.gpu
 def test_default_workload_carries_the_other_baseline_configs():
-    """The default (C3) line at N = 1 ends with a bounded `secondary` block: C2, one of eight C3 shards and the C4 per-GPU slice, each
-    with its own value / ms_per_step / roofline (kernel, achieved, peak, frac).  One timed step here; the driver runs 20."""
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+    """The default (C3) line at N = 1 ends with a time-boxed `secondary` block: the C4 per-GPU share (all 1M queries x one 12.5M-row shard),
+    the reference's one published run (10k x 4M x 1536: in memory, and through compute_knn from a parquet file -- shrunk to 200k base
+    rows here, the driver runs the 4M), C2 and one of eight C3 shards, each with its own value / ms_per_step / roofline (kernel,
+    achieved, peak, frac).  One timed step here; the driver runs 20."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--files-base-rows", "200000"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = _json_lines(r.stdout)
@@ -58,8 +64,9 @@ def test_default_workload_carries_the_other_baseline_configs():
     assert b["metric"].startswith("queries/sec + pairwise-dist TFLOP/s, 100k x 10M") and b["config"]["base_rows"] == 10_000_000
     assert b["exact_prescreen"]["identical_to_direct"] is True
     sec = b["secondary"]
-    assert sorted(sec) == ["c2", "c3shard", "c4gpu"]
-    for name, peak, kernel in (("c2", 157.3, "nwk_tile_kernel<"), ("c3shard", 157.3, "nwk_tile_kernel<"), ("c4gpu", 2500.0, "nwk_tile_kernel_f16")):
+    assert sorted(sec) == ["c2", "c3shard", "c4gpu", "refcli"]
+    for name, peak, kernel in (("c2", 157.3, "nwk_tile_kernel<"), ("c3shard", 157.3, "nwk_tile_kernel<"), ("c4gpu", 2500.0, "nwk_tile_kernel_f16"),
+                               ("refcli", 157.3, "nwk_tile_kernel<")):
         s = sec[name]
         assert "error" not in s, s
         assert s["value"] > 0 and s["ms_per_step"] > 0 and s["unit"] == "queries/s" and s["steps"] >= 1
@@ -67,6 +74,18 @@ def test_default_workload_carries_the_other_baseline_configs():
         assert rf["peak"] == peak and rf["kernel"].startswith(kernel) and 0.0 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / peak) < 1e-9
     assert sec["c2"]["exact_prescreen"]["identical_to_direct"] is True and sec["c3shard"]["exact_prescreen"]["identical_to_direct"] is True
     assert sec["c4gpu"]["dtype"] == "f16" and sec["c2"]["config"]["base_rows"] == 1_000_000
+    c4 = sec["c4gpu"]                                                       # one GPU's REAL share of config 4: every query, its shard
+    assert c4["config"]["queries"] == 1_000_000 and c4["config"]["base_rows"] == 12_500_000 and c4["config"]["dim"] == 1536
+    assert c4["invariant"]["violations"] == 0 and c4["invariant"]["fallbacks"] == 0 and c4["invariant"]["checked_pairs"] > 100_000_000
+    assert c4["breakdown_ms_per_step"]["overflowed_queries"] == 0 and "50000 queries" in c4["warmup_note"]
+    ref = sec["refcli"]
+    assert ref["config"]["queries"] == 10_000 and ref["config"]["base_rows"] == 4_000_000 and ref["exact_prescreen"]["identical_to_direct"] is True
+    pub = ref["vs_reference_published"]
+    assert pub["reference"]["knn_stage_s"] == 103.46 and "cross-hardware" in pub["label"] and pub["ratio_in_memory"] > 1.0
+    tf = ref["through_files"]
+    assert "error" not in tf and tf["base_rows"] == 200_000 and tf["direct"]["knn_stage_s"] > 0 and tf["prescreened"]["knn_stage_s"] > 0
+    assert b["roofline"]["hbm"]["achieved"] > 1000.0                        # the layout pass over 41 GB of base: TB/s, not GB/s
+    assert b["wall_s_since_process_start"] < 465.0
 
 
 @pytest.mark.gpu

@@ -158,3 +158,23 @@ def test_exact_mode_on_either_kernel_form(oracle, metric, form):
         assert eng.tile_kernel_name().startswith({1: "nwk_tile_kernel_f16s", 3: "nwk_tile_kernel_f16p", 4: "nwk_tile_kernel_f16x"}[form])
     rd, ri = oracle.knn_canonical(base16.astype(np.float32), queries16.astype(np.float32), 20, metric)
     assert np.array_equal(idx, ri) and _bitwise(dist, rd)
+
+
+@pytest.mark.drives_fallback
+@pytest.mark.parametrize("metric", EXACT)
+def test_a_failed_invariant_widens_the_bound_and_keeps_the_bits(oracle, metric, capfd):
+    """Exact fp16 mode has no fp32 rows to fall back to: a failed invariant (provoked with pre_check_pct = 1) makes the search run again
+    under a 16x wider bound per attempt, each attempt checked in turn; the result is the canonical one."""
+    from neighborhoodwatch_amd import KnnEngine
+    rng = np.random.default_rng(5)
+    base16 = rng.standard_normal((30000, 320)).astype(np.float16)
+    queries16 = rng.standard_normal((200, 320)).astype(np.float16)
+    rd, ri = oracle.knn_canonical(base16.astype(np.float32), queries16.astype(np.float32), 40, metric)
+    with KnnEngine(0) as eng:
+        eng.set_base(base16)
+        eng.set_option("pre_check_pct", 1)
+        dist, idx = eng.search(queries16, 40, metric)
+        st = eng.stats()
+        assert st["prescreen"] == 1 and 1 <= st["prescreen_fallbacks"] <= 3 and st["prescreen_violations"] > 0, st
+        assert np.array_equal(idx, ri) and _bitwise(dist, rd)
+        assert "16x wider bound" in capfd.readouterr().err

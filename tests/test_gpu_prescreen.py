@@ -342,3 +342,41 @@ def test_removed_fp16_builds_are_refused(removed):
     with KnnEngine(0) as eng:
         with pytest.raises(ValueError, match="f16_mfma"):
             eng.set_option("f16_mfma", removed)
+
+
+def test_the_invariant_is_counted_on_every_rescored_pair(pre_engine, oracle):
+    """nwknn_stats.prescreen_checked / _violations / _worst: every pair the rescoring kernel recomputes is compared with the estimate
+    it was listed under.  On real hardware the fp16 MFMA's summation stays far inside the 4 d u the bound allows for it."""
+    base, queries = oracle.gen(0x91, 0, 60000, 512), oracle.gen(0x92, 0, 700, 512)
+    pre_engine.set_base(base)
+    for metric in ADDITIVE:
+        pre_engine.search(queries, 100, metric)
+        st = pre_engine.stats()
+        assert st["prescreen"] == 1 and st["prescreen_checked"] > 700 * 100 and st["prescreen_violations"] == 0 and st["prescreen_fallbacks"] == 0
+        assert 0.0 < st["prescreen_worst"] < 0.9, (metric, st["prescreen_worst"])
+
+
+@pytest.mark.drives_fallback
+@pytest.mark.parametrize("metric", ADDITIVE)
+def test_a_failed_invariant_sends_the_search_to_the_direct_kernel_same_bits(oracle, metric, capfd):
+    """Option pre_check_pct = 1 holds the invariant against 1 % of the bound: real pairs exceed that, the attempt is discarded, the
+    search runs again on the direct fp32 kernel and says so -- and the result is the canonical one, bit for bit."""
+    from neighborhoodwatch_amd import KnnEngine
+    base, queries = oracle.gen(0x93, 0, 40000, 384), oracle.gen(0x94, 0, 300, 384)
+    rd, ri = oracle.knn_canonical(base, queries, 50, metric)
+    with KnnEngine(0) as eng:
+        eng.set_prescreen(True)
+        eng.set_base(base)
+        eng.set_option("pre_check_pct", 1)
+        dist, idx = eng.search(queries, 50, metric)
+        st = eng.stats()
+        assert st["prescreen"] == 0 and st["prescreen_fallbacks"] == 1 and st["prescreen_violations"] > 0, st
+        assert np.array_equal(idx, ri) and _bitwise(dist, rd)
+        assert "pre-screen invariant failed" in capfd.readouterr().err
+        eng.set_option("pre_check_pct", 100)
+        dist, idx = eng.search(queries, 50, metric)
+        st = eng.stats()
+        assert st["prescreen"] == 1 and st["prescreen_fallbacks"] == 0 and st["prescreen_violations"] == 0
+        assert np.array_equal(idx, ri) and _bitwise(dist, rd)
+        with pytest.raises(ValueError):
+            eng.set_option("pre_check_pct", 0)

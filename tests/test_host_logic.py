@@ -339,3 +339,31 @@ def test_fixed_size_list_embedding_column(tmp_path):
     kind, cols = cu_knn.table_input(pq.read_table(synth.write_source_parquet(str(tmp_path / "c.parquet"), 5, 20, 8)).select(
         [f"embedding_{i}" for i in range(8)]))
     assert kind == "columns" and len(cols) == 8                                    # the reference's layout still takes the column path
+
+
+@pytest.mark.parametrize("env", [{"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so"}, {"ROCPROF_OUTPUT_PATH": "/tmp/x"},
+                                 {"ROCP_TOOL_LIBRARIES": "/opt/rocm/lib/rocprofiler-sdk/librocprofv3-list-avail.so"}])
+def test_bench_does_not_start_ranks_from_under_a_profiler(env):
+    """`rocprofv3 ... -- python3 bench.py --gpus N`: the profiler's preloaded library has initialised the GPU before main(), so starting
+    the N ranks from that process is the exec-after-GPU-init the pool forbids.  bench.py sees the preload and refuses (exit 4) before
+    anything is started; without the preload it would go on to start the ranks (not done here: no GPU)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    sys.path.insert(0, str(root))
+    import bench
+    old = {k: os.environ.get(k) for k in env}
+    try:
+        os.environ.update(env)
+        assert bench.profiler_preload()
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    assert bench.profiler_preload() == ""
+    if "LD_PRELOAD" in env:
+        return                                     # (a missing preload library would only add loader noise to the child below)
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--workload", "dev"], env={**os.environ, **env},
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 4 and "refusing to start 2 ranks from under a profiler" in r.stderr and r.stdout == ""
