@@ -158,7 +158,7 @@ def cpu_baseline(base_dev, queries_dev, k, metric, full_b, flop_budget=0.45e13):
     return out
 
 
-REF_FILES_EST_S = 75               # the file leg of the reference's published run: write a 24.6 GB parquet file, run compute_knn from it
+REF_FILES_EST_S = 45               # the file leg of the reference's published run: write a 24.6 GB parquet file, run compute_knn from it
 REF_FILES_BASE_ROWS = 4_000_000
 
 
@@ -207,6 +207,7 @@ def ref_cli_through_files(eng, base_rows=REF_FILES_BASE_ROWS, q_rows=10_000, d=1
         out["file_gb"] = os.path.getsize(os.path.join(tmp, "base.parquet")) / 1e9
         for label, pre in (("direct", False), ("prescreened", True)):
             shutil.rmtree(os.path.join(tmp, "partial"), ignore_errors=True)
+            os.makedirs(os.path.join(tmp, "partial"))                    # the CLI creates it (nw_utils.py:67-73)
             with contextlib.redirect_stdout(sys.stderr):                 # the drivers print progress like the reference; stdout carries the JSON line only
                 t0 = time.perf_counter()
                 cu_knn.compute_knn(tmp, "synthetic", d, "query.parquet", q_rows, "base.parquet", base_rows, mem_tune=True, k=k, prescreen=pre)
@@ -275,7 +276,7 @@ class Bench:
         return gathered
 
     # ---- one workload ----------------------------------------------------------------------------------------------------------------
-    def run(self, name, steps, warmup, pre_steps, metric_override=None, shard="base", verify=False, with_cpu=False, warm_queries=0):
+    def run(self, name, steps, warmup, pre_steps, metric_override=None, shard="base", verify=False, with_cpu=False, warm_queries=0, pre_shard="auto"):
         torch, td, eng, world, rank = self.torch, self.td, self.eng, self.world, self.rank
         from neighborhoodwatch_amd.distributed import query_sharded_search, shard_bounds, sharded_search
         Q, B, d, k, metric, dtype, desc = WORKLOADS[name]
@@ -295,12 +296,14 @@ class Bench:
         host_d = torch.empty((Q, k), dtype=torch.float32).pin_memory() if rank == 0 else None
         host_i = torch.empty((Q, k), dtype=torch.int64).pin_memory() if rank == 0 else None
 
+        ctx = {"base": base_raw, "lo": lo, "by_query": by_query}       # what the current leg searches (the pre-screened leg may re-shard)
+
         def search_shard(qs, kk, offset):
             if maxsim:
-                eng.maxsim_set_docs(base_raw)
+                eng.maxsim_set_docs(ctx["base"])
                 score, doc = eng.maxsim_search(qs, kk, doc_offset=offset)
                 return -score, doc                                    # ranked like distances through the shared merge
-            eng.set_base(base_raw)                                    # layout + norms are part of every job
+            eng.set_base(ctx["base"])                                 # layout + norms are part of every job
             return eng.search(qs, kk, metric, index_offset=offset)
 
         def fence():
@@ -319,10 +322,10 @@ class Bench:
 
             def step(record, qs):
                 tm = coll if record else None
-                if by_query:
+                if ctx["by_query"]:
                     dist, idx = query_sharded_search(lambda q_, kk: search_shard(q_, kk, 0), qs, k, None, tm)
                 else:
-                    dist, idx = sharded_search(search_shard, eng.merge, qs, k, lo, None, tm)
+                    dist, idx = sharded_search(search_shard, eng.merge, qs, k, ctx["lo"], None, tm, self.args.merge)
                 if rank == 0:
                     host_d[:dist.shape[0]].copy_(dist, non_blocking=True)
                     host_i[:idx.shape[0]].copy_(idx, non_blocking=True)
@@ -352,11 +355,14 @@ class Bench:
                 fl = torch.tensor([agg["tile_flops"], agg["tile_ms"]], dtype=torch.float64, device=self.red_dev)
                 td.all_reduce(fl, op=td.ReduceOp.SUM)
                 sum_flops, sum_ms = float(fl[0]), float(fl[1])
-                cm = torch.tensor([coll.get("allgather_ms", 0.0), coll.get("merge_ms", 0.0)], dtype=torch.float64, device=self.red_dev)
+                cm = torch.tensor([coll.get("allgather_ms", 0.0), coll.get("merge_ms", 0.0), coll.get("slices_ms", 0.0)], dtype=torch.float64, device=self.red_dev)
                 td.all_reduce(cm, op=td.ReduceOp.MAX)
                 per_rank = [None] * world
                 td.all_gather_object(per_rank, round(my_search_ms / n_steps, 3))
-                coll = {"backend": self.backend, "allgather_ms": float(cm[0]) / n_steps, "merge_ms": float(cm[1]) / n_steps,
+                coll = {"kind": "torch.distributed (one process per GPU)", "backend": self.backend,
+                        "sharding": "query rows (base replicated): one all-gather of the [Q/N,k] slices, nothing to merge" if ctx["by_query"] else
+                                    f"base rows: all-gather of the [Q,k] partial lists, merge {'of its query slice on every rank + all-gather of the slices' if self.args.merge == 'slice' else 'of all rows on every rank'}",
+                        "allgather_ms": float(cm[0]) / n_steps, "merge_ms": float(cm[1]) / n_steps, "slices_allgather_ms": float(cm[2]) / n_steps,
                         "rank_kernel_ms_per_step": per_rank,             # shard searches, rank by rank: the load balance behind the max-over-ranks time
                         "allgather_bytes_per_rank": coll.get("allgather_bytes", 0),
                         "timing": "per step, max over ranks; all-gather: HIP events on the rank's current stream (RCCL) or host clock "
@@ -405,9 +411,20 @@ class Bench:
         pre = None
         if dtype == "f32" and pre_steps > 0 and not any("prescreen" in o for o in self.args.opt):
             direct = (last[0].clone(), last[1].clone()) if rank == 0 else None
+            # N > 1: the pre-screened walk has as many launches per shard as per whole base (its early, survivor-dense chunks do not shrink
+            # with the shard: DESIGN.md section 7), so this leg shards the QUERY rows when the whole base and its fp16 copy fit one GPU --
+            # no merge, linear in N.  --shard-prescreen base keeps the base sharding of the headline leg.
+            fits = float(B) * d * 10 < 0.8 * torch.cuda.get_device_properties(self.dev_index).total_memory
+            want_q = world > 1 and not ctx["by_query"] and (pre_shard == "queries" or (pre_shard == "auto" and fits))
+            if want_q:
+                ctx["base"] = None
+                del base_raw
+                torch.cuda.empty_cache()
+                base_raw = ctx["base"] = eng.generate(SEED_BASE, 0, B, d, dtype)
+                ctx["lo"], ctx["by_query"] = 0, True
             eng.set_prescreen(True)
             p_warm = min(warmup, 1)
-            p_elapsed, p_agg, p_flops, p_ms, p_last, p_kernel, _ = measure(pre_steps, p_warm)
+            p_elapsed, p_agg, p_flops, p_ms, p_last, p_kernel, p_coll = measure(pre_steps, p_warm)
             eng.set_prescreen(False)
             if rank == 0:
                 pre = {
@@ -415,7 +432,7 @@ class Bench:
                     "value": Q * pre_steps / p_elapsed, "unit": "queries/s", "steps": pre_steps, "warmup": p_warm, "ms_per_step": p_elapsed / pre_steps * 1e3,
                     "pairwise_tflops": 2.0 * Q * B * d * flop_mult * pre_steps / p_elapsed / 1e12,
                     "identical_to_direct": bool(torch.equal(direct[0], p_last[0])) and bool(torch.equal(direct[1], p_last[1])),
-                    "prescreen_searches": p_agg["prescreen"], "invariant": invariant(p_agg),
+                    "prescreen_searches": p_agg["prescreen"], "invariant": invariant(p_agg), "collective": p_coll,
                     "roofline": roofline(p_agg, p_flops, p_ms, pre_steps, p_kernel, MFMA_PEAK_TFLOPS["f16"],
                                          recorded_traffic(name + "_prescreen") if world == 1 else (None, None)),
                     "breakdown_ms_per_step": {"tile": p_agg["tile_ms"] / pre_steps, "rescore": p_agg["rescore_ms"] / pre_steps,
@@ -461,9 +478,87 @@ class Bench:
                 eng.set_base(full)
                 rd, ri = eng.search(queries, k, metric)
             ok = bool(torch.equal(ri, last[1])) and bool(torch.equal(rd, last[0]))
+        ctx.clear()
         del base_raw, queries, last
         torch.cuda.empty_cache()
         return out, ok
+
+
+def main_inlib(args):
+    """--collective inlib: the same job through the C ABI's own collective -- ONE process, N GPUs (nwknn_comm_create over ncclCommInitAll,
+    nwknn_search_sharded: a host thread per device for the shard searches, one ncclAllGather per array, device g merges its slice of the
+    query rows).  A step = seeded base shards generated and laid out on the devices + the sharded search with HOST queries and HOST
+    results (what the C ABI hands over; the torch flavour keeps the queries resident).  No torch.distributed anywhere."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if int(os.environ.get("RANK", "0")) != 0:
+        return 0                                                      # started under torchrun by habit: rank 0 drives all the GPUs
+    import torch
+    from neighborhoodwatch_amd import KnnEngine, ShardedKnnEngine
+    n = args.gpus
+    if torch.cuda.device_count() < n:
+        raise SystemExit(f"--gpus {n} --collective inlib needs {n} GPUs, this node shows {torch.cuda.device_count()}")
+    Q, B, d, k, metric, dtype, desc = WORKLOADS[args.workload]
+    if metric == "maxsim":
+        raise SystemExit("--collective inlib covers the kNN workloads (nwknn_search_sharded); MaxSim shards through torch.distributed")
+    if args.metric:
+        metric = args.metric
+    with KnnEngine(0) as gen:
+        queries = gen.generate(SEED_QUERY, 0, Q, d, dtype).cpu().numpy()
+    eng = ShardedKnnEngine(list(range(n)), profile=True)
+    for kvs in args.opt:
+        for kv in kvs.split(","):
+            name, value = kv.split("=")
+            eng.set_option(name, int(value))
+    agg = {"search_ms": 0.0, "allgather_ms": 0.0, "merge_ms": 0.0, "tile_flops": 0.0, "tile_ms": 0.0}
+
+    def step(record):
+        eng.generate_base(SEED_BASE, B, d, dtype)
+        out = eng.search(queries, k, metric)
+        if record:
+            st = eng.stats()
+            for key in agg:
+                agg[key] += st[key]
+        return out
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dist, idx = step(True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ach = agg["tile_flops"] / 1e12 / (agg["tile_ms"] / 1e3) if agg["tile_ms"] > 0 else 0.0
+    peak = MFMA_PEAK_TFLOPS[dtype]
+    devices = []
+    for g in range(n):
+        pr = torch.cuda.get_device_properties(g)
+        devices.append({"rank": g, "device": g, "name": pr.name, "gcn_arch": getattr(pr, "gcnArchName", ""), "uuid": str(getattr(pr, "uuid", "")),
+                        "hbm_gib": round(pr.total_memory / 2**30, 1)})
+    line = {"metric": "queries/sec + pairwise-dist TFLOP/s, 100k x 10M d=1024 k=100" if args.workload == "c3" else f"queries/sec ({args.workload})",
+            "value": Q * args.steps / elapsed, "unit": "queries/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype,
+            "data": "synthetic (seeded counter-based embeddings in [-1,1); base shards generated on the devices, queries handed over from host memory)",
+            "ranks": 1, "devices": devices, "pairwise_tflops": 2.0 * Q * B * d * args.steps / elapsed / 1e12,
+            "config": {"workload": desc, "queries": Q, "base_rows": B, "dim": d, "k": k, "metric": metric,
+                       "parallelism": f"base rows sharded x{n} inside ONE process (C ABI: nwknn_comm_*), RCCL all-gather of [Q,k] partials + sliced merge"},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                         "kernel": "per-device rate: tile FLOPs summed over the devices / tile-kernel time summed over the devices"},
+            "collective": {"kind": "in-library (C ABI nwknn_search_sharded: one process, N GPUs, ncclCommInitAll)", "backend": "rccl",
+                           "search_ms": agg["search_ms"] / args.steps, "allgather_ms": agg["allgather_ms"] / args.steps,
+                           "merge_ms": agg["merge_ms"] / args.steps, "allgather_bytes_per_rank": n * Q * k * 12,
+                           "timing": "per step, HIP events, maxima over the devices (nwknn_comm_stats)"}}
+    ok = None
+    if args.verify:
+        with KnnEngine(0) as one:
+            one.set_base(one.generate(SEED_BASE, 0, B, d, dtype))
+            rd, ri = one.search(queries, k, metric)
+        import numpy as np
+        ok = bool(np.array_equal(ri, idx)) and bool(np.array_equal(rd.view(np.uint32), dist.view(np.uint32)))
+    eng.close()
+    print(json.dumps(line), flush=True)
+    if args.verify:
+        print(json.dumps({"verify": "in-library N-device result == single-engine result", "ok": ok}), flush=True)
+    return 3 if (args.verify and not ok) else 0
 
 
 def main():
@@ -475,6 +570,13 @@ def main():
     ap.add_argument("--shard", default="base", choices=["base", "queries"],
                     help="N > 1: 'base' (default, the headline) shards the base rows and merges [Q,k] partials after one all-gather; "
                          "'queries' replicates the base and shards the query rows (no merge; only when the base fits one GPU)")
+    ap.add_argument("--shard-prescreen", default="auto", choices=["auto", "base", "queries"],
+                    help="N > 1, sharding of the pre-screened leg: 'auto' = query rows when the whole base + its fp16 copy fit one GPU, else as --shard")
+    ap.add_argument("--merge", default="slice", choices=["slice", "replicated"],
+                    help="N > 1, base sharding: 'slice' = rank g merges its slice of the query rows and the slices are all-gathered; 'replicated' = every rank merges all rows")
+    ap.add_argument("--collective", default="torch", choices=["torch", "inlib"],
+                    help="'torch' = one process per GPU over torch.distributed (RCCL); 'inlib' = ONE process driving N GPUs through the C ABI's "
+                         "nwknn_comm_* / nwknn_search_sharded (RCCL inside libnwknn.so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prescreen", action="store_true", help="skip the second measurement (fp16 pre-screen + fp32 rescoring)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary block (C2, one C3 shard, the C4 per-GPU slice) that follows the default workload at N=1")
@@ -486,6 +588,8 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.collective == "inlib":
+        raise SystemExit(main_inlib(args))                    # one process whatever N: nothing to launch
     if args.gpus > 1 and "RANK" not in os.environ:
         why = profiler_preload()
         if why:
@@ -500,7 +604,7 @@ def main():
     td, world, rank = b.td, b.world, b.rank
     devices = b.devices()
     out, ok = b.run(args.workload, args.steps, args.warmup, 0 if args.no_prescreen else min(args.steps, 5), args.metric, args.shard,
-                    args.verify, with_cpu=(world == 1 and not args.no_cpu_baseline))
+                    args.verify, with_cpu=(world == 1 and not args.no_cpu_baseline), pre_shard=args.shard_prescreen)
     if rank == 0:
         line = {"metric": "queries/sec + pairwise-dist TFLOP/s, 100k x 10M d=1024 k=100" if args.workload == "c3" else f"queries/sec ({args.workload})",
                 "value": out.pop("value"), "unit": out.pop("unit"), "n_gpus": world, "steps": out.pop("steps"), "warmup": out.pop("warmup"),

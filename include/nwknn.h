@@ -111,9 +111,9 @@ int nwknn_set_stream(nwknn_handle h, void* hip_stream);
  * (shape and walk order of an XCD's super-tile), "upload_threads" (host threads of the column upload pipeline, default 8),
  * "upload_slab_mib" (slab size of that pipeline, default 128),
  * "pre_eps_pct" (>= 100: percent of the proven pre-screen error bound to apply; larger = more pairs rescored, same result),
- * "pre_check_pct" (1..100, default 100: the invariant |estimate - exact| <= bound of nwknn_stats is checked against this percentage of the
- * bound; a violation sends the search down its fallback, whose result is the same bits -- so a small value only costs time; tests use it
- * to drive the fallback),
+ * "pre_check_ppm" (1..1000000, default 1000000: the invariant |estimate - exact| <= bound of nwknn_stats is checked against this many
+ * millionths of the bound; a violation sends the search down its fallback, whose result is the same bits -- so a small value only costs
+ * time; tests use it to drive the fallback),
  * MaxSim pre-screen tile kernel, d <= 128: "ms_strip" (document tiles a workgroup of the ring kernel walks: 0 = auto, 1 = the any-d
  * kernel), "ms_rescore_valu" (1: rescoring on the vector pipes).
  * No option changes a result: every switch that does (timing ablations, in-kernel stamps, a shrunken error bound) exists only in
@@ -204,6 +204,13 @@ int nwknn_comm_generate_base(nwknn_comm_handle c, uint64_t seed, int64_t rows, i
 int nwknn_search_sharded(nwknn_comm_handle c, const void* queries_host, int64_t nq, int dtype, int32_t k, int metric, float* out_dist,
                          int64_t* out_idx);
 int nwknn_comm_get_stats(nwknn_comm_handle c, nwknn_comm_stats* out);
+/* The exchange's merge step for partial lists the CALLER gathered (another transport, the partial files of merge.py:56-101, a test):
+ * dists / idx are HOST arrays [n_lists][nq][k] (idx < 0 marks an empty slot).  The query rows are cut into n_slices contiguous slices the
+ * way nwknn_search_sharded cuts them over its devices; slice s is merged on device s mod N of the communicator straight from the lists'
+ * own stride, and more than 4096 (list, rank) entries per query are folded in two levels -- the code path of a multi-device search,
+ * reachable with any number of lists on any number of devices.  Writes the k smallest by (distance, index) to HOST out_dist / out_idx [nq][k]. */
+int nwknn_comm_merge_lists(nwknn_comm_handle c, const float* dists_host, const int64_t* idx_host, int32_t n_lists, int64_t nq, int32_t k,
+                           int32_t n_slices, float* out_dist, int64_t* out_idx);
 
 /* ---- MaxSim late interaction (BASELINE.json config 5).  NOT in the reference: its `ck` program runs flat token-level
  *      kNN through process_batches (colbert_knn.py:84-126); this is the ColBERT scoring rule itself, provided as an

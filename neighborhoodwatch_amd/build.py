@@ -24,6 +24,10 @@ HEADERS = [CSRC / "nwk_device.h", CSRC / "nwk_f16_common.h", CSRC / "nwk_tile_f1
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=off", "-x", "hip"]
 
 
+def hipcc_path() -> str:
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
 def _obj(src: Path) -> Path:
     return OBJ / (src.stem + ".o")
 

@@ -32,29 +32,34 @@ __global__ __launch_bounds__(256, OCC) void nwk_tile_kernel(const NwkTileParams 
     const int dp = p.dp;
     const int nk = dp / BKT;
 
-    // ---- LDS-DMA sources.  Wave w fills rows [w*IA*RPI, (w+1)*IA*RPI) of the A tile and [w*IB*RPI, ...) of the B tile.
-    unsigned voffA[4], voffB[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ra = (w * IA + i) * RPI + (l / CH), rb = (w * IB + i) * RPI + (l / CH);
-        voffA[i] = (unsigned)(ra * dp + (((l % CH) ^ ((ra >> RSH) & (CH - 1))) << 2)) * 4u;
-        voffB[i] = (unsigned)(rb * dp + (((l % CH) ^ ((rb >> RSH) & (CH - 1))) << 2)) * 4u;
-    }
+    // ---- LDS-DMA sources.  Wave w fills rows [w*IA*RPI, (w+1)*IA*RPI) of the A tile and [w*IB*RPI, ...) of the B tile; instruction i of
+    // a wave brings rows (w*I+i)*RPI + l/CH.  With 64-B rows (RPI = 16) the swizzle term ((row >> 2) & 3) = (l/CH >> 2) & 3 is the same
+    // for every instruction and wave, so ONE per-lane offset serves all of them and the row block goes into the instruction's scalar
+    // offset (7 VGPRs less than an offset per instruction: the 168-register shape no longer depends on what else the compiler sees).
+    // With 128-B rows (RPI = 8) the term depends on the parity of i: two per-lane offsets.
+    // (two scalars, not an array: a lambda that captures an array whose bound depends on a template parameter makes this clang drop the
+    // kernel's host-side stub without a diagnostic)
+    constexpr bool TWO = ROWB != 64;
+    const unsigned voff0 = (unsigned)((l / CH) * dp + (((l % CH) ^ (((l / CH) >> RSH) & (CH - 1))) << 2)) * 4u;
+    const unsigned voff1 = TWO ? (unsigned)((l / CH) * dp + (((l % CH) ^ (((RPI + l / CH) >> RSH) & (CH - 1))) << 2)) * 4u : voff0;
+    static_assert((RPI >> RSH) % CH == 0 || TWO, "swizzle term independent of the instruction index");
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.qp + q0 * dp), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bp + b0 * dp), 0, 0x7FFFFFFF, 0x00020000);
-    const int ldsA = __builtin_amdgcn_readfirstlane(w * IA * 1024);
-    const int ldsB = __builtin_amdgcn_readfirstlane(A_BYTES + w * IB * 1024);
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int ldsA = wu * IA * 1024;
+    const int ldsB = A_BYTES + wu * IB * 1024;
+    const int rowA = wu * IA * RPI * dp * 4, rowB = wu * IB * RPI * dp * 4;       // byte offset of this wave's first row block (scalar)
 
     auto issue_stage = [&](int stage, int kt) {
         char* base = smem + stage * STAGE;
         const int soff = kt * ROWB;
 #pragma unroll
         for (int i = 0; i < IA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(base + ldsA + i * 1024), 16, voffA[i], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(base + ldsA + i * 1024), 16, (i & 1) ? voff1 : voff0, soff + rowA + i * RPI * dp * 4, 0, 0);
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
             if ((DIAG & 8) && kt > 0) continue;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(base + ldsB + i * 1024), 16, voffB[i], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(base + ldsB + i * 1024), 16, (i & 1) ? voff1 : voff0, soff + rowB + i * RPI * dp * 4, 0, 0);
         }
     };
 

@@ -126,7 +126,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i, ctab, chk;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 0, opt_f16_agg = -1, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128, opt_pre_check_pct = 100;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 0, opt_f16_agg = -1, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128, opt_pre_check_ppm = 1000000;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -331,11 +331,11 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
         // scales the pre-screen error bound.  Results are guaranteed at >= 100 only: smaller values exist in developer builds
         if (value < 0 || value > 100000) return fail(NWKNN_EINVAL, "pre_eps_pct must be 100..100000 (percent of the proven bound)");
         h->opt_pre_eps_pct = value;
-    } else if (!strcmp(name, "pre_check_pct")) {
+    } else if (!strcmp(name, "pre_check_ppm")) {
         // the invariant |estimate - exact| <= bound is checked against this share of the bound.  No value changes a result: a violation
         // sends the search down its fallback, which returns the same bits
-        if (value < 1 || value > 100) return fail(NWKNN_EINVAL, "pre_check_pct must be 1..100 (percent of the pre-screen bound the invariant is checked against)");
-        h->opt_pre_check_pct = value;
+        if (value < 1 || value > 1000000) return fail(NWKNN_EINVAL, "pre_check_ppm must be 1..1000000 (millionths of the pre-screen bound the invariant is checked against)");
+        h->opt_pre_check_ppm = value;
     } else if (!strcmp(name, "f16_mfma")) {
         if (value != -1 && value != 1 && value != 3 && value != 4) return fail(NWKNN_EINVAL, "f16_mfma must be -1 (auto), 1 (burst form), 3 (streaming form) or 4 (ping-pong form)");
         h->opt_f16_shape = value;
@@ -807,7 +807,7 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         rp.prune = (h->opt_pre_prune && !dedupe && !dense) ? 1 : 0;
         rp.rows16 = pl.native16 ? 1 : 0;
         rp.eps_half = pl.pre_eps_half; rp.aq = pl.pre_aq; rp.ab = pl.pre_ab; rp.cst = pl.pre_cst;
-        rp.chk_scale = (float)h->opt_pre_check_pct / 100.0f;
+        rp.chk_scale = (float)((double)h->opt_pre_check_ppm * 1e-6);
         rp.chk = h->chk.as<u64>();
         e = ev_begin(h, 3);
         HIPCHK(nwk_launch_rescore(h->stream, rp, metric, nq_pad));
@@ -1084,8 +1084,8 @@ static int search_common(nwknn_ctx* h, const void* queries, const ColumnSource* 
             return NWKNN_OK;
         }
         discarded += bad;
-        fprintf(stderr, "libnwknn: pre-screen invariant failed on %lld of %lld rescored pairs (|estimate - exact| above %lld %% of the bound): "
-                        "attempt %d discarded, searching again %s\n", bad, (long long)h->stats.prescreen_checked, (long long)h->opt_pre_check_pct,
+        fprintf(stderr, "libnwknn: pre-screen invariant failed on %lld of %lld rescored pairs (|estimate - exact| above %lld ppm of the bound): "
+                        "attempt %d discarded, searching again %s\n", bad, (long long)h->stats.prescreen_checked, (long long)h->opt_pre_check_ppm,
                 attempt, h->f16 ? "under a 16x wider bound" : "on the direct fp32 kernel");                                  // never silent
         if (attempt >= 3) return fail(NWKNN_EHIP, "pre-screen invariant still violated after widening the bound %d times (%lld pairs)", attempt, bad);
     }

@@ -4,9 +4,15 @@
 // the CPU (merge.py:56-101); this is SURVEY 8b/8e's design, reachable from any host language, not only through torch.distributed
 // (neighborhoodwatch_amd/distributed.py is the one-process-per-GPU flavour of the same exchange).
 //
-// One host thread per device drives that device's engine handle (nwknn_search blocks on its stream); the collective is issued from the
-// calling thread inside ncclGroupStart/End, one call per device, on the handles' own streams; afterwards device g merges only ITS
-// slice of the query rows (rows [Q g / N, Q (g+1) / N) of every gathered list) and copies that slice to the caller's host buffers.
+// One host thread per device drives that device's engine handle (nwknn_search blocks on the handle's stream and returns with the partial
+// lists complete in device memory); the collective is issued from the calling thread inside ncclGroupStart/End, one call per device, on
+// that device's EXCHANGE stream (DevPart::stream: collective, merge and D2H of the device, created here, not the engine's); afterwards
+// device g merges only ITS slice of the query rows (rows [Q g / N, Q (g+1) / N) of every gathered list) and copies that slice to the
+// caller's host buffers.  An error after work has been queued never returns with that work in flight: an open RCCL group is closed
+// and every exchange stream is drained first (the caller's host buffers are the targets of asynchronous copies).
+// STATUS: more than one device has never executed on hardware (no multi-GPU box was available to the builder).  What a one-GPU box can
+// run is covered there: the whole path with one device, and the sliced / two-level merge for any number of lists through
+// nwknn_comm_merge_lists (tests/test_gpu_distributed_rccl.py).
 // RCCL is bound at run time (dlopen of librccl.so.1: the copy already in the process -- torch ships one -- or the system's), so the
 // library itself carries no link-time dependency on it and single-GPU users never load it... except through this file's entry points.
 #include "../../include/nwknn.h"
@@ -295,6 +301,94 @@ static int merge_slice(nwknn_comm* c, DevPart& p, int n, long long nq, int k, lo
     return NWKNN_OK;
 }
 
+// device buffers of the exchange step on one device: the gathered lists of n_lists shards and the merged slice [qlo, qhi) of the query rows
+static int ensure_exchange_buffers(DevPart& p, int n_lists, long long nq, int k, long long qlo, long long qhi, bool with_partial)
+{
+    const size_t qk = (size_t)nq * k;
+    const size_t slice = (size_t)(qhi - qlo) * k + 1;
+    int rc;
+    if (with_partial && ((rc = p.b_part_d.ensure(qk * 4)) || (rc = p.b_part_i.ensure(qk * 8)))) return rc;
+    if ((rc = p.b_all_d.ensure(qk * n_lists * 4)) || (rc = p.b_all_i.ensure(qk * n_lists * 8)) || (rc = p.b_out_d.ensure(slice * 4)) ||
+        (rc = p.b_out_i.ensure(slice * 8)))
+        return rc;
+    if ((long long)n_lists * k > 4096) {
+        const int per = std::max(1, 4096 / k);
+        const size_t grp = slice * (size_t)((n_lists + per - 1) / per);
+        if ((rc = p.b_grp_d.ensure(grp * 4)) || (rc = p.b_grp_i.ensure(grp * 8))) return rc;
+    }
+    p.part_d = (float*)p.b_part_d.p; p.part_i = (long long*)p.b_part_i.p;
+    p.all_d = (float*)p.b_all_d.p; p.all_i = (long long*)p.b_all_i.p;
+    p.grp_d = (float*)p.b_grp_d.p; p.grp_i = (long long*)p.b_grp_i.p;
+    p.out_d = (float*)p.b_out_d.p; p.out_i = (long long*)p.b_out_i.p;
+    return NWKNN_OK;
+}
+
+// wait for everything queued on every exchange stream (an error path must not return while copies into the caller's buffers are in flight)
+static void drain_exchange_streams(nwknn_comm* c)
+{
+    for (DevPart& p : c->dev) {
+        if (!p.stream) continue;
+        (void)hipSetDevice(p.device);
+        (void)hipStreamSynchronize(p.stream);
+    }
+    (void)hipGetLastError();
+}
+
+// step 3 of the exchange on device `p`: merge rows [qlo, qhi) of the n_lists gathered lists in p.all_*, queue the copy to the caller
+static int merge_and_return_slice(nwknn_comm* c, DevPart& p, int n_lists, long long nq, int k, long long qlo, long long qhi, float* out_dist,
+                                  int64_t* out_idx)
+{
+    CHIP(hipSetDevice(p.device));
+    CHIP(hipEventRecord(p.ev1, p.stream));
+    const int rc = merge_slice(c, p, n_lists, nq, k, qlo, qhi - qlo);
+    if (rc != NWKNN_OK) return rc;
+    CHIP(hipEventRecord(p.ev2, p.stream));
+    if (qhi > qlo) {
+        CHIP(hipMemcpyAsync(out_dist + qlo * k, p.out_d, (size_t)(qhi - qlo) * k * 4, hipMemcpyDeviceToHost, p.stream));
+        CHIP(hipMemcpyAsync(out_idx + qlo * k, p.out_i, (size_t)(qhi - qlo) * k * 8, hipMemcpyDeviceToHost, p.stream));
+    }
+    return NWKNN_OK;
+}
+
+// The exchange's merge for lists the CALLER gathered (another transport, partial files, a test): dists / idx are HOST arrays
+// [n_lists][nq][k] (idx < 0 = empty slot); the query rows are cut into n_slices contiguous slices exactly as nwknn_search_sharded cuts
+// them over its devices, slice s is merged on device s mod N of the communicator from the lists' own stride (no repacking), more than
+// 4096 entries per query are folded in two levels.  Writes out_dist / out_idx [nq][k] on the host.
+extern "C" int nwknn_comm_merge_lists(nwknn_comm_handle c, const float* dists_host, const int64_t* idx_host, int32_t n_lists, int64_t nq, int32_t k,
+                                      int32_t n_slices, float* out_dist, int64_t* out_idx)
+{
+    if (!c || !dists_host || !idx_host || !out_dist || !out_idx) return cfail(NWKNN_EINVAL, "nwknn_comm_merge_lists: null argument");
+    if (n_lists <= 0 || nq <= 0 || k <= 0 || n_slices <= 0 || n_slices > 4096) return cfail(NWKNN_EINVAL, "nwknn_comm_merge_lists: n_lists, nq, k, n_slices must be positive");
+    if (k > 4096) return cfail(NWKNN_EINVAL, "nwknn_comm_merge_lists: k=%d exceeds 4096 entries per merge", k);
+    const int n = (int)c->dev.size();
+    const size_t total = (size_t)n_lists * nq * k;
+    int rc = NWKNN_OK;
+    std::vector<char> uploaded((size_t)n, 0);
+    for (int s = 0; s < n_slices && rc == NWKNN_OK; ++s) {
+        DevPart& p = c->dev[s % n];
+        long long qlo, qhi;
+        shard_bounds(nq, n_slices, s, &qlo, &qhi);
+        if (qhi <= qlo) continue;
+        if (hipSetDevice(p.device) != hipSuccess) { rc = cfail(NWKNN_EHIP, "hipSetDevice(%d) failed", p.device); break; }
+        if (uploaded[(size_t)(s % n)]) {                             // the device's out buffer is reused: its previous slice must have left
+            if (hipStreamSynchronize(p.stream) != hipSuccess) { rc = cfail(NWKNN_EHIP, "stream synchronize failed on device %d", p.device); break; }
+        }
+        rc = ensure_exchange_buffers(p, n_lists, nq, k, 0, (nq + n_slices - 1) / n_slices + 1, false);
+        if (rc != NWKNN_OK) break;
+        if (!uploaded[(size_t)(s % n)]) {
+            if (hipMemcpyAsync(p.all_d, dists_host, total * 4, hipMemcpyHostToDevice, p.stream) != hipSuccess ||
+                hipMemcpyAsync(p.all_i, idx_host, total * 8, hipMemcpyHostToDevice, p.stream) != hipSuccess) {
+                rc = cfail(NWKNN_EHIP, "upload of the gathered lists to device %d failed", p.device);
+                break;
+            }
+            uploaded[(size_t)(s % n)] = 1;
+        }
+        rc = merge_and_return_slice(c, p, n_lists, nq, k, qlo, qhi, out_dist, out_idx);
+    }
+    drain_exchange_streams(c);
+    return rc;
+}
+
 extern "C" int nwknn_search_sharded(nwknn_comm_handle c, const void* queries_host, int64_t nq, int dtype, int32_t k, int metric, float* out_dist,
                                     int64_t* out_idx)
 {
@@ -313,63 +407,63 @@ extern "C" int nwknn_search_sharded(nwknn_comm_handle c, const void* queries_hos
         CHIP(hipSetDevice(p.device));
         long long qlo, qhi;
         shard_bounds(nq, n, g, &qlo, &qhi);
-        const size_t slice = (size_t)(qhi - qlo) * k + 1;
-        int rc;
-        if ((rc = p.b_part_d.ensure(qk * 4)) || (rc = p.b_part_i.ensure(qk * 8)) || (rc = p.b_all_d.ensure(qk * n * 4)) ||
-            (rc = p.b_all_i.ensure(qk * n * 8)) || (rc = p.b_out_d.ensure(slice * 4)) || (rc = p.b_out_i.ensure(slice * 8)))
-            return rc;
-        if ((long long)n * k > 4096) {
-            const int per = std::max(1, 4096 / k);
-            const size_t grp = slice * (size_t)((n + per - 1) / per);
-            if ((rc = p.b_grp_d.ensure(grp * 4)) || (rc = p.b_grp_i.ensure(grp * 8))) return rc;
-        }
-        p.part_d = (float*)p.b_part_d.p; p.part_i = (long long*)p.b_part_i.p;
-        p.all_d = (float*)p.b_all_d.p; p.all_i = (long long*)p.b_all_i.p;
-        p.grp_d = (float*)p.b_grp_d.p; p.grp_i = (long long*)p.b_grp_i.p;
-        p.out_d = (float*)p.b_out_d.p; p.out_i = (long long*)p.b_out_i.p;
+        const int rc = ensure_exchange_buffers(p, n, nq, k, qlo, qhi, true);
+        if (rc != NWKNN_OK) return rc;
     }
     // 1. every device searches its shard; ids are global (index_offset = first row of the shard: "+ batch_offset", cu_knn.py:273)
     int rc = on_every_device(c, [&](int g) {
         DevPart& p = c->dev[g];
         return nwknn_search(p.h, queries_host, nq, dtype, NWKNN_HOST, k, metric, p.row_lo, p.part_d, (int64_t*)p.part_i, NWKNN_DEVICE);
     });
-    if (rc != NWKNN_OK) return rc;
-    // 2. one all-gather per array over RCCL (xGMI): every device ends up with the N partial lists, in device order == row order
-    for (int g = 0; g < n; ++g) { CHIP(hipSetDevice(c->dev[g].device)); CHIP(hipEventRecord(c->dev[g].ev0, c->dev[g].stream)); }
-    CNCCL(c, c->rccl.GroupStart());
-    for (int g = 0; g < n; ++g) {
-        DevPart& p = c->dev[g];
-        CNCCL(c, c->rccl.AllGather(p.part_d, p.all_d, qk, ncclFloat32, p.comm, p.stream));
-        CNCCL(c, c->rccl.AllGather(p.part_i, p.all_i, qk, ncclInt64, p.comm, p.stream));
-    }
-    CNCCL(c, c->rccl.GroupEnd());
-    // 3. device g merges its slice of the query rows and hands it to the caller
-    for (int g = 0; g < n; ++g) {
-        DevPart& p = c->dev[g];
-        CHIP(hipSetDevice(p.device));
-        CHIP(hipEventRecord(p.ev1, p.stream));
-        long long qlo, qhi;
-        shard_bounds(nq, n, g, &qlo, &qhi);
-        rc = merge_slice(c, p, n, nq, k, qlo, qhi - qlo);
-        if (rc != NWKNN_OK) return rc;
-        CHIP(hipEventRecord(p.ev2, p.stream));
-        if (qhi > qlo) {
-            CHIP(hipMemcpyAsync(out_dist + qlo * k, p.out_d, (size_t)(qhi - qlo) * k * 4, hipMemcpyDeviceToHost, p.stream));
-            CHIP(hipMemcpyAsync(out_idx + qlo * k, p.out_i, (size_t)(qhi - qlo) * k * 8, hipMemcpyDeviceToHost, p.stream));
+    if (rc != NWKNN_OK) return rc;                                   // nwknn_search returns with its stream drained: nothing is in flight
+    // 2. one all-gather per array over RCCL (xGMI): every device ends up with the N partial lists, in device order == row order.
+    //    From here on work is queued on the exchange streams: no early return -- the first error is kept, the group is closed and the
+    //    streams are drained before it is handed back.
+    auto exchange = [&]() -> int {
+        for (int g = 0; g < n; ++g) { CHIP(hipSetDevice(c->dev[g].device)); CHIP(hipEventRecord(c->dev[g].ev0, c->dev[g].stream)); }
+        CNCCL(c, c->rccl.GroupStart());
+        int in_group = NWKNN_OK;
+        for (int g = 0; g < n && in_group == NWKNN_OK; ++g) {
+            DevPart& p = c->dev[g];
+            in_group = [&]() -> int {
+                CNCCL(c, c->rccl.AllGather(p.part_d, p.all_d, qk, ncclFloat32, p.comm, p.stream));
+                CNCCL(c, c->rccl.AllGather(p.part_i, p.all_i, qk, ncclInt64, p.comm, p.stream));
+                return NWKNN_OK;
+            }();
         }
+        const ncclResult_t ge = c->rccl.GroupEnd();                  // always: a group left open would swallow the next caller's collectives
+        if (in_group != NWKNN_OK) return in_group;
+        if (ge != ncclSuccess) return cfail(NWKNN_EHIP, "ncclGroupEnd failed: %s", c->rccl.GetErrorString(ge));
+        // 3. device g merges its slice of the query rows and hands it to the caller
+        for (int g = 0; g < n; ++g) {
+            long long qlo, qhi;
+            shard_bounds(nq, n, g, &qlo, &qhi);
+            const int r3 = merge_and_return_slice(c, c->dev[g], n, nq, k, qlo, qhi, out_dist, out_idx);
+            if (r3 != NWKNN_OK) return r3;
+        }
+        return NWKNN_OK;
+    };
+    rc = exchange();
+    if (rc != NWKNN_OK) {
+        const std::string keep = nwknn_last_error();                 // draining must not lose the cause
+        drain_exchange_streams(c);
+        return nwknn_internal_fail(rc, keep.c_str());
     }
     double ag = 0.0, mg = 0.0, sr = 0.0, flops = 0.0, tile = 0.0;
+    int rc_sync = NWKNN_OK;
     for (int g = 0; g < n; ++g) {
         DevPart& p = c->dev[g];
-        CHIP(hipSetDevice(p.device));
-        CHIP(hipStreamSynchronize(p.stream));
         float a = 0.f, m = 0.f;
-        CHIP(hipEventElapsedTime(&a, p.ev0, p.ev1));
-        CHIP(hipEventElapsedTime(&m, p.ev1, p.ev2));
+        if (hipSetDevice(p.device) != hipSuccess || hipStreamSynchronize(p.stream) != hipSuccess) {     // keep draining the others
+            if (rc_sync == NWKNN_OK) rc_sync = cfail(NWKNN_EHIP, "exchange stream of device %d failed: %s", p.device, hipGetErrorString(hipGetLastError()));
+            continue;
+        }
+        if (hipEventElapsedTime(&a, p.ev0, p.ev1) != hipSuccess || hipEventElapsedTime(&m, p.ev1, p.ev2) != hipSuccess) { a = m = 0.f; (void)hipGetLastError(); }
         ag = std::max(ag, (double)a); mg = std::max(mg, (double)m);
         nwknn_stats st;
         if (nwknn_get_stats(p.h, &st) == NWKNN_OK) { sr = std::max(sr, st.total_ms); flops += st.tile_flops; tile += st.tile_ms; }
     }
+    if (rc_sync != NWKNN_OK) return rc_sync;
     c->stats.n_devices = n; c->stats.nq = nq; c->stats.k = k;
     c->stats.search_ms = sr; c->stats.allgather_ms = ag; c->stats.merge_ms = mg;
     c->stats.allgather_bytes_per_device = (double)qk * 12.0 * n;

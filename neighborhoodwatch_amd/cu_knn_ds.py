@@ -27,7 +27,7 @@ from .cu_knn import (PARQUET_ROW_GROUP, cleanup, engine_search, engine_set_base,
                      table_columns, table_input)
 from .engine import default_engine, mem_info, resolve_metric
 from .nw_utils import get_full_filename, get_partial_distances_filename, get_partial_indices_filename
-from .parquet_stream import ParquetRows, Prefetch
+from .parquet_stream import ParquetRows, Prefetch, TableRows
 
 
 PREFETCH_SLOTS = 2                  # base batches alive on the host at once: the one on the GPU + the one being decoded (1 = no overlap)
@@ -128,9 +128,16 @@ def _as_rows(dataset, column_names) -> ParquetRows:
     """A dataset argument as a lazy row window over its float columns (the text column the reference's scanner also carries,
     cu_knn_ds.py:122-133, never reaches the GPU and is not decoded here)."""
     cols = _embedding_columns(column_names)
-    if isinstance(dataset, ParquetRows):
+    if isinstance(dataset, (ParquetRows, TableRows)):
         return dataset.select(cols)
-    return ParquetRows(dataset.files, None, cols)
+    files = getattr(dataset, "files", None)
+    if files:
+        return ParquetRows(files, None, cols)
+    if isinstance(dataset, pa.Table):
+        return TableRows(dataset.select(cols))
+    if hasattr(dataset, "to_table"):                              # an in-memory pyarrow dataset (slice_dataset's materialising fallback): no files behind it
+        return TableRows(dataset.to_table(columns=cols))
+    raise TypeError(f"cannot read rows from a {type(dataset).__name__}: expected a parquet-backed or in-memory pyarrow dataset, a Table or ParquetRows")
 
 
 # ---- resume: the running [Q,k] pair after `rows_done` base rows ------------------------------------------------------------
@@ -138,9 +145,11 @@ def _checkpoint_names(data_dir):
     return f"{data_dir}/partial/running_distances.parquet", f"{data_dir}/partial/running_indices.parquet"
 
 
-def _checkpoint_tag(metric, k, query_count, base_rows, rows_done) -> dict:
+def _checkpoint_tag(metric, k, query_count, base_rows, rows_done, inputs: str = "") -> dict:
+    """What a checkpoint was computed from.  ``inputs`` ties it to the data: the provenance of the query and base rows (file paths, sizes,
+    modification times, columns) -- equal counts alone would let a stale checkpoint of ANOTHER job in the same data_dir be resumed."""
     return {"nwknn.metric": metric, "nwknn.k": str(k), "nwknn.queries": str(query_count), "nwknn.base_rows": str(base_rows),
-            "nwknn.rows_done": str(rows_done)}
+            "nwknn.rows_done": str(rows_done), "nwknn.inputs": inputs}
 
 
 def _write_checkpoint(data_dir, dist, idx, tag):
@@ -150,14 +159,14 @@ def _write_checkpoint(data_dir, dist, idx, tag):
         os.replace(name + ".tmp", name)
 
 
-def _load_checkpoint(data_dir, metric, k, query_count, base_rows):
+def _load_checkpoint(data_dir, metric, k, query_count, base_rows, inputs: str = ""):
     """-> (rows_done, distances [Q,k] f32, indices [Q,k] i64) of a checkpoint written by a run of the same job, or None."""
     fd, fi = _checkpoint_names(data_dir)
     try:
         td, ti = pq.read_table(fd), pq.read_table(fi)
         kd, ki = td.schema.metadata or {}, ti.schema.metadata or {}
         rows_done = int(kd[b"nwknn.rows_done"])
-        want = _checkpoint_tag(metric, k, query_count, base_rows, rows_done)
+        want = _checkpoint_tag(metric, k, query_count, base_rows, rows_done, inputs)
         if any(kd.get(a.encode()) != b.encode() or ki.get(a.encode()) != b.encode() for a, b in want.items()):
             return None
         if len(td) != query_count or len(ti) != query_count or td.num_columns != k or ti.num_columns != k or not (0 < rows_done <= base_rows):
@@ -197,7 +206,8 @@ def process_dataset_batches(data_dir,
     metric = resolve_metric(metric, engine)
     eng = default_engine(device)
     eng.set_prescreen(prescreen)
-    query_table = _as_rows(query_dataset, query_column_names).to_table()
+    query_rows = _as_rows(query_dataset, query_column_names)
+    query_table = query_rows.to_table()
     queries = table_input(query_table)
     assert len(query_table) == query_count                                        # cu_knn_ds.py:229-230
     base_rows = _as_rows(base_dataset, base_column_names)
@@ -206,12 +216,13 @@ def process_dataset_batches(data_dir,
 
     run_d = run_i = None                                                          # the running pair: torch CUDA tensors [Q,k]
     start_row = 0
-    ckpt = _load_checkpoint(data_dir, metric, k, query_count, n_base) if resume else None
+    inputs = f"q:{query_rows.provenance()};b:{base_rows.provenance()}"
+    ckpt = _load_checkpoint(data_dir, metric, k, query_count, n_base, inputs) if resume else None
     if ckpt is not None:
         start_row = ckpt[0]
         dev = torch.device("cuda", device)
         run_d, run_i = torch.from_numpy(ckpt[1]).to(dev), torch.from_numpy(ckpt[2]).to(dev)
-        print(f"-- resuming after {start_row} of {n_base} base rows (checkpoint of the same metric / k / row counts)")
+        print(f"-- resuming after {start_row} of {n_base} base rows (checkpoint of the same metric / k / row counts / input files)")
     else:
         _drop_checkpoint(data_dir)
 
@@ -236,7 +247,7 @@ def process_dataset_batches(data_dir,
                 if resume and batch_offset + rows < n_base:
                     if pending_write is not None:
                         pending_write.result()                                    # one checkpoint in flight at a time
-                    tag = _checkpoint_tag(metric, k, query_count, n_base, batch_offset + rows)
+                    tag = _checkpoint_tag(metric, k, query_count, n_base, batch_offset + rows, inputs)
                     pending_write = writer.submit(_write_checkpoint, data_dir, run_d.cpu().numpy(), run_i.cpu().numpy(), tag)
             if pending_write is not None:
                 pending_write.result()

@@ -70,24 +70,63 @@ def _timed_allgather(dist, idx, group, timings):
     return out
 
 
-def sharded_search(search_shard: Callable, merge: Callable, queries, k: int, shard_lo: int, group=None, timings=None):
+def _allgather_row_slices(part_d, part_i, nq: int, k: int, like, group, timings, key: str):
+    """Rank r holds rows shard_bounds(nq, world, r) of a [nq,k] table (``part_*`` = its slice, or None when the slice is empty): pad the
+    slices to the longest, ONE all-gather per array, concatenate in rank order -> the whole table on every rank."""
+    import torch
+    import torch.distributed as td
+    world, rank = td.get_world_size(group), td.get_rank(group)
+    lo, hi = shard_bounds(nq, world, rank)
+    rows = -(-nq // world)                                        # slices differ by at most one row: pad to the longest
+    pd_ = torch.zeros((rows, k), dtype=torch.float32, device=like.device)
+    pi_ = torch.zeros((rows, k), dtype=torch.int64, device=like.device)
+    if hi > lo:
+        pd_[:hi - lo] = part_d
+        pi_[:hi - lo] = part_i
+    sub = {} if timings is not None else None
+    gd, gi = _timed_allgather(pd_, pi_, group, sub)               # [world, rows, k]
+    if timings is not None:
+        timings[key] = timings.get(key, 0.0) + sub["allgather_ms"]
+        timings[key.replace("_ms", "_bytes")] = sub["allgather_bytes"]
+    parts = [shard_bounds(nq, world, r) for r in range(world)]
+    return (torch.cat([gd[r, :b - a] for r, (a, b) in enumerate(parts)]), torch.cat([gi[r, :b - a] for r, (a, b) in enumerate(parts)]))
+
+
+def sharded_search(search_shard: Callable, merge: Callable, queries, k: int, shard_lo: int, group=None, timings=None, merge_mode: str = "slice"):
     """search_shard(queries, k, index_offset) -> (dist [Q,k] f32 tensor, idx [Q,k] i64 tensor, global ids);
-    merge(dists [W,Q,k], idx [W,Q,k], k) -> ([Q,k], [Q,k]).  Returns the merged table (identical on all ranks).
-    ``timings`` (a dict) accumulates ``allgather_ms`` / ``merge_ms`` of the exchange step (the merge call is blocking: host clock)."""
+    merge(dists [W,q,k], idx [W,q,k], k) -> ([q,k], [q,k]).  Returns the merged table (identical on all ranks).
+
+    After the all-gather of the [Q,k] partial lists every rank holds all W lists.  ``merge_mode="slice"`` (default; what the C ABI's
+    nwknn_search_sharded does, nwknn_comm.cpp): rank g merges only ITS slice of the query rows (shard_bounds over the queries) -- 1/W of
+    the merge work -- and a second, small all-gather (Q*k*12 bytes in total) hands every rank the whole table.  ``"replicated"``: every
+    rank merges all Q rows (the first two rounds' behaviour; no second exchange).  Same result, bit for bit.
+    ``timings`` (a dict) accumulates ``allgather_ms`` / ``merge_ms`` (/ ``slices_ms``: the second all-gather) of the exchange step (the
+    merge call is blocking: host clock)."""
     import time
     import torch.distributed as td
+    if merge_mode not in ("slice", "replicated"):
+        raise ValueError(f"merge_mode must be 'slice' or 'replicated', got {merge_mode!r}")
     dist, idx = search_shard(queries, k, shard_lo)
     if not td.is_initialized() or td.get_world_size(group) == 1:
         return dist, idx
     gd, gi = _timed_allgather(dist, idx, group, timings)
-    t0 = time.perf_counter()
-    out = merge(gd, gi, k)
-    if timings is not None:
-        if getattr(out[0], "is_cuda", False):
-            import torch
-            torch.cuda.synchronize(out[0].device)
-        timings["merge_ms"] = timings.get("merge_ms", 0.0) + (time.perf_counter() - t0) * 1e3
-    return out
+
+    def timed_merge(d_, i_):
+        t0 = time.perf_counter()
+        out = merge(d_, i_, k)
+        if timings is not None:
+            if getattr(out[0], "is_cuda", False):
+                import torch
+                torch.cuda.synchronize(out[0].device)
+            timings["merge_ms"] = timings.get("merge_ms", 0.0) + (time.perf_counter() - t0) * 1e3
+        return out
+
+    if merge_mode == "replicated":
+        return timed_merge(gd, gi)
+    nq = dist.shape[0]
+    lo, hi = shard_bounds(nq, td.get_world_size(group), td.get_rank(group))
+    md, mi = timed_merge(gd[:, lo:hi].contiguous(), gi[:, lo:hi].contiguous()) if hi > lo else (None, None)
+    return _allgather_row_slices(md, mi, nq, k, dist, group, timings, "slices_ms")
 
 
 def query_sharded_search(search_all: Callable, queries, k: int, group=None, timings=None):
@@ -95,22 +134,13 @@ def query_sharded_search(search_all: Callable, queries, k: int, group=None, timi
     searches its contiguous slice of the query rows (``shard_bounds`` over the queries); the slices are concatenated in rank
     order by one all-gather -- there is nothing to merge, a query's neighbours all come from one rank.
     search_all(queries_slice, k) -> (dist [q,k] f32 tensor, idx [q,k] i64 tensor).  Returns ([Q,k], [Q,k]) on every rank."""
-    import torch
     import torch.distributed as td
     if not td.is_initialized() or td.get_world_size(group) == 1:
         return search_all(queries, k)
     world, rank = td.get_world_size(group), td.get_rank(group)
     nq = queries.shape[0]
     lo, hi = shard_bounds(nq, world, rank)
-    rows = -(-nq // world)                                        # slices differ by at most one row: pad to the longest
     # fewer queries than ranks: a rank with an empty slice searches nothing and contributes only padding (the engine refuses an
     # empty query set, and a rank that raised here would leave the others blocked in the all-gather)
-    pd_ = torch.zeros((rows, k), dtype=torch.float32, device=queries.device)
-    pi_ = torch.zeros((rows, k), dtype=torch.int64, device=queries.device)
-    if hi > lo:
-        dist, idx = search_all(queries[lo:hi], k)
-        pd_[:hi - lo] = dist
-        pi_[:hi - lo] = idx
-    gd, gi = _timed_allgather(pd_, pi_, group, timings)           # [world, rows, k]
-    parts = [shard_bounds(nq, world, r) for r in range(world)]
-    return (torch.cat([gd[r, :b - a] for r, (a, b) in enumerate(parts)]), torch.cat([gi[r, :b - a] for r, (a, b) in enumerate(parts)]))
+    dist, idx = search_all(queries[lo:hi], k) if hi > lo else (None, None)
+    return _allgather_row_slices(dist, idx, nq, k, queries, group, timings, "allgather_ms")

@@ -35,19 +35,45 @@ def resolve_metric(metric: Optional[str] = None, engine: Optional[str] = None) -
     return metric
 
 
-# Handles still open when the interpreter exits are destroyed HERE, in an atexit hook -- while the HIP runtime is still up -- and never from
-# a __del__ that runs during interpreter finalization: by then the runtime's own teardown may have run, and nwknn_destroy (stream sync,
-# event destroy, hipFree) segfaulted now and then, after a green test run (the process then exits with a signal instead of 0).
+# Handles still open when the interpreter exits are destroyed HERE, in an atexit hook -- the first thing Py_FinalizeEx runs, with every
+# module, torch's allocator and the HIP runtime intact -- and never from a __del__ that runs during interpreter finalization.
+# Why (DESIGN.md section 9 has the reading of the code this rests on): round 3 saw ONE process exit on a signal after a green GPU test run
+# and kept no log of it, so the trigger is not known.  nwknn_destroy is nine kinds of HIP call (set device, stream synchronise, hipFree x 26,
+# event / stream destroy, hipHostFree).  Called from __del__ during finalization it runs after torch's Python side has been torn down in
+# an order nobody controls (module dicts are cleared, then whatever objects remain are freed) -- the runtime library itself is still
+# loaded then, its own exit handlers run later, in exit() -- so the atexit hook removes the only window in which OUR calls run in an
+# unspecified state; it cannot fix a fault that is not ours.  What makes a recurrence readable: __del__ says so on stderr when it meets an
+# open handle at finalization (it must not: _OPEN_AT_FINALIZATION), the exit test runs its child under faulthandler and keeps the child's
+# stderr and exit status in gpurun_out/ when they are not clean.
 _live = weakref.WeakSet()
+_OPEN_AT_FINALIZATION = b"libnwknn: a handle was still open when the interpreter finalised; no HIP call is made from __del__ at that point\n"
+_closed_at_exit = 0
 
 
 @atexit.register
 def _close_live_handles() -> None:
+    global _closed_at_exit
     for obj in list(_live):
         try:
-            obj.close()
+            if obj._is_open():
+                obj.close()
+                _closed_at_exit += 1
         except Exception:
             pass
+
+
+def _del_guard(obj) -> bool:
+    """True when __del__ may destroy the handle.  During interpreter finalization it may not (see above); an open handle there means the
+    atexit hook missed it, which is reported, not papered over."""
+    if not sys.is_finalizing():
+        return True
+    try:
+        if obj._is_open():
+            import os
+            os.write(2, _OPEN_AT_FINALIZATION)
+    except Exception:
+        pass
+    return False
 
 
 class KnnEngine:
@@ -65,13 +91,16 @@ class KnnEngine:
             self.set_option("profile", 1)
 
     # -- lifetime ---------------------------------------------------------------------------------
+    def _is_open(self) -> bool:
+        return getattr(self, "_h", None) is not None and bool(self._h.value)
+
     def close(self) -> None:
-        if getattr(self, "_h", None) is not None and self._h.value:
+        if self._is_open():
             self._L.nwknn_destroy(self._h)
             self._h = ctypes.c_void_p()
 
     def __del__(self):
-        if sys.is_finalizing():                                     # too late for HIP calls (see _close_live_handles)
+        if not _del_guard(self):                                    # too late for HIP calls (see _close_live_handles)
             return
         try:
             self.close()
@@ -415,13 +444,16 @@ class ShardedKnnEngine:
         if profile:
             self.set_option("profile", 1)
 
+    def _is_open(self) -> bool:
+        return getattr(self, "_c", None) is not None and bool(self._c.value)
+
     def close(self) -> None:
-        if getattr(self, "_c", None) is not None and self._c.value:
+        if self._is_open():
             self._L.nwknn_comm_destroy(self._c)
             self._c = ctypes.c_void_p()
 
     def __del__(self):
-        if sys.is_finalizing():                                     # too late for HIP calls (see _close_live_handles)
+        if not _del_guard(self):                                    # too late for HIP calls (see _close_live_handles)
             return
         try:
             self.close()
@@ -469,6 +501,21 @@ class ShardedKnnEngine:
         check(self._L.nwknn_search_sharded(self._c, ctypes.c_void_p(q.ctypes.data), q.shape[0], DTYPE_F16 if q.dtype == np.float16 else DTYPE_F32,
                                            int(k), METRIC_IDS[metric], ctypes.c_void_p(od.ctypes.data), ctypes.c_void_p(oi.ctypes.data)),
               "nwknn_search_sharded")
+        return od, oi
+
+    def merge_lists(self, dists, idx, k: int, n_slices: int = 0):
+        """dists / idx: host [n_lists, Q, k] partial lists (idx < 0 = empty) -> ([Q,k], [Q,k]) by (distance, index): the merge step of a
+        multi-device search (query rows in ``n_slices`` slices, default one per device; sliced and two-level merge) on lists the caller
+        gathered -- merge.py:56-101 across any number of lists."""
+        d = np.ascontiguousarray(dists, dtype=np.float32)
+        i = np.ascontiguousarray(idx, dtype=np.int64)
+        if d.ndim != 3 or d.shape != i.shape or d.shape[2] != int(k):
+            raise ValueError(f"expected [n_lists, Q, {k}] distances and indices, got {d.shape} / {i.shape}")
+        od = np.empty(d.shape[1:], dtype=np.float32)
+        oi = np.empty(d.shape[1:], dtype=np.int64)
+        check(self._L.nwknn_comm_merge_lists(self._c, ctypes.c_void_p(d.ctypes.data), ctypes.c_void_p(i.ctypes.data), d.shape[0], d.shape[1], int(k),
+                                             int(n_slices) or len(self.devices), ctypes.c_void_p(od.ctypes.data), ctypes.c_void_p(oi.ctypes.data)),
+              "nwknn_comm_merge_lists")
         return od, oi
 
     def stats(self) -> dict:

@@ -118,6 +118,18 @@ class ParquetRows:
             return self.schema.empty_table()
         return pieces[0] if len(pieces) == 1 else pa.concat_tables(pieces)       # concat_tables keeps the chunks: no copy
 
+    def provenance(self) -> str:
+        """What the rows come from, for a resume checkpoint to be tied to: every file's path, size and modification time, the window's
+        row count and columns (a stale checkpoint of another job with the same counts must not be folded into this one)."""
+        import hashlib
+        import os
+        h = hashlib.sha1()
+        for path in self.paths:
+            st = os.stat(path)
+            h.update(f"{os.path.abspath(path)}|{st.st_size}|{st.st_mtime_ns}\n".encode())
+        h.update(f"rows={self._count}|cols={len(self._columns)}|{self._columns[0] if self._columns else ''}..{self._columns[-1] if self._columns else ''}".encode())
+        return h.hexdigest()
+
     def to_table(self) -> pa.Table:
         return self.slice(0, self._count)
 
@@ -127,6 +139,41 @@ class ParquetRows:
             raise ValueError("batch_rows must be positive")
         for off in range(int(start), self._count, int(batch_rows)):
             yield self.slice(off, batch_rows)
+
+
+class TableRows:
+    """The same face over rows that are already in memory (a pyarrow Table: the materialising fallback of cu_knn_ds.slice_dataset, or a
+    dataset without files behind it)."""
+
+    def __init__(self, table: pa.Table):
+        self._t = table
+
+    def __len__(self) -> int:
+        return len(self._t)
+
+    num_rows = property(__len__)
+
+    @property
+    def column_names(self) -> List[str]:
+        return list(self._t.column_names)
+
+    @property
+    def schema(self) -> pa.Schema:
+        return self._t.schema
+
+    def select(self, columns: Sequence[str]) -> "TableRows":
+        return TableRows(self._t.select(list(columns)))
+
+    def slice(self, offset: int = 0, length: Optional[int] = None) -> pa.Table:
+        return self._t.slice(offset, length)
+
+    def to_table(self) -> pa.Table:
+        return self._t
+
+    def provenance(self) -> str:
+        """In-memory rows have no file identity: a checkpoint written over them is only good inside this process."""
+        import os
+        return f"memory:{os.getpid()}:{id(self._t)}:{len(self._t)}x{self._t.num_columns}"
 
 
 class Prefetch:

@@ -36,11 +36,21 @@ def _worker(rank, world, port, out_dir):
         dd, ii = orc.knn_canonical(base, qs.numpy(), kk, "sqeuclidean")
         return torch.from_numpy(dd), torch.from_numpy(ii + offset)
 
+    merged_rows = []
+
     def merge(gd, gi, kk):
+        assert gd.shape[0] == world and gd.is_contiguous() and gi.is_contiguous()
+        merged_rows.append(gd.shape[1])
         dd, ii = orc.merge_partials(gd.numpy(), gi.numpy(), kk)
         return torch.from_numpy(dd), torch.from_numpy(ii)
 
-    dist, idx = sharded_search(search_shard, merge, queries, k, lo, None)
+    timings = {}
+    dist, idx = sharded_search(search_shard, merge, queries, k, lo, None, timings)               # default: rank g merges its slice of the query rows
+    qlo, qhi = shard_bounds(Q, world, rank)
+    assert merged_rows == [qhi - qlo], merged_rows                                                 # 21 queries over 2 ranks: 10 and 11 rows, not 21
+    assert timings["allgather_bytes"] == world * Q * k * 12 and timings["slices_bytes"] == world * 11 * k * 12 and timings["merge_ms"] >= 0.0
+    rdist, ridx = sharded_search(search_shard, merge, queries, k, lo, None, None, "replicated")    # every rank merges everything: the same table
+    assert merged_rows == [qhi - qlo, Q] and torch.equal(rdist, dist) and torch.equal(ridx, idx)
     np.savez(Path(out_dir) / f"rank{rank}.npz", dist=dist.numpy(), idx=idx.numpy())
     td.barrier()
     td.destroy_process_group()

@@ -128,6 +128,9 @@ def test_bench_starts_its_own_ranks_when_typed_as_the_driver_types_it():
     c = b["collective"]
     assert c["backend"] == "gloo" and c["allgather_ms"] > 0.0 and c["merge_ms"] > 0.0 and c["allgather_bytes_per_rank"] == 2 * 4096 * 100 * 12
     assert len(c["rank_kernel_ms_per_step"]) == 2 and all(x > 0.0 for x in c["rank_kernel_ms_per_step"])
+    assert "torch.distributed" in c["kind"] and c["sharding"].startswith("base rows") and "query slice" in c["sharding"] and c["slices_allgather_ms"] > 0.0
+    pre = b["exact_prescreen"]                                     # the pre-screened leg shards the QUERY rows (the whole base fits a GPU): same bits
+    assert pre["identical_to_direct"] is True and pre["collective"]["sharding"].startswith("query rows") and pre["collective"]["merge_ms"] == 0.0
     assert "torch.distributed.run" in r.stderr                     # the parent said what it started
 
 
@@ -142,3 +145,22 @@ def test_bench_over_rccl_refuses_more_ranks_than_gpus():
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode != 0
     assert f"needs {n} GPUs" in (r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
+def test_bench_drives_the_in_library_collective():
+    """--collective inlib: the bench line produced through the C ABI's own multi-GPU entry points (nwknn_comm_create / generate_base /
+    nwknn_search_sharded: RCCL inside libnwknn.so, one process) instead of torch.distributed -- with the one device this box has, checked
+    against a single-engine search."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--collective", "inlib", "--workload", "dev", "--steps", "2", "--warmup", "1",
+                        "--verify"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    bench = [x for x in lines if "metric" in x]
+    verify = [x for x in lines if "verify" in x]
+    assert len(bench) == 1 and len(verify) == 1 and verify[0]["ok"] is True
+    b = bench[0]
+    assert b["n_gpus"] == 1 and b["ranks"] == 1 and b["value"] > 0 and 0.0 < b["roofline"]["frac"] < 1.0
+    c = b["collective"]
+    assert "in-library" in c["kind"] and c["backend"] == "rccl" and c["allgather_ms"] > 0.0 and c["merge_ms"] > 0.0 and c["search_ms"] > 0.0
+    assert c["allgather_bytes_per_rank"] == 4096 * 100 * 12

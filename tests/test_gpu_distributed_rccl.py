@@ -50,3 +50,33 @@ def test_rccl_allgather_branch_runs_on_the_gpu_box(tmp_path):
     import json
     line = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")][-1]
     assert line["ok"] is True and line["allgather_ms"] > 0.0 and line["bytes"] == 300 * 20 * 12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_lists,k,n_slices", [(8, 1000, 3), (5, 100, 4), (64, 64, 7), (2, 10, 1), (3, 33, 50)])
+def test_the_sliced_and_two_level_merge_of_a_multi_device_search(oracle, n_lists, k, n_slices):
+    """What devices 1..N-1 of nwknn_search_sharded do has never run on hardware (one-GPU boxes): a query slice that does not start at row
+    0, lists whose stride is not the slice's own size, and -- from 4096 (list, rank) entries per query on -- the two-level fold.  The same
+    code (merge_slice behind nwknn_comm_merge_lists) is driven here on one device with caller-built lists: random partial lists with
+    cross-list equal distances (ties go to the lower index), empty slots, more slices than rows in one case; checked against the oracle's
+    merge (= the reference's fold, tests/golden/merge_*.npz) bit for bit."""
+    import numpy as np
+    from neighborhoodwatch_amd import ShardedKnnEngine
+    rng = np.random.default_rng(n_lists * 1000 + k)
+    nq = 37
+    pool = np.sort(rng.random(200).astype(np.float32))                      # few distinct distances: ties within and across lists
+    dists = np.sort(rng.choice(pool, size=(n_lists, nq, k)), axis=2).astype(np.float32)
+    idx = np.empty((n_lists, nq, k), dtype=np.int64)
+    for l in range(n_lists):                                                 # shard l owns ids [l * 10^6, (l+1) * 10^6): distinct within a query
+        for q in range(nq):
+            ids = np.sort(rng.choice(1_000_000, size=k, replace=False)) + l * 1_000_000
+            order = np.lexsort((ids, dists[l, q]))                           # a partial list is sorted by (distance, index)
+            idx[l, q] = ids[order]
+            dists[l, q] = dists[l, q][order]
+    idx[-1, :, k - k // 4:] = -1                                             # the last list is short: empty slots
+    dists[-1, :, k - k // 4:] = np.inf
+    rd, ri = oracle.merge_partials(dists, idx, k)
+    with ShardedKnnEngine([0]) as eng:
+        od, oi = eng.merge_lists(dists, idx, k, n_slices)
+    assert np.array_equal(oi, ri)
+    assert np.array_equal(od.view(np.uint32), rd.view(np.uint32))

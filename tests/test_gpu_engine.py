@@ -446,22 +446,37 @@ def test_c_abi_collective_refuses_bad_device_lists(engine, oracle):
     assert np.array_equal(i, ri) and _same_bits(d, rd)
 
 
-def test_handles_left_open_are_destroyed_before_the_interpreter_tears_down():
+def test_handles_left_open_are_destroyed_before_the_interpreter_tears_down(tmp_path):
     """A process that exits with engines still open (the module-level default engine of `knn()`, one in a global, one in a reference
-    cycle) must exit with 0: the handles are destroyed in an atexit hook while the HIP runtime is up, not from __del__ during
-    interpreter finalization (an intermittent segfault after a green run otherwise)."""
+    cycle, a ShardedKnnEngine) must exit with 0, and every handle must have been destroyed by the package's atexit hook -- the first
+    thing interpreter shutdown runs -- so that no HIP call is made from a __del__ during finalization.  ONE child process, under
+    faulthandler: a fault would name its Python frame on stderr; whatever is not clean (exit status, stderr) is kept under gpurun_out/
+    so that a recurrence of round 3's unrecorded exit-time signal leaves evidence instead of a guess."""
     import subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
     code = (
+        "import atexit, sys\n"
+        "def report():\n"                                            # registered FIRST, so it runs LAST: after the package's hook
+        "    from neighborhoodwatch_amd import engine as E\n"
+        "    print('closed_at_exit', E._closed_at_exit, 'still_open', sum(1 for o in list(E._live) if o._is_open()), flush=True)\n"
+        "atexit.register(report)\n"
         "import numpy as np\n"
-        "from neighborhoodwatch_amd import KnnEngine, knn\n"
+        "from neighborhoodwatch_amd import KnnEngine, ShardedKnnEngine, knn\n"
         "b = np.random.default_rng(0).standard_normal((3000, 64)).astype(np.float32)\n"
         "d, i = knn(b, b[:10], 5)\n"
         "assert (i[:, 0] == np.arange(10)).all()\n"
         "G = KnnEngine(0); G.set_prescreen(True); G.set_base(b); G.search(b[:300], 5)\n"
         "class C: pass\n"
         "c = C(); c.me = c; c.eng = KnnEngine(0); c.eng.set_base(b)\n"
+        "S = ShardedKnnEngine([0]); S.set_base(b); S.search(b[:20], 5)\n"
+        "import torch; t = torch.ones(8, device='cuda')\n"             # torch's allocator and streams are alive at exit too
         "print('done', flush=True)\n")
-    for _ in range(3):
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
-                           cwd=str(__import__("pathlib").Path(__file__).resolve().parents[1]))
-        assert r.returncode == 0 and "done" in r.stdout, (r.returncode, r.stderr[-2000:])
+    r = subprocess.run([sys.executable, "-X", "faulthandler", "-c", code], capture_output=True, text=True, timeout=300, cwd=str(root))
+    clean = r.returncode == 0 and "done" in r.stdout and "closed_at_exit 4 still_open 0" in r.stdout and "Fatal Python error" not in r.stderr \
+        and "still open when the interpreter finalised" not in r.stderr
+    if not clean:
+        keep = root / "gpurun_out"
+        keep.mkdir(exist_ok=True)
+        (keep / "exit_fault_child.log").write_text(f"returncode {r.returncode}\n--- stdout\n{r.stdout}\n--- stderr\n{r.stderr}\n")
+    assert clean, (r.returncode, r.stdout[-500:], r.stderr[-3000:])

@@ -359,7 +359,7 @@ def test_the_invariant_is_counted_on_every_rescored_pair(pre_engine, oracle):
 @pytest.mark.drives_fallback
 @pytest.mark.parametrize("metric", ADDITIVE)
 def test_a_failed_invariant_sends_the_search_to_the_direct_kernel_same_bits(oracle, metric, capfd):
-    """Option pre_check_pct = 1 holds the invariant against 1 % of the bound: real pairs exceed that, the attempt is discarded, the
+    """Option pre_check_ppm = 10000 holds the invariant against 1 % of the bound: real pairs exceed that, the attempt is discarded, the
     search runs again on the direct fp32 kernel and says so -- and the result is the canonical one, bit for bit."""
     from neighborhoodwatch_amd import KnnEngine
     base, queries = oracle.gen(0x93, 0, 40000, 384), oracle.gen(0x94, 0, 300, 384)
@@ -367,16 +367,16 @@ def test_a_failed_invariant_sends_the_search_to_the_direct_kernel_same_bits(orac
     with KnnEngine(0) as eng:
         eng.set_prescreen(True)
         eng.set_base(base)
-        eng.set_option("pre_check_pct", 1)
+        eng.set_option("pre_check_ppm", 10_000)
         dist, idx = eng.search(queries, 50, metric)
         st = eng.stats()
         assert st["prescreen"] == 0 and st["prescreen_fallbacks"] == 1 and st["prescreen_violations"] > 0, st
         assert np.array_equal(idx, ri) and _bitwise(dist, rd)
         assert "pre-screen invariant failed" in capfd.readouterr().err
-        eng.set_option("pre_check_pct", 100)
+        eng.set_option("pre_check_ppm", 1_000_000)
         dist, idx = eng.search(queries, 50, metric)
         st = eng.stats()
         assert st["prescreen"] == 1 and st["prescreen_fallbacks"] == 0 and st["prescreen_violations"] == 0
         assert np.array_equal(idx, ri) and _bitwise(dist, rd)
         with pytest.raises(ValueError):
-            eng.set_option("pre_check_pct", 0)
+            eng.set_option("pre_check_ppm", 0)

@@ -316,6 +316,27 @@ def test_slice_dataset_is_lazy_and_checkpoints_round_trip(tmp_path):
     assert merge.get_file_count(str(tmp_path / "partial")) == 0                             # checkpoints are not partial pairs
     cu_knn_ds._drop_checkpoint(str(tmp_path))
     assert cu_knn_ds._load_checkpoint(str(tmp_path), "sqeuclidean", 5, 12, 1000) is None
+    # a checkpoint is tied to its INPUT FILES (path, size, mtime, columns), not only to counts: another job's leftover with the same
+    # shape in the same data_dir is not resumed
+    rows = cu_knn_ds._as_rows(w, cu_knn_ds.get_dataset_columns(w, 8))
+    prov = rows.provenance()
+    assert prov == cu_knn_ds._as_rows(cu_knn_ds.slice_dataset(d, 0, 20), cu_knn_ds.get_dataset_columns(w, 8)).provenance()
+    assert prov != cu_knn_ds._as_rows(cu_knn_ds.slice_dataset(d, 0, 19), cu_knn_ds.get_dataset_columns(w, 8)).provenance()
+    cu_knn_ds._write_checkpoint(str(tmp_path), dist, idx, cu_knn_ds._checkpoint_tag("sqeuclidean", 5, 12, 1000, 400, f"q:x;b:{prov}"))
+    assert cu_knn_ds._load_checkpoint(str(tmp_path), "sqeuclidean", 5, 12, 1000, f"q:x;b:{prov}")[0] == 400
+    import os
+    os.utime(f, ns=(1, 1))                                                       # the base file changes under the same name and size
+    prov2 = cu_knn_ds._as_rows(cu_knn_ds.slice_dataset(d, 0, 20), cu_knn_ds.get_dataset_columns(w, 8)).provenance()
+    assert prov2 != prov and cu_knn_ds._load_checkpoint(str(tmp_path), "sqeuclidean", 5, 12, 1000, f"q:x;b:{prov2}") is None
+    # the materialising fallback of slice_dataset (start > 0) yields a dataset with no files behind it: rows come from memory
+    from neighborhoodwatch_amd.parquet_stream import TableRows
+    mem = cu_knn_ds.slice_dataset(d, 5, 25)
+    mrows = cu_knn_ds._as_rows(mem, cu_knn_ds.get_dataset_columns(mem, 8))
+    assert isinstance(mrows, TableRows) and len(mrows) == 20 and mrows.column_names == [f"embedding_{j}" for j in range(8)]
+    assert mrows.slice(3, 4).num_rows == 4 and mrows.provenance().startswith("memory:")
+    assert np.array_equal(mrows.to_table().column("embedding_0").to_numpy(), synth.gen_rows(6, 5, 20, 8)[:, 0])
+    with pytest.raises(TypeError):
+        cu_knn_ds._as_rows(object(), ["embedding_0"])
 
 
 def test_fixed_size_list_embedding_column(tmp_path):

@@ -1,0 +1,45 @@
+"""CPU (hipcc cross-compiles without a GPU): the register budgets the kernels' occupancy depends on, read from the compiler's own
+metadata.  The fp32 tile kernel runs THREE workgroups per CU only while its 256-row shape stays within 168 VGPRs, and its speed
+depended for two rounds on a handful of spilled registers whose number moved with unrelated code; the fp16 ping-pong
+kernel must not touch scratch at all at its tile rate.  A toolchain bump that moves either is seen here, not on the GPU box."""
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+CSRC = ROOT / "neighborhoodwatch_amd" / "csrc"
+sys.path.insert(0, str(ROOT / "tools"))
+
+
+@pytest.fixture(scope="module")
+def metadata():
+    import isa_report
+    files = [CSRC / "nwk_tile_f32.hip", CSRC / "nwk_tile_f16x_pre.hip"]
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        md = list(pool.map(isa_report.kernel_metadata, files))
+    return {"f32": md[0], "f16x": md[1]}
+
+
+def test_fp32_tile_kernel_keeps_three_workgroups_per_cu(metadata):
+    md = metadata["f32"]
+    for metric, max_spill in ((0, 7), (1, 7), (2, 40)):       # cosine's epilogue (two square roots and a division per output) is the heavy one
+        k = md[f"nwk_tile_kernel<{metric}, false, 256, 16, 0, 3>"]
+        assert k["vgpr"] <= 168 and k["agpr"] == 0, k          # 3 x 168 <= 512 registers per SIMD lane
+        assert k["lds"] <= 160 * 1024 // 3, k                  # three 48 KiB workgroups share a CU's 160 KiB
+        assert k["vgpr_spill"] <= max_spill and k["sgpr_spill"] == 0, k
+        assert k["mfma"] == 64 and k["lds_dma"] == 12, k       # one 16-float slab = 2 x 4 k-pairs x (4 x 2) accumulators, unrolled once; 6 LDS-DMA per slab (prologue + loop)
+    for name, k in md.items():
+        if name.endswith(", 0, 2>"):                           # the two-per-CU builds (dense chunk, 128-row shape) never spill
+            assert k["vgpr_spill"] == 0 and k["scratch"] == 0, (name, k)
+    assert md["nwk_tile_kernel<0, false, 128, 32, 0, 2>"]["lds"] == 65536
+
+
+def test_fp16_ping_pong_kernel_never_touches_scratch(metadata):
+    md = metadata["f16x"]
+    for metric in (0, 1, 2):
+        k = md[f"nwk_tile_kernel_f16x<{metric}, 1>"]
+        assert k["vgpr"] <= 256 and k["vgpr_spill"] == 0 and k["sgpr_spill"] == 0 and k["scratch"] == 0, k      # two waves per SIMD: 256 registers each
+        assert k["lds"] <= 160 * 1024, k
+        assert k["mfma"] == 256, k                              # 4 call sites x 64 MFMAs of one slab
