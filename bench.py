@@ -263,6 +263,19 @@ class Bench:
                 name, value = kv.split("=")
                 self.eng.set_option(name, int(value))
 
+    # ---- what this device's matrix pipes deliver with nothing in the way ----------------------------------------------------------------
+    def ceiling(self, dtype):
+        """nwknn_mfma_ceiling, once per dtype and process: TFLOP/s and in-kernel clock of a bare MFMA loop on random operands (1 s of
+        back-to-back launches, the second half timed) -- the power-limited rate of THIS device, which the nominal peak ignores."""
+        if not hasattr(self, "_ceil"):
+            self._ceil = {}
+        if dtype not in self._ceil:
+            try:
+                self._ceil[dtype] = self.eng.mfma_ceiling(dtype, 1.0)
+            except Exception as e:                                      # a calibration figure must never cost the line
+                self._ceil[dtype] = {"error": f"{type(e).__name__}: {e}"}
+        return self._ceil[dtype]
+
     # ---- what torch.distributed saw ---------------------------------------------------------------------------------------------
     def devices(self):
         torch, td = self.torch, self.td
@@ -381,7 +394,12 @@ class Bench:
             # one launch per search is the dense first chunk (cap/2 base rows, a different template instance in the
             # rocprofv3 stats, ~1 ms): the per-launch figures are over the filtered launches that carry the work
             n_l = max(agg_["tile_launches"] - n_steps, 1)
-            return {"bound": "mfma", "achieved": ach, "peak": pk, "unit": "TFLOP/s", "frac": ach / pk, "traffic": traffic,
+            bare = self.ceiling("f16" if pk > 1000 else "f32") if world == 1 else {}
+            extra = ({"bare_loop_tflops": bare["tflops"], "bare_loop_clock_ghz": bare["clock_ghz"], "frac_of_bare_loop": ach / bare["tflops"],
+                      "bare_loop_note": "nwknn_mfma_ceiling on this device: the same MFMA instruction back to back on random operands in registers, "
+                                        "same register tile and waves per SIMD, no operand traffic, no epilogue"}
+                     if bare.get("tflops") else ({"bare_loop_error": bare["error"]} if "error" in bare else {}))
+            return {"bound": "mfma", "achieved": ach, "peak": pk, "unit": "TFLOP/s", "frac": ach / pk, **extra, "traffic": traffic,
                     "traffic_note": "bytes per launch, rocprofv3 PMC passes recorded in profiles/ (not sampled live; quoted only when recorded on this kernel)",
                     "kernel": kernel, "launches": n_l, "avg_launch_ms": agg_["tile_ms"] / n_l, "flops_per_launch": agg_["tile_flops"] / n_l}
 

@@ -224,6 +224,15 @@ int nwknn_maxsim_set_docs(nwknn_handle h, const void* doc_tokens, int64_t n_docs
 int nwknn_maxsim_search(nwknn_handle h, const void* query_tokens, int64_t n_queries, int32_t tokens_per_query, int dtype,
                         int location, int32_t k, int64_t doc_offset, float* out_score, int64_t* out_doc, int out_location);
 
+/* ---- device calibration (no reference counterpart) ----------------------------------------------------------------------------
+ * TFLOP/s of a BARE MFMA loop on this device, on seeded random operands held in registers -- no LDS, no LDS-DMA, no global memory, no
+ * epilogue -- at the register tile and waves per SIMD of the tile kernel of that dtype (f16: v_mfma_f32_16x16x32_f16, 8 x 4 accumulators,
+ * two waves per SIMD; f32: v_mfma_f32_32x32x2_f32, 4 x 2, three workgroups per CU), launched back to back for `seconds` and timed over
+ * the second half.  Under dense MFMA work the chip holds its clock well below the 2.4 GHz the nominal peaks assume (power limit), by a
+ * device-dependent amount: this is what a kernel on THIS device can be held against (bench.py: roofline.frac_of_bare_loop).
+ * out_clock_ghz (optional): the in-kernel clock, cycles per 100 MHz tick, median over workgroups. */
+int nwknn_mfma_ceiling(nwknn_handle h, int dtype, double seconds, double* out_tflops, double* out_clock_ghz);
+
 /* ---- synthetic inputs (no reference counterpart: generate_dataset.py needs the network) ----------------- */
 /* Fill device buffer out[rows][d] with value(seed, row0 + r, c) in [-1,1): float32 on a 2^-23 grid, or fp16 on a
  * 2^-10 grid (the top bits of the same draw); the same integer recipe as oracle/cpu_oracle.gen_numpy /

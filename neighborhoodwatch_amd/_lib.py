@@ -30,7 +30,7 @@ EXPORTS = [
     "nwknn_set_base_column_chunks", "nwknn_search_column_chunks",
     "nwknn_maxsim_set_docs", "nwknn_maxsim_search", "nwknn_tile_kernel_name",
     "nwknn_comm_create", "nwknn_comm_destroy", "nwknn_comm_device_count", "nwknn_comm_engine", "nwknn_comm_set_option",
-    "nwknn_comm_set_base", "nwknn_comm_generate_base", "nwknn_search_sharded", "nwknn_comm_get_stats", "nwknn_comm_merge_lists",
+    "nwknn_comm_set_base", "nwknn_comm_generate_base", "nwknn_search_sharded", "nwknn_comm_get_stats", "nwknn_comm_merge_lists", "nwknn_mfma_ceiling",
 ]
 
 
@@ -130,6 +130,7 @@ def load() -> ctypes.CDLL:
     L.nwknn_comm_generate_base.argtypes = [c_void_p, c_uint64, c_int64, c_int32, c_int]
     L.nwknn_search_sharded.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int32, c_int, c_void_p, c_void_p]
     L.nwknn_comm_get_stats.argtypes = [c_void_p, POINTER(NwknnCommStats)]
+    L.nwknn_mfma_ceiling.argtypes = [c_void_p, c_int, c_double, POINTER(c_double), POINTER(c_double)]
     L.nwknn_comm_merge_lists.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p]
     for name in EXPORTS:
         fn = getattr(L, name)

@@ -176,7 +176,7 @@ extern "C++" {
 template <int METRIC, int TM, int BKT>
 static hipError_t launch_tile_shape(hipStream_t st, const NwkTileParams& p, bool dense, unsigned grid, int diag, int occ)
 {
-    // <256,16>: 48 KiB of LDS per workgroup, so THREE fit a CU if the kernel stays within 168 VGPRs (it does, with 7 spilled
+    // <256,16>: 48 KiB of LDS per workgroup, so THREE fit a CU if the kernel stays within 168 VGPRs (it does, with 5 spilled
     // outside the K loop): the third workgroup's MFMAs fill what the barriers, DMA issue and tile turnarounds of the other two
     // leave idle -- C3: 144.3 -> 148.6 TF (+3.0 %, same-box A/B).  <128,32> needs 64 KiB: two per CU.  (A 128 x 128 tile on
     // 16-float slabs fits FOUR per CU -- 112 VGPRs, 32 KiB -- and is slower: 145.4 TF, a third more operand bytes per FLOP.)

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
@@ -124,7 +125,7 @@ struct nwknn_ctx {
     long long nb_pad_for_copy = 0;
     int dp_for_copy = 0;
     // running top-k state
-    DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i, ctab, chk;
+    DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i, ctab, chk, calib;
     // options
     long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 0, opt_f16_agg = -1, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128, opt_pre_check_ppm = 1000000;
     int num_cu = 256;
@@ -253,7 +254,7 @@ extern "C" int nwknn_destroy(nwknn_handle h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->bp, &h->bn, &h->braw, &h->qraw, &h->qp, &h->qn, &h->tau, &h->cnt, &h->buf, &h->ovf, &h->ovf_any, &h->qtiles,
-                      &h->out_d, &h->out_i, &h->mrg_d, &h->mrg_i, &h->ctab, &h->chk, &h->bp16, &h->qp16, &h->cnt0, &h->scal, &h->ms_rq, &h->ms_cd, &h->ms_surv, &h->ms_nsurv})
+                      &h->out_d, &h->out_i, &h->mrg_d, &h->mrg_i, &h->ctab, &h->chk, &h->calib, &h->bp16, &h->qp16, &h->cnt0, &h->scal, &h->ms_rq, &h->ms_cd, &h->ms_surv, &h->ms_nsurv})
         b->release();
     for (EvPair& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (int i = 0; i < 2; ++i) {
@@ -1397,6 +1398,61 @@ extern "C" int nwknn_merge(nwknn_handle h, const float* dists, const int64_t* id
 }
 
 // ---- synthetic inputs -------------------------------------------------------------------------------
+// ---- device calibration ---------------------------------------------------------------------------------------------------------------
+extern "C" int nwknn_mfma_ceiling(nwknn_handle h, int dtype, double seconds, double* out_tflops, double* out_clock_ghz)
+{
+    if (!h || !out_tflops) return fail(NWKNN_EINVAL, "nwknn_mfma_ceiling: null argument");
+    if (dtype != NWKNN_DTYPE_F32 && dtype != NWKNN_DTYPE_F16) return fail(NWKNN_EINVAL, "nwknn_mfma_ceiling: dtype must be f32 or f16");
+    if (!(seconds > 0.0) || seconds > 30.0) return fail(NWKNN_EINVAL, "nwknn_mfma_ceiling: seconds must be in (0, 30]");
+    RCCHK(use_device(h));
+    const int f16 = dtype == NWKNN_DTYPE_F16;
+    const unsigned grid = (unsigned)h->num_cu * (f16 ? 8u : 12u);          // f16: one 8-wave workgroup per CU at a time; f32: three 4-wave workgroups
+    const int iters = f16 ? 2000 : 1000;                                   // ~20 ms per launch
+    const size_t rnd_bytes = 4u << 20, out_bytes = (size_t)grid * 24;
+    RCCHK(h->calib.ensure(rnd_bytes + out_bytes));
+    char* rnd = h->calib.as<char>();
+    char* out = rnd + rnd_bytes;
+    if (f16) HIPCHK(nwk_launch_gen_f16(h->stream, 0x6E77CA11ull, 0, (long long)(rnd_bytes / 2 / 64), 64, rnd));
+    else HIPCHK(nwk_launch_gen(h->stream, 0x6E77CA11ull, 0, (long long)(rnd_bytes / 4 / 64), 64, (float*)rnd));
+    const double flops_per_launch = (double)grid * (f16 ? 8.0 : 4.0) * iters * 64.0 * (f16 ? 2.0 * 16 * 16 * 32 : 2.0 * 32 * 32 * 2);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(NWKNN_EHIP, "hipEventCreate failed"); }
+    int rc = NWKNN_OK;
+    double best = 0.0;
+    // launches back to back until `seconds` have passed (the clock settles under the load); the rate is that of the second half
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+    int timed = 0;
+    bool timing = false;
+    while (rc == NWKNN_OK) {
+        const double t = elapsed();
+        if (!timing && t >= 0.5 * seconds) { if (hipEventRecord(e0, h->stream) != hipSuccess) rc = fail(NWKNN_EHIP, "hipEventRecord failed"); timing = true; }
+        if (timing && t >= seconds && timed > 0) break;
+        if (nwk_launch_mfma_bare(h->stream, f16, rnd, iters, grid, out) != hipSuccess) { rc = fail(NWKNN_EHIP, "bare MFMA loop launch failed: %s", hipGetErrorString(hipGetLastError())); break; }
+        if (timing) ++timed;
+        if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(NWKNN_EHIP, "bare MFMA loop failed: %s", hipGetErrorString(hipGetLastError())); break; }
+    }
+    if (rc == NWKNN_OK) {
+        float ms = 0.f;
+        if (hipEventRecord(e1, h->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f))
+            rc = fail(NWKNN_EHIP, "timing the bare MFMA loop failed");
+        else best = flops_per_launch * timed / (ms * 1e-3) / 1e12;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    RCCHK(rc);
+    *out_tflops = best;
+    if (out_clock_ghz) {                                                     // median over the workgroups of the last launch: cycles / (100 MHz ticks)
+        std::vector<unsigned long long> raw((size_t)grid * 3);
+        HIPCHK(hipMemcpy(raw.data(), out, out_bytes, hipMemcpyDeviceToHost));
+        std::vector<double> clk;
+        for (unsigned g = 0; g < grid; ++g) if (raw[(size_t)g * 3 + 1] > 0) clk.push_back((double)raw[(size_t)g * 3] / (double)raw[(size_t)g * 3 + 1] * 0.1);
+        std::sort(clk.begin(), clk.end());
+        *out_clock_ghz = clk.empty() ? 0.0 : clk[clk.size() / 2];
+    }
+    return NWKNN_OK;
+}
+
 extern "C" int nwknn_generate(nwknn_handle h, uint64_t seed, int64_t row0, int64_t rows, int32_t d, int dtype, void* out_device)
 {
     if (!h || !out_device) return fail(NWKNN_EINVAL, "nwknn_generate: null argument");

@@ -131,4 +131,5 @@ hipError_t nwk_launch_maxsim_bounds(hipStream_t st, const float* norms, long lon
 hipError_t nwk_launch_maxsim_rescore(hipStream_t st, NwkMsRescoreParams p, long long nq_pad, int slices);
 hipError_t nwk_launch_merge(hipStream_t st, const float* dists, const long long* idx, int n_lists, long long list_stride, long long nq, int k_in,
                             int k_out, float* out_d, long long* out_i);
+hipError_t nwk_launch_mfma_bare(hipStream_t st, int f16, const void* rnd, int iters, unsigned grid, void* out);   // nwk_calib.hip: one launch of the bare MFMA loop; out: grid x {u64 cycles, u64 realtime (100 MHz), float}
 int nwknn_internal_fail(int code, const char* msg);        // sets the calling thread's nwknn_last_error() message, returns code

@@ -414,6 +414,14 @@ class KnnEngine:
         del keep
         return os_, od
 
+    def mfma_ceiling(self, dtype: str = "f16", seconds: float = 1.0) -> dict:
+        """What a bare MFMA loop (random operands in registers, nothing else) delivers on this device: {'tflops', 'clock_ghz'}.  The
+        power-limited ceiling a tile kernel of that dtype can be held against (nwknn_mfma_ceiling)."""
+        tf, clk = ctypes.c_double(), ctypes.c_double()
+        check(self._L.nwknn_mfma_ceiling(self._h, DTYPE_F16 if dtype in ("f16", "fp16") else DTYPE_F32, float(seconds), ctypes.byref(tf), ctypes.byref(clk)),
+              "nwknn_mfma_ceiling")
+        return {"tflops": tf.value, "clock_ghz": clk.value}
+
     def generate(self, seed: int, row0: int, rows: int, dim: int, dtype: str = "f32"):
         """Seeded synthetic rows straight into HBM (torch CUDA tensor [rows, dim], float32 or float16)."""
         import torch

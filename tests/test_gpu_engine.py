@@ -480,3 +480,19 @@ def test_handles_left_open_are_destroyed_before_the_interpreter_tears_down(tmp_p
         keep.mkdir(exist_ok=True)
         (keep / "exit_fault_child.log").write_text(f"returncode {r.returncode}\n--- stdout\n{r.stdout}\n--- stderr\n{r.stderr}\n")
     assert clean, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_bare_mfma_loop_calibration_is_in_the_physical_range():
+    """nwknn_mfma_ceiling: the rate of a bare MFMA loop on random operands on this device.  It cannot exceed the nominal peak (2.4 GHz x
+    the instruction's FLOPs per cycle), and on gfx950 it sits well below it for fp16 (the chip holds its clock down under dense MFMA
+    work); the in-kernel clock it reports is what explains the gap.  bench.py divides the tile kernels' achieved rates by it."""
+    from neighborhoodwatch_amd import KnnEngine
+    with KnnEngine(0) as eng:
+        h = eng.mfma_ceiling("f16", 0.6)
+        f = eng.mfma_ceiling("f32", 0.6)
+        with pytest.raises(ValueError):
+            eng.mfma_ceiling("f16", 0.0)
+    assert 900.0 < h["tflops"] < 2500.0 and 1.0 < h["clock_ghz"] <= 2.45, h
+    assert 110.0 < f["tflops"] < 157.4 and 1.5 < f["clock_ghz"] <= 2.45, f
+    assert abs(h["tflops"] - 2500.0 * h["clock_ghz"] / 2.4) < 0.1 * h["tflops"]          # rate = FLOPs per cycle x the clock held (pipe 100 % busy)
+    assert abs(f["tflops"] - 157.3 * f["clock_ghz"] / 2.4) < 0.1 * f["tflops"]
