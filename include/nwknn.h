@@ -92,7 +92,7 @@ int nwknn_destroy(nwknn_handle h);
 /* Run all work of this handle on an existing HIP stream (hipStream_t, e.g. torch's current stream); NULL
  * restores the handle's own stream. */
 int nwknn_set_stream(nwknn_handle h, void* hip_stream);
-/* Tunables: "capacity" (candidate slots per query, power of two >= 4k), "first_chunk", "max_chunk"
+/* Tunables: "capacity" (candidate slots per query, power of two >= 4k, at most 8192), "first_chunk", "max_chunk"
  * (base rows per launch, multiples of 128; MaxSim: a quarter of it in documents), "profile" (0/1: per-kernel HIP-event timing into nwknn_stats),
  * "compute_dtype" (NWKNN_DTYPE_F32 | NWKNN_DTYPE_F16: with F16 the next nwknn_set_base rounds fp32 input to fp16 and
  * distance tiles run on the fp16 MFMA path with fp32 accumulation), "tile_rows" (0 auto | 128 | 256, fp32 path),
@@ -147,7 +147,8 @@ int nwknn_set_base_columns(nwknn_handle h, const void* const* columns, int64_t r
 /* For each of the nq query rows: the k nearest rows of the base set, ascending by (distance, index),
  * lower index first among equal distances.  out_idx = row number in the base set + index_offset
  * (index_offset plays the role of `+ batch_offset`, cu_knn.py:273: pass the shard's first global row).
- * Requires 0 < k <= base rows (cu_knn.py:177-178,237) and k <= 1024. */
+ * Requires 0 < k <= base rows (cu_knn.py:177-178,237) and k <= 2048 (a query's candidate list is sorted in LDS: 4 k slots of 16 bytes
+ * in a CU's 160 KiB; the reference's operators take any k, its CLI defaults to 100 and `ck` to 1000). */
 int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int dtype, int location, int32_t k, int metric,
                  int64_t index_offset, float* out_dist, int64_t* out_idx, int out_location);
 /* Same with COLUMN-major host queries (cu_knn.py:229-235 converts the query tile the same way as the base tile). */
@@ -208,9 +209,18 @@ int nwknn_comm_get_stats(nwknn_comm_handle c, nwknn_comm_stats* out);
  * dists / idx are HOST arrays [n_lists][nq][k] (idx < 0 marks an empty slot).  The query rows are cut into n_slices contiguous slices the
  * way nwknn_search_sharded cuts them over its devices; slice s is merged on device s mod N of the communicator straight from the lists'
  * own stride, and more than 4096 (list, rank) entries per query are folded in two levels -- the code path of a multi-device search,
- * reachable with any number of lists on any number of devices.  Writes the k smallest by (distance, index) to HOST out_dist / out_idx [nq][k]. */
+ * reachable with any number of lists on any number of devices.  Writes the k best by (distance, index) to HOST out_dist / out_idx [nq][k]. */
 int nwknn_comm_merge_lists(nwknn_comm_handle c, const float* dists_host, const int64_t* idx_host, int32_t n_lists, int64_t nq, int32_t k,
-                           int32_t n_slices, float* out_dist, int64_t* out_idx);
+                           int32_t n_slices, int descending, float* out_dist, int64_t* out_idx);
+/* (descending != 0: the values are SCORES, higher first, ties to the lower id -- the order of nwknn_maxsim_search.) */
+
+/* MaxSim over the devices (BASELINE config 5 names 8 GPUs; like nwknn_maxsim_* an extension with no reference counterpart): documents
+ * sharded contiguously over the devices (HOST doc_tokens [n_docs][tokens_per_doc][d] float32), queries replicated, per-shard top-k with
+ * global document ids, ONE all-gather per array, device g merges its slice of the queries by (score descending, doc id ascending).
+ * With one device: the result of nwknn_maxsim_search. */
+int nwknn_comm_maxsim_set_docs(nwknn_comm_handle c, const void* doc_tokens_host, int64_t n_docs, int32_t tokens_per_doc, int32_t d, int dtype);
+int nwknn_maxsim_search_sharded(nwknn_comm_handle c, const void* query_tokens_host, int64_t n_queries, int32_t tokens_per_query, int dtype,
+                                int32_t k, float* out_score, int64_t* out_doc);
 
 /* ---- MaxSim late interaction (BASELINE.json config 5).  NOT in the reference: its `ck` program runs flat token-level
  *      kNN through process_batches (colbert_knn.py:84-126); this is the ColBERT scoring rule itself, provided as an
@@ -223,6 +233,21 @@ int nwknn_maxsim_set_docs(nwknn_handle h, const void* doc_tokens, int64_t n_docs
  * (score, then lower doc id): out_score float32 [n_queries][k], out_doc int64 [n_queries][k] (+ doc_offset). */
 int nwknn_maxsim_search(nwknn_handle h, const void* query_tokens, int64_t n_queries, int32_t tokens_per_query, int dtype,
                         int location, int32_t k, int64_t doc_offset, float* out_score, int64_t* out_doc, int out_location);
+
+/* ---- self-check: the distances of GIVEN pairs (validate_files_v0, parquet_to_format.py:351-383, recomputes every listed neighbour's
+ *      distance on the CPU, row by row) ---------------------------------------------------------------------------------------------
+ * out_dist[q][j] = the canonical distance (same arithmetic, same bits as nwknn_search) between query row q and base row
+ * idx[q][j] - index_offset of the handle's base set; NaN where that row does not exist (idx < index_offset, empty slots of a merge).
+ * idx lives where the queries live (`location`); 0 < k <= 4096.  With metric NWKNN_METRIC_ONE_MINUS_DOT on unit vectors this is the
+ * validator's `1 - dot(q, b)`. */
+int nwknn_pair_distances(nwknn_handle h, const void* queries, int64_t nq, int dtype, int location, const int64_t* idx, int32_t k, int metric,
+                         int64_t index_offset, float* out_dist, int out_location);
+
+/* The validator's own arithmetic: out_dot[q][j] = the FLOAT64 dot product of query row q and base row idx[q][j] - index_offset (both as the
+ * handle holds them: float32 or float16 values; NaN where the row does not exist) -- parquet_to_format.py:368-373 computes exactly this per
+ * neighbour in Python.  Float64 sums agree with numpy's to ~1e-13, so `isclose(1 - dot, distance / 2)` can be decided from them. */
+int nwknn_pair_dots(nwknn_handle h, const void* queries, int64_t nq, int dtype, int location, const int64_t* idx, int32_t k, int64_t index_offset,
+                    double* out_dot, int out_location);
 
 /* ---- device calibration (no reference counterpart) ----------------------------------------------------------------------------
  * TFLOP/s of a BARE MFMA loop on this device, on seeded random operands held in registers -- no LDS, no LDS-DMA, no global memory, no

@@ -30,7 +30,8 @@ EXPORTS = [
     "nwknn_set_base_column_chunks", "nwknn_search_column_chunks",
     "nwknn_maxsim_set_docs", "nwknn_maxsim_search", "nwknn_tile_kernel_name",
     "nwknn_comm_create", "nwknn_comm_destroy", "nwknn_comm_device_count", "nwknn_comm_engine", "nwknn_comm_set_option",
-    "nwknn_comm_set_base", "nwknn_comm_generate_base", "nwknn_search_sharded", "nwknn_comm_get_stats", "nwknn_comm_merge_lists", "nwknn_mfma_ceiling",
+    "nwknn_comm_set_base", "nwknn_comm_generate_base", "nwknn_search_sharded", "nwknn_comm_get_stats", "nwknn_comm_merge_lists", "nwknn_mfma_ceiling", "nwknn_pair_distances", "nwknn_pair_dots",
+    "nwknn_comm_maxsim_set_docs", "nwknn_maxsim_search_sharded",
 ]
 
 
@@ -88,6 +89,36 @@ def _bind_to_torch_rocm_runtime() -> None:
             pass
 
 
+def _torch_lib_dir():
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    return Path(list(spec.submodule_search_locations)[0]) / "lib"
+
+
+def bind_to_torch_rccl() -> None:
+    """One RCCL per process, loaded in torch's order.  Called when the C ABI's collective is first used (nwknn_comm_create dlopens
+    "librccl.so.1", the copy already in the process first).  PyTorch-ROCm bundles its own librccl.so under that SONAME.  Two orders end in
+    `free(): invalid pointer` / `double free or corruption` (SIGABRT) in the libraries' static destructors at process exit -- AFTER every
+    handle has been destroyed cleanly, so nothing a destroy call does can prevent it:
+      * /opt/rocm's RCCL loaded first, `import torch` afterwards (the system RCCL next to torch's copies of its dependencies:
+        profiles/r04d_exit_fault_child_two_rccl_copies.log);
+      * torch's OWN librccl.so loaded by path first, `import torch` afterwards (profiles/r04e_exit_fault_probe_import_order.log, variant D;
+        variants B -- no torch import at all -- and C -- torch imported first -- exit with 0).
+    What works is torch's own load order, so that is what is forced here: if torch is installed it is imported BEFORE RCCL is touched (its
+    libtorch_hip brings librccl.so in as a dependency) and nwknn_comm_create then finds that copy.  Without torch the system copy is used."""
+    if _torch_lib_dir() is None:
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def load() -> ctypes.CDLL:
     """Load libnwknn.so once and declare every prototype of include/nwknn.h."""
     global _lib
@@ -130,8 +161,12 @@ def load() -> ctypes.CDLL:
     L.nwknn_comm_generate_base.argtypes = [c_void_p, c_uint64, c_int64, c_int32, c_int]
     L.nwknn_search_sharded.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int32, c_int, c_void_p, c_void_p]
     L.nwknn_comm_get_stats.argtypes = [c_void_p, POINTER(NwknnCommStats)]
+    L.nwknn_pair_distances.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int32, c_int, c_int64, c_void_p, c_int]
+    L.nwknn_pair_dots.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int32, c_int64, c_void_p, c_int]
     L.nwknn_mfma_ceiling.argtypes = [c_void_p, c_int, c_double, POINTER(c_double), POINTER(c_double)]
-    L.nwknn_comm_merge_lists.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p]
+    L.nwknn_comm_merge_lists.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int, c_void_p, c_void_p]
+    L.nwknn_comm_maxsim_set_docs.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int]
+    L.nwknn_maxsim_search_sharded.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int, c_int32, c_void_p, c_void_p]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("nwknn_last_error", "nwknn_tile_kernel_name", "nwknn_comm_engine"):

@@ -303,11 +303,70 @@ __global__ __launch_bounds__(256) void nwk_finalize_kernel(const u64* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// explicit pairs (nwknn_pair_distances): idx [nq][k] -> list slots the rescoring kernel recomputes, and back
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nwk_pairs_to_keys_kernel(const long long* __restrict__ idx, long long nq, long long nq_pad, int k, int cap,
+                                                                 long long index_offset, long long nb, u64* __restrict__ buf,
+                                                                 u32* __restrict__ cnt, u32* __restrict__ cnt0)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < nq_pad) { cnt[i] = i < nq ? (u32)k : 0u; cnt0[i] = 0u; }
+    if (i >= nq * k) return;
+    const long long q = i / k;
+    const int j = (int)(i - q * k);
+    const long long row = idx[i] - index_offset;
+    buf[q * cap + j] = (row >= 0 && row < nb) ? (u64)(u32)row : ~0ull;        // ~0: an empty slot, left alone by the rescoring kernel
+}
+
+__global__ __launch_bounds__(256) void nwk_keys_to_distances_kernel(const u64* __restrict__ buf, long long nq, int k, int cap, float* __restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq * k) return;
+    const long long q = i / k;
+    const u64 key = buf[q * cap + (int)(i - q * k)];
+    out[i] = key == ~0ull ? __builtin_nanf("") : unsortable_f32((u32)(key >> 32));
+}
+
+// float64 dot products of given pairs (nwknn_pair_dots): one lane per pair, both prepared rows walked 16 B at a time.  The prepared fp32
+// layout permutes k inside groups of 8 -- the same way on both sides, and a sum does not care.  The validator's arithmetic
+// (parquet_to_format.py:368-373 works in float64), not the engine's canonical fp32 chain.
+template <bool ROWS16>
+__global__ __launch_bounds__(256) void nwk_pair_dots_kernel(const void* __restrict__ qp, const void* __restrict__ bp, const long long* __restrict__ idx,
+                                                             long long nq, int k, int dp, long long index_offset, long long nb, double* __restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq * k) return;
+    const long long q = i / k;
+    const long long row = idx[i] - index_offset;
+    if (row < 0 || row >= nb) { out[i] = __builtin_nan(""); return; }
+    double acc = 0.0;
+    if (ROWS16) {
+        const f16x8* a = (const f16x8*)((const _Float16*)qp + q * dp);
+        const f16x8* b = (const f16x8*)((const _Float16*)bp + row * dp);
+        for (int c = 0; c < dp / 8; ++c) {
+            const f16x8 x = a[c], y = b[c];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc = fma((double)(float)x[t], (double)(float)y[t], acc);
+        }
+    } else {
+        const f32x4* a = (const f32x4*)((const float*)qp + q * dp);
+        const f32x4* b = (const f32x4*)((const float*)bp + row * dp);
+        for (int c = 0; c < dp / 4; ++c) {
+            const f32x4 x = a[c], y = b[c];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = fma((double)x[t], (double)y[t], acc);
+        }
+    }
+    out[i] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
 // merge of n_lists partial top-k lists [n_lists][Q][k_in] by (distance, index)   (merge.py:73-101)
 // ------------------------------------------------------------------------------------------------
+// descending != 0: the values are SCORES, higher first (MaxSim): ranked through their negation, so ties still go to the lower index
 __global__ __launch_bounds__(256) void nwk_merge_kernel(const float* __restrict__ dists, const long long* __restrict__ idx, int n_lists,
                                                          long long list_stride, int k_in, int k_out, float* __restrict__ out_d,
-                                                         long long* __restrict__ out_i, int np2)
+                                                         long long* __restrict__ out_i, int np2, int descending)
 {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     u32* sd = (u32*)dyn;                            // sortable distance
@@ -320,7 +379,7 @@ __global__ __launch_bounds__(256) void nwk_merge_kernel(const float* __restrict_
             const int lst = i / k_in, j = i - lst * k_in;
             const long long at = (long long)lst * list_stride + q * k_in + j;        // list_stride: entries between two lists (nq * k_in when they are dense)
             const long long id = idx[at];
-            sd[i] = id < 0 ? 0xFFFFFFFFu : sortable_u32(dists[at]);
+            sd[i] = id < 0 ? 0xFFFFFFFFu : sortable_u32(descending ? -dists[at] : dists[at]);
             si[i] = id < 0 ? 0x7FFFFFFFFFFFFFFFll : id;
         } else { sd[i] = 0xFFFFFFFFu; si[i] = 0x7FFFFFFFFFFFFFFFll; }
     }
@@ -342,7 +401,8 @@ __global__ __launch_bounds__(256) void nwk_merge_kernel(const float* __restrict_
     }
     for (int j = tid; j < k_out; j += 256) {
         const bool ok = j < np2 && si[j] != 0x7FFFFFFFFFFFFFFFll;
-        out_d[q * k_out + j] = ok ? unsortable_f32(sd[j]) : __builtin_inff();
+        const float v = ok ? unsortable_f32(sd[j]) : __builtin_inff();
+        out_d[q * k_out + j] = descending ? -v : v;
         out_i[q * k_out + j] = ok ? si[j] : -1;
     }
 }
@@ -390,17 +450,45 @@ hipError_t nwk_launch_finalize(hipStream_t st, const u64* buf, const u32* cnt, i
     return hipGetLastError();
 }
 
+hipError_t nwk_launch_pairs_to_keys(hipStream_t st, const long long* idx, long long nq, long long nq_pad, int k, int cap, long long index_offset,
+                                    long long nb, u64* buf, u32* cnt, u32* cnt0)
+{
+    const long long total = nq * k > nq_pad ? nq * k : nq_pad;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(nwk_pairs_to_keys_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, idx, nq, nq_pad, k, cap, index_offset, nb, buf, cnt, cnt0);
+    return hipGetLastError();
+}
+
+hipError_t nwk_launch_pair_dots(hipStream_t st, int rows16, const void* qp, const void* bp, const long long* idx, long long nq, int k, int dp,
+                                long long index_offset, long long nb, double* out)
+{
+    const long long total = nq * k;
+    if (total <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (rows16) hipLaunchKernelGGL(nwk_pair_dots_kernel<true>, dim3(grid), dim3(256), 0, st, qp, bp, idx, nq, k, dp, index_offset, nb, out);
+    else hipLaunchKernelGGL(nwk_pair_dots_kernel<false>, dim3(grid), dim3(256), 0, st, qp, bp, idx, nq, k, dp, index_offset, nb, out);
+    return hipGetLastError();
+}
+
+hipError_t nwk_launch_keys_to_distances(hipStream_t st, const u64* buf, long long nq, int k, int cap, float* out)
+{
+    const long long total = nq * k;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(nwk_keys_to_distances_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, buf, nq, k, cap, out);
+    return hipGetLastError();
+}
+
 // lists l = 0..n_lists-1 start list_stride entries apart (dense [n_lists][nq][k_in]: list_stride = nq * k_in; a slice of the query rows of
 // gathered lists: the stride of the whole lists)
 hipError_t nwk_launch_merge(hipStream_t st, const float* dists, const long long* idx, int n_lists, long long list_stride, long long nq, int k_in,
-                            int k_out, float* out_d, long long* out_i)
+                            int k_out, float* out_d, long long* out_i, int descending)
 {
     if (nq <= 0) return hipSuccess;
     int np2 = 2;
     while (np2 < n_lists * k_in) np2 <<= 1;
     const size_t lds = (size_t)np2 * 12;
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(nwk_merge_kernel, dim3((unsigned)nq), dim3(256), lds, st, dists, idx, n_lists, list_stride, k_in, k_out, out_d, out_i, np2);
+    hipLaunchKernelGGL(nwk_merge_kernel, dim3((unsigned)nq), dim3(256), lds, st, dists, idx, n_lists, list_stride, k_in, k_out, out_d, out_i, np2, descending);
     return hipGetLastError();
 }
 

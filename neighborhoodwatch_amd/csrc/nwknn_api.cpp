@@ -285,7 +285,7 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
         return fail(NWKNN_EINVAL, "option '%s'=%lld exists in developer builds of libnwknn only (-DNWKNN_DEV): it changes or unguards results", name, (long long)value);
     if (!h) return fail(NWKNN_EINVAL, "null handle or option name");
     if (!strcmp(name, "capacity")) {
-        if (value != 0 && (value < 256 || value > 4096 || (value & (value - 1)))) return fail(NWKNN_EINVAL, "capacity must be 0 (auto) or a power of two in [256, 4096]");
+        if (value != 0 && (value < 256 || value > NWK_MAX_CAPACITY || (value & (value - 1)))) return fail(NWKNN_EINVAL, "capacity must be 0 (auto) or a power of two in [256, %d]", NWK_MAX_CAPACITY);
         h->opt_capacity = value;
     } else if (!strcmp(name, "first_chunk")) {
         if (value < 0) return fail(NWKNN_EINVAL, "first_chunk must be non-negative");
@@ -672,7 +672,7 @@ static int make_plan(nwknn_ctx* h, int k, long long nq, bool pre, SearchPlan* pl
     long long cap = h->opt_capacity;
     if (cap == 0) { cap = 1024; while (cap < 4ll * k) cap <<= 1; }
     if (cap < 2ll * k + NWK_TILE_ROWS) return fail(NWKNN_EINVAL, "capacity %lld too small for k=%d (need >= 2k+%d)", cap, k, NWK_TILE_ROWS);
-    if (cap > 4096) return fail(NWKNN_EINVAL, "k=%d needs capacity %lld > 4096", k, cap);
+    if (cap > NWK_MAX_CAPACITY) return fail(NWKNN_EINVAL, "k=%d needs capacity %lld > %d", k, cap, NWK_MAX_CAPACITY);
     const long long G = (h->f16 || pre) ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS;  // base rows per tile = granule of every chunk
     long long first = h->opt_first_chunk ? round_up(h->opt_first_chunk, G) : cap / 2;
     first = std::max<long long>(first, round_up(k, G));
@@ -899,7 +899,7 @@ static int search_attempt(nwknn_ctx* h, const void* queries, const ColumnSource*
     if (h->ms_docs > 0) return fail(NWKNN_ESTATE, "nwknn_search: the handle holds MaxSim documents; call nwknn_set_base for kNN");
     if (nq <= 0) return fail(NWKNN_EINVAL, "nwknn_search: nq=%lld must be positive", (long long)nq);
     if (k <= 0 || k > h->nb) return fail(NWKNN_EINVAL, "nwknn_search: k=%d must satisfy 0 < k <= %lld base rows", k, h->nb);   // cu_knn.py:237
-    if (k > 1024) return fail(NWKNN_EINVAL, "nwknn_search: k=%d exceeds the supported maximum 1024", k);
+    if (k > NWK_MAX_K) return fail(NWKNN_EINVAL, "nwknn_search: k=%d exceeds the supported maximum %d", k, NWK_MAX_K);
     if (metric < 0 || metric > 2) return fail(NWKNN_EINVAL, "nwknn_search: unknown metric %d", metric);
     if (dtype != NWKNN_DTYPE_F32 && dtype != NWKNN_DTYPE_F16 && !(qcolumns && dtype == NWKNN_DTYPE_F64))
         return fail(NWKNN_EINVAL, "nwknn_search: unsupported query dtype %d", dtype);
@@ -1397,7 +1397,74 @@ extern "C" int nwknn_merge(nwknn_handle h, const float* dists, const int64_t* id
     return NWKNN_OK;
 }
 
-// ---- synthetic inputs -------------------------------------------------------------------------------
+// ---- explicit pairs: the canonical distance of (query q, base row idx[q][j]) -- the self-check of validate_files_v0 ----------------------
+static int pair_distances_impl(nwknn_ctx* h, const void* queries, int64_t nq, int dtype, int location, const int64_t* idx, int32_t k, int metric,
+                               int64_t index_offset, float* out_dist, double* out_dot64, int out_location)
+{
+    if (!h || !queries || !idx || (!out_dist && !out_dot64)) return fail(NWKNN_EINVAL, "nwknn_pair_distances: null argument");
+    if (!h->bp.p || h->nb <= 0) return fail(NWKNN_ESTATE, "nwknn_pair_distances: call nwknn_set_base first");
+    if (h->ms_docs > 0) return fail(NWKNN_ESTATE, "nwknn_pair_distances: the handle holds MaxSim documents");
+    if (nq <= 0 || k <= 0 || k > 4096) return fail(NWKNN_EINVAL, "nwknn_pair_distances: nq=%lld, k=%d must satisfy nq > 0, 0 < k <= 4096", (long long)nq, k);
+    if (metric < 0 || metric > 2) return fail(NWKNN_EINVAL, "nwknn_pair_distances: unknown metric %d", metric);
+    if (dtype != NWKNN_DTYPE_F32 && dtype != NWKNN_DTYPE_F16) return fail(NWKNN_EINVAL, "nwknn_pair_distances: unsupported query dtype %d", dtype);
+    if ((location != NWKNN_HOST && location != NWKNN_DEVICE) || (out_location != NWKNN_HOST && out_location != NWKNN_DEVICE))
+        return fail(NWKNN_EINVAL, "nwknn_pair_distances: bad location");
+    RCCHK(use_device(h));
+    long long cap = 256;
+    while (cap < k) cap <<= 1;
+    const long long nq_pad = round_up(nq, NWK_QPAD_ROWS);
+    RCCHK(h->qp.ensure((size_t)nq_pad * h->dp * (h->f16 ? 2 : 4)));
+    RCCHK(h->qn.ensure((size_t)nq_pad * 4));
+    RCCHK(h->cnt.ensure((size_t)nq_pad * 4));
+    RCCHK(h->cnt0.ensure((size_t)nq_pad * 4));
+    RCCHK(h->buf.ensure((size_t)nq_pad * cap * 8));
+    h->ev_used = 0;
+    RCCHK(stage_and_prep(h, queries, location, dtype == NWKNN_DTYPE_F16, h->f16, nq, h->d, nq_pad, h->dp, h->qraw, h->qp.p, h->qn.as<float>()));
+    const long long* didx = (const long long*)idx;
+    const size_t nk = (size_t)nq * k;
+    if (location == NWKNN_HOST) {                                   // the index table lives where the queries live
+        RCCHK(h->mrg_i.ensure(nk * 8));
+        HIPCHK(hipMemcpyAsync(h->mrg_i.p, idx, nk * 8, hipMemcpyHostToDevice, h->stream));
+        didx = h->mrg_i.as<long long>();
+    }
+    if (out_dot64) {                                                // nwknn_pair_dots: float64 sums over the prepared rows
+        double* od64 = out_dot64;
+        if (out_location == NWKNN_HOST) { RCCHK(h->out_i.ensure(nk * 8)); od64 = h->out_i.as<double>(); }
+        HIPCHK(nwk_launch_pair_dots(h->stream, h->f16 ? 1 : 0, h->qp.p, h->bp.p, didx, nq, k, h->dp, index_offset, h->nb, od64));
+        if (out_location == NWKNN_HOST) HIPCHK(hipMemcpyAsync(out_dot64, od64, nk * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return NWKNN_OK;
+    }
+    HIPCHK(nwk_launch_pairs_to_keys(h->stream, didx, nq, nq_pad, k, (int)cap, index_offset, h->nb, h->buf.as<u64>(), h->cnt.as<u32>(), h->cnt0.as<u32>()));
+    NwkRescoreParams rp;
+    memset(&rp, 0, sizeof rp);
+    rp.qp = h->qp.as<float>(); rp.bp = h->bp.as<float>(); rp.qn = h->qn.as<float>(); rp.bn = h->bn.as<float>();
+    rp.buf = h->buf.as<u64>(); rp.cnt = h->cnt.as<u32>(); rp.cnt0 = h->cnt0.as<u32>();
+    rp.dp = h->dp; rp.cap = (int)cap; rp.k = k; rp.prune = 0; rp.rows16 = h->f16 ? 1 : 0;
+    rp.chk_scale = 1.0f; rp.chk = nullptr;                          // nothing to hold these keys against: they carry no estimate
+    HIPCHK(nwk_launch_rescore(h->stream, rp, metric, nq_pad));      // the canonical chain over the prepared rows, one lane per pair
+    float* od = out_dist;
+    if (out_location == NWKNN_HOST) { RCCHK(h->out_d.ensure(nk * 4)); od = h->out_d.as<float>(); }
+    HIPCHK(nwk_launch_keys_to_distances(h->stream, h->buf.as<u64>(), nq, k, (int)cap, od));
+    if (out_location == NWKNN_HOST) HIPCHK(hipMemcpyAsync(out_dist, od, nk * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NWKNN_OK;
+}
+
+extern "C" int nwknn_pair_distances(nwknn_handle h, const void* queries, int64_t nq, int dtype, int location, const int64_t* idx, int32_t k, int metric,
+                                    int64_t index_offset, float* out_dist, int out_location)
+{
+    if (!out_dist) return fail(NWKNN_EINVAL, "nwknn_pair_distances: null argument");
+    return guarded([&] { return pair_distances_impl(h, queries, nq, dtype, location, idx, k, metric, index_offset, out_dist, nullptr, out_location); });
+}
+
+extern "C" int nwknn_pair_dots(nwknn_handle h, const void* queries, int64_t nq, int dtype, int location, const int64_t* idx, int32_t k, int64_t index_offset,
+                               double* out_dot, int out_location)
+{
+    if (!out_dot) return fail(NWKNN_EINVAL, "nwknn_pair_dots: null argument");
+    return guarded([&] { return pair_distances_impl(h, queries, nq, dtype, location, idx, k, NWKNN_METRIC_ONE_MINUS_DOT, index_offset, nullptr, out_dot, out_location); });
+}
+
 // ---- device calibration ---------------------------------------------------------------------------------------------------------------
 extern "C" int nwknn_mfma_ceiling(nwknn_handle h, int dtype, double seconds, double* out_tflops, double* out_clock_ghz)
 {

@@ -132,6 +132,7 @@ struct nwknn_comm {
     Rccl rccl;
     std::vector<DevPart> dev;
     long long rows = 0;
+    long long ms_docs = 0;                        // > 0: the devices hold MaxSim documents (rows counts documents then)
     int d = 0;
     nwknn_comm_stats stats;
 };
@@ -239,7 +240,7 @@ static int check_shards(nwknn_comm* c, int64_t rows, int32_t d, const char* what
     if (rows < (int64_t)c->dev.size()) return cfail(NWKNN_EINVAL, "%s: %lld base rows cannot be sharded over %zu devices", what, (long long)rows, c->dev.size());
     const int n = (int)c->dev.size();
     for (int g = 0; g < n; ++g) shard_bounds(rows, n, g, &c->dev[g].row_lo, &c->dev[g].row_hi);
-    c->rows = rows; c->d = d;
+    c->rows = rows; c->d = d; c->ms_docs = 0;
     return NWKNN_OK;
 }
 
@@ -277,14 +278,14 @@ extern "C" int nwknn_comm_generate_base(nwknn_comm_handle c, uint64_t seed, int6
 
 // device g: the k best of its query slice over the N gathered lists.  One merge sorts at most 4096 (list, rank) entries per query in
 // LDS; more (8 shards x k = 1000) are folded in groups of lists first, which gives the same k smallest.
-static int merge_slice(nwknn_comm* c, DevPart& p, int n, long long nq, int k, long long qlo, long long qn)
+static int merge_slice(nwknn_comm* c, DevPart& p, int n, long long nq, int k, long long qlo, long long qn, int descending = 0)
 {
     if (qn <= 0) return NWKNN_OK;
     const long long stride = nq * k;                                  // entries between two gathered lists
     const float* src_d = p.all_d + qlo * k;
     const long long* src_i = p.all_i + qlo * k;
     if ((long long)n * k <= 4096) {
-        hipError_t e = nwk_launch_merge(p.stream, src_d, src_i, n, stride, qn, k, k, p.out_d, p.out_i);
+        hipError_t e = nwk_launch_merge(p.stream, src_d, src_i, n, stride, qn, k, k, p.out_d, p.out_i, descending);
         if (e != hipSuccess) return cfail(NWKNN_EHIP, "merge launch failed: %s", hipGetErrorString(e));
         return NWKNN_OK;
     }
@@ -293,10 +294,10 @@ static int merge_slice(nwknn_comm* c, DevPart& p, int n, long long nq, int k, lo
     for (int gidx = 0; gidx < groups; ++gidx) {
         const int l0 = gidx * per, ln = std::min(per, n - l0);
         hipError_t e = nwk_launch_merge(p.stream, src_d + (long long)l0 * stride, src_i + (long long)l0 * stride, ln, stride, qn, k, k,
-                                        p.grp_d + (long long)gidx * qn * k, p.grp_i + (long long)gidx * qn * k);
+                                        p.grp_d + (long long)gidx * qn * k, p.grp_i + (long long)gidx * qn * k, descending);
         if (e != hipSuccess) return cfail(NWKNN_EHIP, "merge launch failed: %s", hipGetErrorString(e));
     }
-    hipError_t e = nwk_launch_merge(p.stream, p.grp_d, p.grp_i, groups, qn * k, qn, k, k, p.out_d, p.out_i);
+    hipError_t e = nwk_launch_merge(p.stream, p.grp_d, p.grp_i, groups, qn * k, qn, k, k, p.out_d, p.out_i, descending);
     if (e != hipSuccess) return cfail(NWKNN_EHIP, "merge launch failed: %s", hipGetErrorString(e));
     return NWKNN_OK;
 }
@@ -336,11 +337,11 @@ static void drain_exchange_streams(nwknn_comm* c)
 
 // step 3 of the exchange on device `p`: merge rows [qlo, qhi) of the n_lists gathered lists in p.all_*, queue the copy to the caller
 static int merge_and_return_slice(nwknn_comm* c, DevPart& p, int n_lists, long long nq, int k, long long qlo, long long qhi, float* out_dist,
-                                  int64_t* out_idx)
+                                  int64_t* out_idx, int descending = 0)
 {
     CHIP(hipSetDevice(p.device));
     CHIP(hipEventRecord(p.ev1, p.stream));
-    const int rc = merge_slice(c, p, n_lists, nq, k, qlo, qhi - qlo);
+    const int rc = merge_slice(c, p, n_lists, nq, k, qlo, qhi - qlo, descending);
     if (rc != NWKNN_OK) return rc;
     CHIP(hipEventRecord(p.ev2, p.stream));
     if (qhi > qlo) {
@@ -355,7 +356,7 @@ static int merge_and_return_slice(nwknn_comm* c, DevPart& p, int n_lists, long l
 // them over its devices, slice s is merged on device s mod N of the communicator from the lists' own stride (no repacking), more than
 // 4096 entries per query are folded in two levels.  Writes out_dist / out_idx [nq][k] on the host.
 extern "C" int nwknn_comm_merge_lists(nwknn_comm_handle c, const float* dists_host, const int64_t* idx_host, int32_t n_lists, int64_t nq, int32_t k,
-                                      int32_t n_slices, float* out_dist, int64_t* out_idx)
+                                      int32_t n_slices, int descending, float* out_dist, int64_t* out_idx)
 {
     if (!c || !dists_host || !idx_host || !out_dist || !out_idx) return cfail(NWKNN_EINVAL, "nwknn_comm_merge_lists: null argument");
     if (n_lists <= 0 || nq <= 0 || k <= 0 || n_slices <= 0 || n_slices > 4096) return cfail(NWKNN_EINVAL, "nwknn_comm_merge_lists: n_lists, nq, k, n_slices must be positive");
@@ -383,39 +384,17 @@ extern "C" int nwknn_comm_merge_lists(nwknn_comm_handle c, const float* dists_ho
             }
             uploaded[(size_t)(s % n)] = 1;
         }
-        rc = merge_and_return_slice(c, p, n_lists, nq, k, qlo, qhi, out_dist, out_idx);
+        rc = merge_and_return_slice(c, p, n_lists, nq, k, qlo, qhi, out_dist, out_idx, descending ? 1 : 0);
     }
     drain_exchange_streams(c);
     return rc;
 }
 
-extern "C" int nwknn_search_sharded(nwknn_comm_handle c, const void* queries_host, int64_t nq, int dtype, int32_t k, int metric, float* out_dist,
-                                    int64_t* out_idx)
+// steps 2 and 3 of a sharded search plus the accounting, shared by kNN and MaxSim: the devices' partial lists (p.part_*) are complete
+static int exchange_and_merge(nwknn_comm* c, long long nq, int k, int descending, float* out_dist, int64_t* out_idx)
 {
-    if (!c || !queries_host || !out_dist || !out_idx) return cfail(NWKNN_EINVAL, "nwknn_search_sharded: null argument");
-    if (c->rows <= 0) return cfail(NWKNN_ESTATE, "nwknn_search_sharded: call nwknn_comm_set_base / nwknn_comm_generate_base first");
-    if (nq <= 0) return cfail(NWKNN_EINVAL, "nwknn_search_sharded: nq must be positive");
     const int n = (int)c->dev.size();
-    for (const DevPart& p : c->dev)
-        if (k <= 0 || k > p.row_hi - p.row_lo)
-            return cfail(NWKNN_EINVAL, "nwknn_search_sharded: k=%d must satisfy 0 < k <= %lld rows of the smallest shard (cu_knn.py:177-178,237)", k,
-                         (long long)(p.row_hi - p.row_lo));
     const size_t qk = (size_t)nq * k;
-    // buffers
-    for (int g = 0; g < n; ++g) {
-        DevPart& p = c->dev[g];
-        CHIP(hipSetDevice(p.device));
-        long long qlo, qhi;
-        shard_bounds(nq, n, g, &qlo, &qhi);
-        const int rc = ensure_exchange_buffers(p, n, nq, k, qlo, qhi, true);
-        if (rc != NWKNN_OK) return rc;
-    }
-    // 1. every device searches its shard; ids are global (index_offset = first row of the shard: "+ batch_offset", cu_knn.py:273)
-    int rc = on_every_device(c, [&](int g) {
-        DevPart& p = c->dev[g];
-        return nwknn_search(p.h, queries_host, nq, dtype, NWKNN_HOST, k, metric, p.row_lo, p.part_d, (int64_t*)p.part_i, NWKNN_DEVICE);
-    });
-    if (rc != NWKNN_OK) return rc;                                   // nwknn_search returns with its stream drained: nothing is in flight
     // 2. one all-gather per array over RCCL (xGMI): every device ends up with the N partial lists, in device order == row order.
     //    From here on work is queued on the exchange streams: no early return -- the first error is kept, the group is closed and the
     //    streams are drained before it is handed back.
@@ -438,12 +417,12 @@ extern "C" int nwknn_search_sharded(nwknn_comm_handle c, const void* queries_hos
         for (int g = 0; g < n; ++g) {
             long long qlo, qhi;
             shard_bounds(nq, n, g, &qlo, &qhi);
-            const int r3 = merge_and_return_slice(c, c->dev[g], n, nq, k, qlo, qhi, out_dist, out_idx);
+            const int r3 = merge_and_return_slice(c, c->dev[g], n, nq, k, qlo, qhi, out_dist, out_idx, descending);
             if (r3 != NWKNN_OK) return r3;
         }
         return NWKNN_OK;
     };
-    rc = exchange();
+    int rc = exchange();
     if (rc != NWKNN_OK) {
         const std::string keep = nwknn_last_error();                 // draining must not lose the cause
         drain_exchange_streams(c);
@@ -469,6 +448,81 @@ extern "C" int nwknn_search_sharded(nwknn_comm_handle c, const void* queries_hos
     c->stats.allgather_bytes_per_device = (double)qk * 12.0 * n;
     c->stats.tile_flops = flops; c->stats.tile_ms = tile;
     return NWKNN_OK;
+}
+
+static int prepare_exchange(nwknn_comm* c, long long nq, int k)
+{
+    const int n = (int)c->dev.size();
+    for (int g = 0; g < n; ++g) {
+        DevPart& p = c->dev[g];
+        CHIP(hipSetDevice(p.device));
+        long long qlo, qhi;
+        shard_bounds(nq, n, g, &qlo, &qhi);
+        const int rc = ensure_exchange_buffers(p, n, nq, k, qlo, qhi, true);
+        if (rc != NWKNN_OK) return rc;
+    }
+    return NWKNN_OK;
+}
+
+extern "C" int nwknn_search_sharded(nwknn_comm_handle c, const void* queries_host, int64_t nq, int dtype, int32_t k, int metric, float* out_dist,
+                                    int64_t* out_idx)
+{
+    if (!c || !queries_host || !out_dist || !out_idx) return cfail(NWKNN_EINVAL, "nwknn_search_sharded: null argument");
+    if (c->rows <= 0 || c->ms_docs > 0) return cfail(NWKNN_ESTATE, "nwknn_search_sharded: call nwknn_comm_set_base / nwknn_comm_generate_base first");
+    if (nq <= 0) return cfail(NWKNN_EINVAL, "nwknn_search_sharded: nq must be positive");
+    for (const DevPart& p : c->dev)
+        if (k <= 0 || k > p.row_hi - p.row_lo)
+            return cfail(NWKNN_EINVAL, "nwknn_search_sharded: k=%d must satisfy 0 < k <= %lld rows of the smallest shard (cu_knn.py:177-178,237)", k,
+                         (long long)(p.row_hi - p.row_lo));
+    int rc = prepare_exchange(c, nq, k);
+    if (rc != NWKNN_OK) return rc;
+    // 1. every device searches its shard; ids are global (index_offset = first row of the shard: "+ batch_offset", cu_knn.py:273)
+    rc = on_every_device(c, [&](int g) {
+        DevPart& p = c->dev[g];
+        return nwknn_search(p.h, queries_host, nq, dtype, NWKNN_HOST, k, metric, p.row_lo, p.part_d, (int64_t*)p.part_i, NWKNN_DEVICE);
+    });
+    if (rc != NWKNN_OK) return rc;                                   // nwknn_search returns with its stream drained: nothing is in flight
+    return exchange_and_merge(c, nq, k, 0, out_dist, out_idx);
+}
+
+// ---- MaxSim over the devices (BASELINE config 5 "on 8 GPUs"; an extension like nwknn_maxsim_*: no reference parity) --------------------------
+// Documents sharded contiguously (device g holds docs [n g / N, n (g+1) / N)), queries replicated, per-shard top-k with global doc ids,
+// the same ONE all-gather per array, and the sliced merge ranks by (score descending, doc id ascending).
+extern "C" int nwknn_comm_maxsim_set_docs(nwknn_comm_handle c, const void* doc_tokens_host, int64_t n_docs, int32_t tokens_per_doc, int32_t d, int dtype)
+{
+    if (!doc_tokens_host) return cfail(NWKNN_EINVAL, "nwknn_comm_maxsim_set_docs: null documents");
+    if (dtype != NWKNN_DTYPE_F32) return cfail(NWKNN_EINVAL, "nwknn_comm_maxsim_set_docs: float32 tokens only");
+    if (tokens_per_doc <= 0) return cfail(NWKNN_EINVAL, "nwknn_comm_maxsim_set_docs: tokens_per_doc must be positive");
+    const int rc = check_shards(c, n_docs, d, "nwknn_comm_maxsim_set_docs");
+    if (rc != NWKNN_OK) return rc;
+    const int rc2 = on_every_device(c, [&](int g) {
+        DevPart& p = c->dev[g];
+        return nwknn_maxsim_set_docs(p.h, (const char*)doc_tokens_host + (size_t)p.row_lo * tokens_per_doc * d * 4, p.row_hi - p.row_lo, tokens_per_doc, d, dtype,
+                                     NWKNN_HOST);
+    });
+    c->ms_docs = rc2 == NWKNN_OK ? n_docs : 0;
+    if (rc2 != NWKNN_OK) c->rows = 0;
+    return rc2;
+}
+
+extern "C" int nwknn_maxsim_search_sharded(nwknn_comm_handle c, const void* query_tokens_host, int64_t n_queries, int32_t tokens_per_query, int dtype,
+                                           int32_t k, float* out_score, int64_t* out_doc)
+{
+    if (!c || !query_tokens_host || !out_score || !out_doc) return cfail(NWKNN_EINVAL, "nwknn_maxsim_search_sharded: null argument");
+    if (c->ms_docs <= 0) return cfail(NWKNN_ESTATE, "nwknn_maxsim_search_sharded: call nwknn_comm_maxsim_set_docs first");
+    if (n_queries <= 0) return cfail(NWKNN_EINVAL, "nwknn_maxsim_search_sharded: n_queries must be positive");
+    for (const DevPart& p : c->dev)
+        if (k <= 0 || k > p.row_hi - p.row_lo)
+            return cfail(NWKNN_EINVAL, "nwknn_maxsim_search_sharded: k=%d must satisfy 0 < k <= %lld documents of the smallest shard", k,
+                         (long long)(p.row_hi - p.row_lo));
+    int rc = prepare_exchange(c, n_queries, k);
+    if (rc != NWKNN_OK) return rc;
+    rc = on_every_device(c, [&](int g) {
+        DevPart& p = c->dev[g];
+        return nwknn_maxsim_search(p.h, query_tokens_host, n_queries, tokens_per_query, dtype, NWKNN_HOST, k, p.row_lo, p.part_d, (int64_t*)p.part_i, NWKNN_DEVICE);
+    });
+    if (rc != NWKNN_OK) return rc;
+    return exchange_and_merge(c, n_queries, k, 1, out_score, out_doc);
 }
 
 extern "C" int nwknn_comm_get_stats(nwknn_comm_handle c, nwknn_comm_stats* out)

@@ -13,6 +13,8 @@
 #define NWK_K_ALIGN_F16 64         // prepared fp16 rows: multiple of this many halves
 #define NWK_MAX_WORKGROUPS_PER_LAUNCH (1ll << 22)   // x 512 threads = 2^31: half of what HIP accepts, super-tile padding has room
 #define NWK_F16_TILE_ROWS 256      // fp16 path: query and base tiles are 256 rows
+#define NWK_MAX_CAPACITY 8192      // candidate slots per query: the compaction kernel sorts a list in LDS (16 B per slot: 128 KiB of the CU's 160)
+#define NWK_MAX_K 2048             // a list holds at least 4 k slots
 
 struct NwkTileParams {
     const float* qp;               // prepared queries [nq_pad][dp]
@@ -130,6 +132,11 @@ hipError_t nwk_launch_maxsim_bounds(hipStream_t st, const float* norms, long lon
                                     int is_doc, float* out);
 hipError_t nwk_launch_maxsim_rescore(hipStream_t st, NwkMsRescoreParams p, long long nq_pad, int slices);
 hipError_t nwk_launch_merge(hipStream_t st, const float* dists, const long long* idx, int n_lists, long long list_stride, long long nq, int k_in,
-                            int k_out, float* out_d, long long* out_i);
+                            int k_out, float* out_d, long long* out_i, int descending = 0);
+hipError_t nwk_launch_pairs_to_keys(hipStream_t st, const long long* idx, long long nq, long long nq_pad, int k, int cap, long long index_offset,
+                                    long long nb, unsigned long long* buf, unsigned int* cnt, unsigned int* cnt0);
+hipError_t nwk_launch_pair_dots(hipStream_t st, int rows16, const void* qp, const void* bp, const long long* idx, long long nq, int k, int dp,
+                                long long index_offset, long long nb, double* out);
+hipError_t nwk_launch_keys_to_distances(hipStream_t st, const unsigned long long* buf, long long nq, int k, int cap, float* out);
 hipError_t nwk_launch_mfma_bare(hipStream_t st, int f16, const void* rnd, int iters, unsigned grid, void* out);   // nwk_calib.hip: one launch of the bare MFMA loop; out: grid x {u64 cycles, u64 realtime (100 MHz), float}
 int nwknn_internal_fail(int code, const char* msg);        // sets the calling thread's nwknn_last_error() message, returns code

@@ -152,6 +152,12 @@ def _checkpoint_tag(metric, k, query_count, base_rows, rows_done, inputs: str = 
             "nwknn.rows_done": str(rows_done), "nwknn.inputs": inputs}
 
 
+def checkpoint_inputs(query_rows, base_rows) -> str:
+    """The identity of a job's input rows as a checkpoint records it (``ParquetRows.provenance``: file paths, sizes, mtimes, row window,
+    columns)."""
+    return f"q:{query_rows.provenance()};b:{base_rows.provenance()}"
+
+
 def _write_checkpoint(data_dir, dist, idx, tag):
     fd, fi = _checkpoint_names(data_dir)
     for name, arr in ((fd, dist), (fi, idx)):                    # whole files, swapped in by rename: a reader never sees half a table
@@ -216,7 +222,7 @@ def process_dataset_batches(data_dir,
 
     run_d = run_i = None                                                          # the running pair: torch CUDA tensors [Q,k]
     start_row = 0
-    inputs = f"q:{query_rows.provenance()};b:{base_rows.provenance()}"
+    inputs = checkpoint_inputs(query_rows, base_rows)
     ckpt = _load_checkpoint(data_dir, metric, k, query_count, n_base, inputs) if resume else None
     if ckpt is not None:
         start_row = ckpt[0]

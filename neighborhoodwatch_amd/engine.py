@@ -289,6 +289,53 @@ class KnnEngine:
         del keep
         return od, oi
 
+    def pair_distances(self, queries, idx, metric: str = "sqeuclidean", index_offset: int = 0):
+        """Canonical distances of GIVEN pairs: out[q, j] = distance(queries[q], dataset[idx[q, j] - index_offset]) -- the same bits a search
+        would report for that pair; NaN where the row does not exist.  numpy in -> numpy out, torch CUDA in -> torch CUDA out.  This is
+        what the reference's validator recomputes on the CPU, neighbour by neighbour (parquet_to_format.py:351-383)."""
+        metric = resolve_metric(metric)
+        ptr, nq, dim, dt, loc, keep = self._matrix(queries, "queries")
+        if self.rows == 0:
+            raise _lib.NwknnError("pair_distances before set_base")
+        if dim != self.dim:
+            raise ValueError(f"queries have dimension {dim}, dataset has {self.dim}")
+        if loc == DEVICE:
+            import torch
+            self._order_after_torch(keep, "queries")
+            it = idx.to(device=keep.device, dtype=torch.int64).contiguous()
+            if it.dim() != 2 or it.shape[0] != nq:
+                raise ValueError(f"idx must be [{nq}, k], got {tuple(it.shape)}")
+            out = torch.empty(tuple(it.shape), dtype=torch.float32, device=keep.device)
+            torch.cuda.current_stream(keep.device).synchronize()
+            ip, op, k = it.data_ptr(), out.data_ptr(), it.shape[1]
+        else:
+            it = np.ascontiguousarray(idx, dtype=np.int64)
+            if it.ndim != 2 or it.shape[0] != nq:
+                raise ValueError(f"idx must be [{nq}, k], got {it.shape}")
+            out = np.empty(it.shape, dtype=np.float32)
+            ip, op, k = it.ctypes.data, out.ctypes.data, it.shape[1]
+        check(self._L.nwknn_pair_distances(self._h, ctypes.c_void_p(ptr), nq, dt, loc, ctypes.c_void_p(ip), int(k), METRIC_IDS[metric], int(index_offset),
+                                           ctypes.c_void_p(op), loc), "nwknn_pair_distances")
+        del keep, it
+        return out
+
+    def pair_dots(self, queries, idx, index_offset: int = 0) -> np.ndarray:
+        """float64 dot products of GIVEN pairs (host numpy in and out): out[q, j] = sum_k queries[q, k] * dataset[idx[q, j] - index_offset, k] in
+        double precision, NaN where the row does not exist -- the arithmetic of the reference's validator (nwknn_pair_dots)."""
+        ptr, nq, dim, dt, loc, keep = self._matrix(np.asarray(queries), "queries")
+        if self.rows == 0:
+            raise _lib.NwknnError("pair_dots before set_base")
+        if dim != self.dim:
+            raise ValueError(f"queries have dimension {dim}, dataset has {self.dim}")
+        it = np.ascontiguousarray(idx, dtype=np.int64)
+        if it.ndim != 2 or it.shape[0] != nq:
+            raise ValueError(f"idx must be [{nq}, k], got {it.shape}")
+        out = np.empty(it.shape, dtype=np.float64)
+        check(self._L.nwknn_pair_dots(self._h, ctypes.c_void_p(ptr), nq, dt, HOST, ctypes.c_void_p(it.ctypes.data), int(it.shape[1]), int(index_offset),
+                                      ctypes.c_void_p(out.ctypes.data), HOST), "nwknn_pair_dots")
+        del keep
+        return out
+
     MERGE_MAX_ENTRIES = 4096        # nwknn_merge sorts at most this many (list, rank) entries per query in LDS
 
     def merge(self, dists, idx, k: int):
@@ -442,6 +489,7 @@ class ShardedKnnEngine:
 
     def __init__(self, devices=(0,), profile: bool = False):
         self._L = _lib.load()
+        _lib.bind_to_torch_rccl()                                   # one RCCL per process: torch's copy, if torch is installed (see _lib.py)
         self._c = ctypes.c_void_p()
         devs = [int(x) for x in devices]
         arr = (ctypes.c_int * len(devs))(*devs)
@@ -511,7 +559,32 @@ class ShardedKnnEngine:
               "nwknn_search_sharded")
         return od, oi
 
-    def merge_lists(self, dists, idx, k: int, n_slices: int = 0):
+    def maxsim_set_docs(self, doc_tokens) -> None:
+        """Host doc tokens [n_docs, 64, d] float32 (or ragged matrices, padded as KnnEngine.maxsim_set_docs pads them), sharded contiguously
+        over the devices."""
+        if isinstance(doc_tokens, (list, tuple)):
+            doc_tokens = KnnEngine.pad_tokens(doc_tokens, KnnEngine.MAXSIM_DOC_TOKENS, repeat_last=True)
+        a = np.ascontiguousarray(doc_tokens, dtype=np.float32)
+        if a.ndim != 3:
+            raise ValueError("doc_tokens must be [n_docs, tokens, d]")
+        check(self._L.nwknn_comm_maxsim_set_docs(self._c, ctypes.c_void_p(a.ctypes.data), a.shape[0], a.shape[1], a.shape[2], DTYPE_F32),
+              "nwknn_comm_maxsim_set_docs")
+        self.rows, self.dim, self.docs = a.shape[0] * a.shape[1], a.shape[2], a.shape[0]
+
+    def maxsim_search(self, query_tokens, k: int):
+        """-> (scores float32 [q,k] descending, global doc ids int64 [q,k]) over all the devices' documents."""
+        if isinstance(query_tokens, (list, tuple)):
+            query_tokens = KnnEngine.pad_tokens(query_tokens, KnnEngine.MAXSIM_QUERY_TOKENS, repeat_last=False)
+        a = np.ascontiguousarray(query_tokens, dtype=np.float32)
+        if a.ndim != 3 or a.shape[2] != self.dim:
+            raise ValueError(f"query_tokens must be [n_queries, tokens, {self.dim}]")
+        os_ = np.empty((a.shape[0], k), dtype=np.float32)
+        od = np.empty((a.shape[0], k), dtype=np.int64)
+        check(self._L.nwknn_maxsim_search_sharded(self._c, ctypes.c_void_p(a.ctypes.data), a.shape[0], a.shape[1], DTYPE_F32, int(k),
+                                                  ctypes.c_void_p(os_.ctypes.data), ctypes.c_void_p(od.ctypes.data)), "nwknn_maxsim_search_sharded")
+        return os_, od
+
+    def merge_lists(self, dists, idx, k: int, n_slices: int = 0, descending: bool = False):
         """dists / idx: host [n_lists, Q, k] partial lists (idx < 0 = empty) -> ([Q,k], [Q,k]) by (distance, index): the merge step of a
         multi-device search (query rows in ``n_slices`` slices, default one per device; sliced and two-level merge) on lists the caller
         gathered -- merge.py:56-101 across any number of lists."""
@@ -522,7 +595,7 @@ class ShardedKnnEngine:
         od = np.empty(d.shape[1:], dtype=np.float32)
         oi = np.empty(d.shape[1:], dtype=np.int64)
         check(self._L.nwknn_comm_merge_lists(self._c, ctypes.c_void_p(d.ctypes.data), ctypes.c_void_p(i.ctypes.data), d.shape[0], d.shape[1], int(k),
-                                             int(n_slices) or len(self.devices), ctypes.c_void_p(od.ctypes.data), ctypes.c_void_p(oi.ctypes.data)),
+                                             int(n_slices) or len(self.devices), 1 if descending else 0, ctypes.c_void_p(od.ctypes.data), ctypes.c_void_p(oi.ctypes.data)),
               "nwknn_comm_merge_lists")
         return od, oi
 

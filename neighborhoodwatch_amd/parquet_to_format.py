@@ -209,23 +209,69 @@ def dot_product(A, B):
     return sum(a * b for a, b in zip(A, B))
 
 
-def validate_files_v0(data_dir, query_vector_fvec, base_vector_fvec, indices_ivec, distances_fvec):
+def _report(n, col, x, dist, idx):
+    print(f"Expected '1 - similarity' ({x}) equal to distance ({dist[n, col]}) for query vector {n} "
+          f"and base vector {idx[n, col]}")
+
+
+def _validate_rows_on_host(queries, base, idx, dist, rows, cols=None) -> int:
+    """The reference's check in float64 for the given query rows (all neighbours, or only ``cols[n]``): the verdict of record."""
+    bad_total = 0
+    for n in rows:
+        q = queries[n].astype(np.float64)
+        js = np.arange(idx.shape[1]) if cols is None else cols[n]
+        similarity = base[idx[n, js]].astype(np.float64) @ q
+        bad = ~np.isclose(1.0 - similarity, dist[n, js].astype(np.float64) / 2.0)
+        for t in np.flatnonzero(bad):
+            _report(n, js[t], 1 - similarity[t], dist, idx)
+        bad_total += int(bad.sum())
+    return bad_total
+
+
+def validate_files_v0(data_dir, query_vector_fvec, base_vector_fvec, indices_ivec, distances_fvec, device=None):
     """For every query and every listed neighbour: ``isclose(1 - dot(q, b), distance / 2)`` -- squared L2 of unit vectors
-    (parquet_to_format.py:351-383).  Vectorised per query; returns the mismatch count (the reference only prints it)."""
-    queries = read_vectors(data_dir, query_vector_fvec).astype(np.float64)
+    (parquet_to_format.py:351-383); returns the mismatch count (the reference only prints it).
+
+    With an MI355X present (``device`` = its ordinal, default: GPU 0 when there is one) the gather + dot of the Q x k pairs runs on the GPU
+    in float64 (nwknn_pair_dots; the reference walks the pairs row by row in Python).  A float64 sum on the GPU and numpy's differ by
+    ~1e-13 (summation order), so a pair whose ``|1 - dot - distance / 2|`` is within 1e-10 of numpy.isclose's tolerance edge is handed to
+    the host check of record; every other pair is decided from the GPU value.  Without a GPU the whole check runs on the host."""
+    queries = read_vectors(data_dir, query_vector_fvec)
     base = read_vectors(data_dir, base_vector_fvec)
     idx = read_vectors(data_dir, indices_ivec)
-    dist = read_vectors(data_dir, distances_fvec).astype(np.float64)
-    total_mismatch_count = 0
+    dist = read_vectors(data_dir, distances_fvec)
+    nonzero = [n for n in range(queries.shape[0]) if queries[n].any()]
     for n in range(queries.shape[0]):
         if not queries[n].any():
             print(f"Skipping zero query vector {n}/{queries.shape[0]}")
-            continue
-        similarity = base[idx[n]].astype(np.float64) @ queries[n]
-        bad = ~np.isclose(1.0 - similarity, dist[n] / 2.0)
-        for col in np.flatnonzero(bad):
-            print(f"Expected '1 - similarity' ({1 - similarity[col]}) equal to distance ({dist[n, col]}) for query vector {n} "
-                  f"and base vector {idx[n, col]}")
-        total_mismatch_count += int(bad.sum())
+    if device is None:
+        from .engine import device_count
+        try:
+            device = 0 if device_count() > 0 else -1
+        except Exception:
+            device = -1
+    if device < 0 or idx.shape[1] > 4096 or not nonzero:
+        total_mismatch_count = _validate_rows_on_host(queries, base, idx, dist, nonzero)
+        print(f"Total mismatch count: {total_mismatch_count}")
+        return total_mismatch_count
+    from .engine import KnnEngine
+    total_mismatch_count = 0
+    with KnnEngine(int(device)) as eng:
+        eng.set_base(np.ascontiguousarray(base, dtype=np.float32))
+        step = max(1, (1 << 24) // max(idx.shape[1], 1))                         # ~16M pairs per call
+        rows = np.asarray(nonzero, dtype=np.int64)
+        for r0 in range(0, len(rows), step):
+            rs = rows[r0:r0 + step]
+            x = 1.0 - eng.pair_dots(np.ascontiguousarray(queries[rs], dtype=np.float32), idx[rs])
+            half = dist[rs].astype(np.float64) / 2.0
+            gap = np.abs(x - half) - (1e-8 + 1e-5 * np.abs(half))               # numpy.isclose defaults: |a - b| <= atol + rtol * |b|
+            unsure = ~(np.abs(gap) > 1e-10)                                      # too close to the edge to call (NaN included)
+            bad = (gap > 1e-10) & ~unsure
+            for t, col in zip(*np.nonzero(bad)):
+                _report(int(rs[t]), int(col), x[t, col], dist, idx)
+            total_mismatch_count += int(bad.sum())
+            for t in np.flatnonzero(unsure.any(axis=1)):
+                n = int(rs[t])
+                total_mismatch_count += _validate_rows_on_host(queries, base, idx, dist, [n], {n: np.flatnonzero(unsure[t])})
     print(f"Total mismatch count: {total_mismatch_count}")
     return total_mismatch_count

@@ -140,12 +140,37 @@ def test_small_chunks_do_not_change_the_result(oracle):
 def test_large_k(engine, oracle):
     base, queries = oracle.gen(61, 0, 6000, 40), oracle.gen(62, 0, 20, 40)
     engine.set_base(base)
-    for k in (1000, 1024):
+    for k in (1000, 1024, 1025, 2048):                           # 1025 on: 8192 list slots per query (compaction sorts 128 KiB in LDS)
         d, i = engine.search(queries, k, "one_minus_dot")        # ck runs 1 - dot (colbert_knn.py:94)
         rd, ri = oracle.knn_canonical(base, queries, k, "one_minus_dot")
         assert np.array_equal(i, ri) and _same_bits(d, rd)
     with pytest.raises(ValueError):
-        engine.search(queries, 1025)
+        engine.search(queries, 2049)
+
+
+@pytest.mark.parametrize("mode", ["direct", "prescreen", "f16"])
+def test_k_2000_through_every_path(oracle, mode):
+    """k beyond 1024 (the reference's operators take any k: cu_knn.py:243, `ck -k`): 8192-slot lists on the direct fp32 kernel, through
+    the fp16 pre-screen + rescoring, and in exact fp16 mode; sharded over three virtual shards and merged (two-level fold: 3 x 2000
+    entries per query exceed one merge)."""
+    from neighborhoodwatch_amd import KnnEngine
+    base, queries = oracle.gen(0xB1, 0, 30000, 96), oracle.gen(0xB2, 0, 130, 96)
+    if mode == "f16":
+        base, queries = base.astype(np.float16), queries.astype(np.float16)
+    rd, ri = oracle.knn_canonical(base.astype(np.float32), queries.astype(np.float32), 2000)
+    with KnnEngine(0) as eng:
+        eng.set_prescreen(mode == "prescreen")
+        eng.set_base(base)
+        d, i = eng.search(queries, 2000)
+        st = eng.stats()
+        assert st["prescreen"] == (0 if mode == "direct" else 1) and st["overflowed_queries"] == 0
+        assert np.array_equal(i, ri) and _same_bits(d, rd)
+        parts = []
+        for lo, hi in ((0, 9000), (9000, 21000), (21000, 30000)):
+            eng.set_base(base[lo:hi])
+            parts.append(eng.search(queries, 2000, index_offset=lo))
+        md, mi = eng.merge(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]), 2000)
+        assert np.array_equal(mi, ri) and _same_bits(md, rd)
 
 
 @pytest.mark.parametrize("name", ["basic", "ties", "single", "nine"])
@@ -496,3 +521,35 @@ def test_bare_mfma_loop_calibration_is_in_the_physical_range():
     assert 110.0 < f["tflops"] < 157.4 and 1.5 < f["clock_ghz"] <= 2.45, f
     assert abs(h["tflops"] - 2500.0 * h["clock_ghz"] / 2.4) < 0.1 * h["tflops"]          # rate = FLOPs per cycle x the clock held (pipe 100 % busy)
     assert abs(f["tflops"] - 157.3 * f["clock_ghz"] / 2.4) < 0.1 * f["tflops"]
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean", "one_minus_dot", "cosine"])
+@pytest.mark.parametrize("f16", [False, True])
+def test_pair_distances_are_the_bits_a_search_reports(oracle, metric, f16):
+    """nwknn_pair_distances: the canonical distance of GIVEN (query, base row) pairs -- what the reference's validator recomputes on the
+    CPU neighbour by neighbour (parquet_to_format.py:351-383).  For the pairs a search returned it must reproduce the search's
+    distances bit for bit (both run the fmaf chain of the oracle), with the shard's index offset, on host and device buffers; a row
+    that does not exist gives NaN."""
+    import torch
+    from neighborhoodwatch_amd import KnnEngine
+    base, queries = oracle.gen(0xA1, 0, 7000, 200), oracle.gen(0xA2, 0, 333, 200)
+    if f16:
+        base, queries = base.astype(np.float16), queries.astype(np.float16)
+    off = 1_000_000
+    with KnnEngine(0) as eng:
+        eng.set_base(base)
+        d, i = eng.search(queries, 50, metric, index_offset=off)
+        pd = eng.pair_distances(queries, i, metric, index_offset=off)
+        assert _same_bits(pd, d)
+        rd, ri = oracle.knn_canonical(base.astype(np.float32), queries.astype(np.float32), 50, metric)
+        assert np.array_equal(i, ri + off) and _same_bits(pd, rd)
+        shuffled = i[:, ::-1].copy()                               # any pairs, in any order
+        assert _same_bits(eng.pair_distances(queries, shuffled, metric, index_offset=off), d[:, ::-1])
+        holes = i.copy(); holes[::7, 3] = -1; holes[5, 0] = off + 7000          # an empty merge slot; one past the last row
+        ph = eng.pair_distances(queries, holes, metric, index_offset=off)
+        assert np.isnan(ph[::7, 3]).all() and np.isnan(ph[5, 0]) and np.isnan(ph).sum() == len(range(0, 333, 7)) + 1
+        tq, ti = torch.from_numpy(queries).cuda(), torch.from_numpy(i).cuda()
+        td = eng.pair_distances(tq, ti, metric, index_offset=off)
+        assert td.is_cuda and _same_bits(td.cpu().numpy(), d)
+        with pytest.raises(ValueError):
+            eng.pair_distances(queries, i[:10], metric)

@@ -112,9 +112,15 @@ def test_dataset_api_streams_batches_and_resumes_from_its_checkpoint(dataset, or
     with pytest.raises(RuntimeError, match="simulated crash"):
         cu_knn_ds.compute_knn_ds(data_dir, 384, qf, 300, bf, 2600, False, 10, 400, resume=True)
     assert [c[0] for c in calls] == [0, 400, 800, 1200] and all(c[1] for c in calls)     # global offsets; results asked for on the device
-    ck = cu_knn_ds._load_checkpoint(data_dir, "sqeuclidean", 10, 300, 2600)
+    def rows_of(name, count):
+        ds_ = cu_knn_ds.slice_dataset(cu_knn_ds.load_dataset(data_dir, name), 0, count)
+        return cu_knn_ds._as_rows(ds_, cu_knn_ds.get_dataset_columns(ds_, 384))
+    inputs = cu_knn_ds.checkpoint_inputs(rows_of(qf, 300), rows_of(bf, 2600))
+    ck = cu_knn_ds._load_checkpoint(data_dir, "sqeuclidean", 10, 300, 2600, inputs)
     assert ck is not None and ck[0] == 1200
-    assert cu_knn_ds._load_checkpoint(data_dir, "cosine", 10, 300, 2600) is None         # another metric's checkpoint is not trusted
+    assert cu_knn_ds._load_checkpoint(data_dir, "cosine", 10, 300, 2600, inputs) is None  # another metric's checkpoint is not trusted
+    assert cu_knn_ds._load_checkpoint(data_dir, "sqeuclidean", 10, 300, 2600) is None     # nor one whose input files are not these
+    assert cu_knn_ds._load_checkpoint(data_dir, "sqeuclidean", 10, 300, 2600, cu_knn_ds.checkpoint_inputs(rows_of(qf, 300), rows_of(bf, 2599))) is None
 
     monkeypatch.setattr(eng_mod.KnnEngine, "search_columns", real_search)
     seen = []
@@ -312,3 +318,27 @@ def test_ck_cli_end_to_end(tmp_path, oracle):
     assert np.array_equal(_arr(fi, np.int64), ri) and np.array_equal(_arr(fd, np.float32).view(np.uint32), rd.view(np.uint32))
     qf, bf, iif, df_ = p2f.get_ivec_fvec_filenames(data_dir, "colbertv2.0", 128, 21000, 140, 10, None)
     assert p2f.count_vectors(data_dir, iif) == 140 and p2f.count_vectors(data_dir, bf) == 21000
+
+
+def test_validator_on_the_gpu_gives_the_host_verdict(tmp_path, oracle):
+    """validate_files_v0 (parquet_to_format.py:351-383) with the Q x k gather + dot on the GPU (nwknn_pair_distances): the mismatch count
+    and the reported pairs are those of the float64 host check -- a clean result, a corrupted distance, a corrupted index and a pair too
+    close to the tolerance to be called from the fp32 value (handed to the host)."""
+    from neighborhoodwatch_amd import parquet_to_format as ptf
+    data_dir = str(tmp_path)
+    base, queries = synth.gen_unit_rows(0x51, 0, 20000, 384), synth.gen_unit_rows(0x52, 0, 600, 384)
+    queries[17] = 0.0                                                      # the reference skips zero query vectors
+    d, i = oracle.knn_canonical(base, queries, 100)
+    for name, arr, t in (("q.fvec", queries, "f"), ("b.fvec", base, "f"), ("i.ivec", i.astype(np.int32), "i"), ("d.fvec", d, "f")):
+        ptf.write_ivec_fvec_from_dataframe(data_dir, "m", f"{data_dir}/{name}", arr, t, arr.shape[1])
+    files = [f"{data_dir}/{n}" for n in ("q.fvec", "b.fvec", "i.ivec", "d.fvec")]
+    assert ptf.validate_files_v0(data_dir, *files, device=0) == 0 == ptf.validate_files_v0(data_dir, *files, device=-1)
+    bad_d, bad_i = d.copy(), i.astype(np.int32).copy()
+    bad_d[5, 2] += 0.01                                                    # a wrong distance
+    bad_d[9, 50] *= 1.0 + 0.9e-5                                           # inside numpy.isclose's tolerance, but too close to call in fp32
+    bad_d[11, 7] *= 1.0 + 3e-5                                             # outside it
+    bad_i[300, 99] = (bad_i[300, 99] + 1234) % 20000                       # a wrong neighbour
+    ptf.write_ivec_fvec_from_dataframe(data_dir, "m", files[3], bad_d, "f", 100)
+    ptf.write_ivec_fvec_from_dataframe(data_dir, "m", files[2], bad_i, "i", 100)
+    host = ptf.validate_files_v0(data_dir, *files, device=-1)
+    assert ptf.validate_files_v0(data_dir, *files, device=0) == host and host in (3, 4)

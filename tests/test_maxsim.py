@@ -173,3 +173,52 @@ def test_hip_maxsim_ragged_documents_and_queries(oracle, prescreen):
         assert np.allclose(np.sort(exact)[::-1][:25], s[q], rtol=1e-5, atol=1e-4)
     with pytest.raises(ValueError, match="tokens"):
         KnnEngine.pad_tokens([np.zeros((65, d), np.float32)], 64, True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prescreen", [False, True])
+def test_maxsim_through_the_c_abi_collective(oracle, prescreen):
+    """nwknn_comm_maxsim_set_docs / nwknn_maxsim_search_sharded: documents sharded over the communicator's devices, one all-gather per
+    array, sliced merge by (score descending, doc id ascending).  With the one device of this box it must give nwknn_maxsim_search's
+    bits -- RCCL, the all-gather and the descending merge all run; more devices are covered list-wise by the next test."""
+    from neighborhoodwatch_amd import ShardedKnnEngine
+    docs, qs = _tokens(oracle, 0xC7, 2500, 64, 128), _tokens(oracle, 0xC8, 41, 32, 128)
+    rs, ri = oracle.maxsim_canonical(docs, qs, 100)
+    with ShardedKnnEngine([0]) as eng:
+        eng.set_prescreen(prescreen)
+        eng.maxsim_set_docs(docs)
+        s, i = eng.maxsim_search(qs, 100)
+        st = eng.stats()
+        with pytest.raises(Exception):
+            eng.search(qs.reshape(-1, 128), 5)                    # the devices hold MaxSim documents, not a kNN base
+    assert np.array_equal(i, ri) and np.array_equal(s.view(np.uint32), rs.view(np.uint32))
+    assert st["n_devices"] == 1 and st["allgather_ms"] > 0.0 and st["merge_ms"] > 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_lists,k,n_slices", [(8, 1000, 3), (4, 100, 2)])
+def test_descending_merge_of_score_lists(n_lists, k, n_slices):
+    """The merge step of a multi-device MaxSim search on caller-built lists: scores ranked high to low, equal scores by the lower doc id,
+    empty slots (-inf, -1) last; sliced and (8 x 1000 entries) two-level."""
+    from neighborhoodwatch_amd import ShardedKnnEngine
+    rng = np.random.default_rng(n_lists + k)
+    nq = 29
+    pool = rng.standard_normal(300).astype(np.float32) * 50
+    scores = -np.sort(-rng.choice(pool, size=(n_lists, nq, k)), axis=2)
+    docs = np.empty((n_lists, nq, k), dtype=np.int64)
+    for l in range(n_lists):
+        for q in range(nq):
+            ids = rng.choice(1_000_000, size=k, replace=False) + l * 1_000_000
+            order = np.lexsort((ids, -scores[l, q]))
+            docs[l, q], scores[l, q] = ids[order], scores[l, q][order]
+    docs[0, :, k - 7:] = -1
+    scores[0, :, k - 7:] = -np.inf
+    flat_s, flat_d = scores.transpose(1, 0, 2).reshape(nq, -1), docs.transpose(1, 0, 2).reshape(nq, -1)
+    es, ed = np.empty((nq, k), np.float32), np.empty((nq, k), np.int64)
+    for q in range(nq):
+        ok = flat_d[q] >= 0
+        order = np.lexsort((flat_d[q][ok], -flat_s[q][ok]))[:k]
+        es[q], ed[q] = flat_s[q][ok][order], flat_d[q][ok][order]
+    with ShardedKnnEngine([0]) as eng:
+        s, d = eng.merge_lists(scores, docs, k, n_slices, descending=True)
+    assert np.array_equal(d, ed) and np.array_equal(s.view(np.uint32), es.view(np.uint32))

@@ -3,15 +3,16 @@
 set -o pipefail
 tag=${1:-r04d}
 mkdir -p gpurun_out
-python -m pytest tests/ -x -q -m gpu --durations=12 > gpurun_out/${tag}_pytest_gpu.log 2>&1; rc=$?
+python -m pytest ${TESTS:-tests/} -x -q -m gpu --durations=12 > gpurun_out/${tag}_pytest_gpu.log 2>&1; rc=$?
 echo "pytest exit status $rc" >> gpurun_out/${tag}_pytest_gpu.log
 tail -20 gpurun_out/${tag}_pytest_gpu.log
 [ $rc -ne 0 ] && exit $rc
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1; rc=$?
 echo "smoke exit status $rc" >> gpurun_out/${tag}_smoke.log; tail -2 gpurun_out/${tag}_smoke.log
 [ $rc -ne 0 ] && exit $rc
-/usr/bin/time -v python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_c3_bench.json 2> gpurun_out/${tag}_c3_bench.err; rc=$?
-grep -E "Elapsed|Maximum resident" gpurun_out/${tag}_c3_bench.err
+SECONDS=0
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_c3_bench.json 2> gpurun_out/${tag}_c3_bench.err; rc=$?
+echo "bench.py --gpus 1 --steps 20 --warmup 5: ${SECONDS} s of wall clock, exit status $rc" | tee gpurun_out/${tag}_c3_bench.wall
 [ $rc -ne 0 ] && { tail -30 gpurun_out/${tag}_c3_bench.err; exit $rc; }
 python - <<PY
 import json
