@@ -52,6 +52,9 @@ WORKLOADS = {
     # what ONE of eight GPUs does per step of the headline job at --gpus 8 (all queries x its 1.25M-row shard; no collective):
     # 8 x its queries/s is the ceiling of the 8-GPU line, measurable on a one-GPU box
     "c3shard": (100_000, 1_250_000, 1024, 100, "sqeuclidean", "f32", "one of eight C3 shards: 100k queries x 1.25M base rows, d=1024, k=100, fp32 (not a headline number)"),
+    # ... and what one of eight GPUs does when the QUERY rows are sharded instead (how the pre-screened leg runs at --gpus 8: every GPU holds the
+    # whole base and an eighth of the queries; no merge)
+    "c3qshard": (12_500, 10_000_000, 1024, 100, "sqeuclidean", "f32", "one of eight C3 query shards: 12.5k queries x 10M base rows, d=1024, k=100, fp32 (not a headline number)"),
     # BASELINE config 4 (fp16 MFMA + L2, 8 GPUs) and the piece of it one GPU sees (its 12.5M-row shard, a tenth of the queries)
     "c4": (1_000_000, 100_000_000, 1536, 100, "sqeuclidean", "f16", "C4: 1M queries x 100M base, d=1536 (ada-002 shape), k=100, fp16 MFMA sqeuclidean"),
     # under north_star's base sharding every GPU sees ALL the queries against its shard

@@ -23,6 +23,7 @@ struct NwkCalibOut {
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 2) void nwk_mfma_bare_f16_kernel(const _Float16* __restrict__ rnd, int iters, NwkCalibOut* out)
 {
+    extern __shared__ char occupancy_ballast[];                      // dynamic LDS nobody touches: the launcher sizes it to cap the workgroups per CU
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     f16x8 fa[2][8], fb[2][4];
     const f16x8* src = (const f16x8*)rnd + ((size_t)(blockIdx.x * WAVES + w) % 64) * 64 * 24 + l;     // 24 fragments per lane, 64 distinct waves' worth
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nwk_mfma_bare_f16_kernel(const 
 
 __global__ __launch_bounds__(256, 3) void nwk_mfma_bare_f32_kernel(const float* __restrict__ rnd, int iters, NwkCalibOut* out)
 {
+    extern __shared__ char occupancy_ballast[];
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
     float fa[4][4], fb[4][2];                                        // [k-pair][row block] / [k-pair][column block]: one 8-k group of a slab (24 registers, as in the kernel)
     const float* src = rnd + ((size_t)(blockIdx.x * 4 + w) % 64) * 64 * 24 + l;
@@ -105,10 +107,19 @@ __global__ __launch_bounds__(256, 3) void nwk_mfma_bare_f32_kernel(const float* 
 extern "C++" {
 
 // One launch: `grid` workgroups x `iters` loop iterations.  FLOPs per launch = grid x waves x iters x 64 MFMAs x 2 x M x N x K.
-hipError_t nwk_launch_mfma_bare(hipStream_t st, int f16, const void* rnd, int iters, unsigned grid, void* out)
+// waves_per_simd: how many of these MFMA-only waves share a SIMD (f16: 1 = four-wave workgroups, one per CU; 2 = the eight-wave workgroup of
+// the tile kernel; f32: 1..3 four-wave workgroups per CU), enforced with dynamic LDS nobody touches.
+hipError_t nwk_launch_mfma_bare(hipStream_t st, int f16, int waves_per_simd, const void* rnd, int iters, unsigned grid, void* out)
 {
-    if (f16) hipLaunchKernelGGL((nwk_mfma_bare_f16_kernel<8>), dim3(grid), dim3(512), 0, st, (const _Float16*)rnd, iters, (NwkCalibOut*)out);
-    else hipLaunchKernelGGL(nwk_mfma_bare_f32_kernel, dim3(grid), dim3(256), 0, st, (const float*)rnd, iters, (NwkCalibOut*)out);
+    const size_t lds_total = 160 * 1024;
+    if (f16) {
+        if (waves_per_simd >= 2) hipLaunchKernelGGL((nwk_mfma_bare_f16_kernel<8>), dim3(grid), dim3(512), lds_total / 2 + 1024, st, (const _Float16*)rnd, iters, (NwkCalibOut*)out);
+        else hipLaunchKernelGGL((nwk_mfma_bare_f16_kernel<4>), dim3(grid), dim3(256), lds_total / 2 + 1024, st, (const _Float16*)rnd, iters, (NwkCalibOut*)out);
+    } else {
+        const int occ = waves_per_simd < 1 ? 1 : (waves_per_simd > 3 ? 3 : waves_per_simd);
+        const size_t lds = occ == 3 ? lds_total / 3 - 2048 : (occ == 2 ? lds_total / 2 - 2048 : lds_total / 2 + 1024);
+        hipLaunchKernelGGL(nwk_mfma_bare_f32_kernel, dim3(grid), dim3(256), lds, st, (const float*)rnd, iters, (NwkCalibOut*)out);
+    }
     return hipGetLastError();
 }
 

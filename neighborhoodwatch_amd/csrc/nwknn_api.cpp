@@ -1473,50 +1473,66 @@ extern "C" int nwknn_mfma_ceiling(nwknn_handle h, int dtype, double seconds, dou
     if (!(seconds > 0.0) || seconds > 30.0) return fail(NWKNN_EINVAL, "nwknn_mfma_ceiling: seconds must be in (0, 30]");
     RCCHK(use_device(h));
     const int f16 = dtype == NWKNN_DTYPE_F16;
-    const unsigned grid = (unsigned)h->num_cu * (f16 ? 8u : 12u);          // f16: one 8-wave workgroup per CU at a time; f32: three 4-wave workgroups
-    const int iters = f16 ? 2000 : 1000;                                   // ~20 ms per launch
-    const size_t rnd_bytes = 4u << 20, out_bytes = (size_t)grid * 24;
-    RCCHK(h->calib.ensure(rnd_bytes + out_bytes));
+    const size_t rnd_bytes = 4u << 20, out_cap = (size_t)h->num_cu * 16 * 24;
+    RCCHK(h->calib.ensure(rnd_bytes + out_cap));
     char* rnd = h->calib.as<char>();
     char* out = rnd + rnd_bytes;
     if (f16) HIPCHK(nwk_launch_gen_f16(h->stream, 0x6E77CA11ull, 0, (long long)(rnd_bytes / 2 / 64), 64, rnd));
     else HIPCHK(nwk_launch_gen(h->stream, 0x6E77CA11ull, 0, (long long)(rnd_bytes / 4 / 64), 64, (float*)rnd));
-    const double flops_per_launch = (double)grid * (f16 ? 8.0 : 4.0) * iters * 64.0 * (f16 ? 2.0 * 16 * 16 * 32 : 2.0 * 32 * 32 * 2);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIPCHK(hipEventCreate(&e0));
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(NWKNN_EHIP, "hipEventCreate failed"); }
     int rc = NWKNN_OK;
     double best = 0.0;
-    // launches back to back until `seconds` have passed (the clock settles under the load); the rate is that of the second half
-    const auto t_begin = std::chrono::steady_clock::now();
-    auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
-    int timed = 0;
-    bool timing = false;
-    while (rc == NWKNN_OK) {
-        const double t = elapsed();
-        if (!timing && t >= 0.5 * seconds) { if (hipEventRecord(e0, h->stream) != hipSuccess) rc = fail(NWKNN_EHIP, "hipEventRecord failed"); timing = true; }
-        if (timing && t >= seconds && timed > 0) break;
-        if (nwk_launch_mfma_bare(h->stream, f16, rnd, iters, grid, out) != hipSuccess) { rc = fail(NWKNN_EHIP, "bare MFMA loop launch failed: %s", hipGetErrorString(hipGetLastError())); break; }
-        if (timing) ++timed;
-        if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(NWKNN_EHIP, "bare MFMA loop failed: %s", hipGetErrorString(hipGetLastError())); break; }
-    }
-    if (rc == NWKNN_OK) {
+    unsigned best_grid = 0;
+    // The loop is run at every number of MFMA-only waves per SIMD the kernels use or could use (identical waves that do nothing but issue
+    // MFMAs contend for the pipe differently than a kernel's waves, which take turns); the ceiling is the best of them.  Each variant:
+    // launches back to back until its share of `seconds` has passed (the clock settles under the load), the second half timed.
+    const int n_var = f16 ? 2 : 3;
+    const bool verbose = getenv("NWKNN_CALIB_VERBOSE") != nullptr;
+    for (int wps = 1; wps <= n_var && rc == NWKNN_OK; ++wps) {
+        const int waves = f16 ? (wps == 2 ? 8 : 4) : 4;                      // waves per workgroup
+        const int per_cu = f16 ? 1 : wps;                                    // workgroups resident per CU
+        const unsigned grid = (unsigned)h->num_cu * (unsigned)per_cu * 4u;   // four rounds of resident workgroups per launch
+        const int iters = f16 ? (wps == 2 ? 2000 : 4000) : 3000 / wps;       // ~20 ms per launch
+        const double flops_per_launch = (double)grid * waves * iters * 64.0 * (f16 ? 2.0 * 16 * 16 * 32 : 2.0 * 32 * 32 * 2);
+        const double share = seconds / n_var;
+        const auto t_begin = std::chrono::steady_clock::now();
+        auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
+        int timed = 0;
+        bool timing = false;
+        while (rc == NWKNN_OK) {
+            const double t = elapsed();
+            if (!timing && t >= 0.5 * share) { if (hipEventRecord(e0, h->stream) != hipSuccess) rc = fail(NWKNN_EHIP, "hipEventRecord failed"); timing = true; }
+            if (timing && t >= share && timed > 0) break;
+            if (nwk_launch_mfma_bare(h->stream, f16, wps, rnd, iters, grid, out) != hipSuccess) { rc = fail(NWKNN_EHIP, "bare MFMA loop launch failed: %s", hipGetErrorString(hipGetLastError())); break; }
+            if (timing) ++timed;
+            if (hipStreamSynchronize(h->stream) != hipSuccess) { rc = fail(NWKNN_EHIP, "bare MFMA loop failed: %s", hipGetErrorString(hipGetLastError())); break; }
+        }
+        if (rc != NWKNN_OK) break;
         float ms = 0.f;
-        if (hipEventRecord(e1, h->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f))
+        if (hipEventRecord(e1, h->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f)) {
             rc = fail(NWKNN_EHIP, "timing the bare MFMA loop failed");
-        else best = flops_per_launch * timed / (ms * 1e-3) / 1e12;
+            break;
+        }
+        const double tf = flops_per_launch * timed / (ms * 1e-3) / 1e12;
+        if (verbose) fprintf(stderr, "libnwknn: bare %s MFMA loop, %d wave(s) per SIMD: %.1f TFLOP/s\n", f16 ? "f16" : "f32", wps, tf);
+        if (tf > best) {
+            best = tf; best_grid = grid;
+            if (out_clock_ghz) {                                             // median over the workgroups of this variant's last launch: cycles / (100 MHz ticks)
+                std::vector<unsigned long long> raw((size_t)grid * 3);
+                if (hipMemcpy(raw.data(), out, (size_t)grid * 24, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(NWKNN_EHIP, "reading the loop's clock stamps failed"); break; }
+                std::vector<double> clk;
+                for (unsigned g = 0; g < grid; ++g) if (raw[(size_t)g * 3 + 1] > 0) clk.push_back((double)raw[(size_t)g * 3] / (double)raw[(size_t)g * 3 + 1] * 0.1);
+                std::sort(clk.begin(), clk.end());
+                *out_clock_ghz = clk.empty() ? 0.0 : clk[clk.size() / 2];
+            }
+        }
     }
+    (void)best_grid;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     RCCHK(rc);
     *out_tflops = best;
-    if (out_clock_ghz) {                                                     // median over the workgroups of the last launch: cycles / (100 MHz ticks)
-        std::vector<unsigned long long> raw((size_t)grid * 3);
-        HIPCHK(hipMemcpy(raw.data(), out, out_bytes, hipMemcpyDeviceToHost));
-        std::vector<double> clk;
-        for (unsigned g = 0; g < grid; ++g) if (raw[(size_t)g * 3 + 1] > 0) clk.push_back((double)raw[(size_t)g * 3] / (double)raw[(size_t)g * 3 + 1] * 0.1);
-        std::sort(clk.begin(), clk.end());
-        *out_clock_ghz = clk.empty() ? 0.0 : clk[clk.size() / 2];
-    }
     return NWKNN_OK;
 }
 

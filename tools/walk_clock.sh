@@ -12,7 +12,7 @@ for cfg in $cfgs; do
   for pass in sq fetch; do
     ctr="GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES"; [ $pass = fetch ] && ctr="FETCH_SIZE"
     rm -rf gpurun_out/wc_${pass}
-    rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d gpurun_out/wc_${pass} -- python3 bench.py --workload $w $args --no-cpu-baseline --no-secondary --opt super_q_shift=$sh,super_walk_q=$wq ${EXTRA_OPT} > gpurun_out/wc_${pass}.json 2> gpurun_out/wc_${pass}.err || { tail -5 gpurun_out/wc_${pass}.err; exit 1; }
+    rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d gpurun_out/wc_${pass} -- python3 bench.py --workload $w $args --no-cpu-baseline --no-secondary --opt super_q_shift=$sh,super_walk_q=$wq${EXTRA_OPT} > gpurun_out/wc_${pass}.json 2> gpurun_out/wc_${pass}.err || { tail -5 gpurun_out/wc_${pass}.err; exit 1; }
   done
   python3 - >> $out <<PY
 import collections, csv, glob, json
@@ -30,10 +30,10 @@ def collect(d):
 a, ms, n = collect("wc_sq"); f, fms, fn = collect("wc_fetch")
 cyc = a["GRBM_GUI_ACTIVE"] / 8
 b = json.loads(open("gpurun_out/wc_sq.json").read().strip().splitlines()[-1])
-rf = (b.get("exact_prescreen") or b)["roofline"] if "$w" != "c3" or "prescreen=1" not in "${EXTRA_OPT}" else b["roofline"]
+rf = b["roofline"]          # the f16 workloads, or an fp32 workload run with EXTRA_OPT=,prescreen=1: the main leg IS the fp16 kernel's
 print(f"$w {1<<$sh:2d} q-tiles x {64>>$sh:2d} b-strips, {'query' if $wq else 'base'} tile fastest: f16x launches {n}, kernel {ms:9.2f} ms (fetch pass {fms:9.2f}), "
       f"clock {cyc/(ms*1e-3)/1e9:.3f} GHz, MFMA busy {a['SQ_VALU_MFMA_BUSY_CYCLES']/(cyc*1024)*100:.1f} %, busy x clock / 2.4 = {a['SQ_VALU_MFMA_BUSY_CYCLES']/(cyc*1024)*cyc/(ms*1e-3)/2.4e9:.3f}, "
-      f"fabric {f['FETCH_SIZE']*2048/1e9/max(fn,1):7.1f} GB per launch, bench: {b['value']:.0f} q/s, tile {rf['achieved']:.1f} TF = {rf['frac']:.3f}")
+      f"fabric {f['FETCH_SIZE']*2048/1e9/max(fn,1):7.1f} GB per launch, bench: {b['value']:.0f} q/s, tile {rf['achieved']:.1f} TF = {rf['achieved']/2500.0:.3f} of 2.5 PF")
 PY
   tail -1 $out
 done
