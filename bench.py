@@ -516,8 +516,12 @@ def main_inlib(args):
     import torch
     from neighborhoodwatch_amd import KnnEngine, ShardedKnnEngine
     n = args.gpus
-    if torch.cuda.device_count() < n:
-        raise SystemExit(f"--gpus {n} --collective inlib needs {n} GPUs, this node shows {torch.cuda.device_count()}")
+    have = torch.cuda.device_count()
+    virtual = have < n and bool(os.environ.get("NWKNN_RCCL_LIBRARY"))          # rehearsal: a stand-in transport whose ranks share GPUs (tests/fake_rccl)
+    if have < n and not virtual:
+        raise SystemExit(f"--gpus {n} --collective inlib needs {n} GPUs, this node shows {have} "
+                         "(NWKNN_RCCL_LIBRARY=<tests/fake_rccl build> rehearses the N-device path on fewer)")
+    dev_list = [g % max(have, 1) for g in range(n)]
     Q, B, d, k, metric, dtype, desc = WORKLOADS[args.workload]
     if metric == "maxsim":
         raise SystemExit("--collective inlib covers the kNN workloads (nwknn_search_sharded); MaxSim shards through torch.distributed")
@@ -525,7 +529,7 @@ def main_inlib(args):
         metric = args.metric
     with KnnEngine(0) as gen:
         queries = gen.generate(SEED_QUERY, 0, Q, d, dtype).cpu().numpy()
-    eng = ShardedKnnEngine(list(range(n)), profile=True)
+    eng = ShardedKnnEngine(dev_list, profile=True)
     for kvs in args.opt:
         for kv in kvs.split(","):
             name, value = kv.split("=")
@@ -552,8 +556,8 @@ def main_inlib(args):
     peak = MFMA_PEAK_TFLOPS[dtype]
     devices = []
     for g in range(n):
-        pr = torch.cuda.get_device_properties(g)
-        devices.append({"rank": g, "device": g, "name": pr.name, "gcn_arch": getattr(pr, "gcnArchName", ""), "uuid": str(getattr(pr, "uuid", "")),
+        pr = torch.cuda.get_device_properties(dev_list[g])
+        devices.append({"rank": g, "device": dev_list[g], "name": pr.name, "gcn_arch": getattr(pr, "gcnArchName", ""), "uuid": str(getattr(pr, "uuid", "")),
                         "hbm_gib": round(pr.total_memory / 2**30, 1)})
     line = {"metric": "queries/sec + pairwise-dist TFLOP/s, 100k x 10M d=1024 k=100" if args.workload == "c3" else f"queries/sec ({args.workload})",
             "value": Q * args.steps / elapsed, "unit": "queries/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
@@ -564,7 +568,8 @@ def main_inlib(args):
                        "parallelism": f"base rows sharded x{n} inside ONE process (C ABI: nwknn_comm_*), RCCL all-gather of [Q,k] partials + sliced merge"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                          "kernel": "per-device rate: tile FLOPs summed over the devices / tile-kernel time summed over the devices"},
-            "collective": {"kind": "in-library (C ABI nwknn_search_sharded: one process, N GPUs, ncclCommInitAll)", "backend": "rccl",
+            "collective": {"kind": "in-library (C ABI nwknn_search_sharded: one process, N GPUs, ncclCommInitAll)",
+                           "backend": "REHEARSAL: stand-in transport, virtual devices sharing GPUs (NWKNN_RCCL_LIBRARY)" if virtual else "rccl",
                            "search_ms": agg["search_ms"] / args.steps, "allgather_ms": agg["allgather_ms"] / args.steps,
                            "merge_ms": agg["merge_ms"] / args.steps, "allgather_bytes_per_rank": n * Q * k * 12,
                            "timing": "per step, HIP events, maxima over the devices (nwknn_comm_stats)"}}

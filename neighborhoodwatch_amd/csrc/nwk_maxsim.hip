@@ -579,6 +579,30 @@ __global__ __launch_bounds__(256) void nwk_maxsim_prune_kernel(const NwkMsRescor
     }
 }
 
+// The pre-screen's invariant for one rescored (query, doc) pair, as in nwk_rescore_kernel: the listed estimate of -score against the
+// canonical -score and the bound the pair was kept under (the expression of nwk_maxsim_prune_kernel).  Called by the lane that writes the key.
+struct MsCheck {
+    u32 n_chk = 0, n_bad = 0;
+    float worst = 0.0f;
+    __device__ __forceinline__ void pair(const NwkMsRescoreParams& p, float rq, u64 old_key, float neg_score)
+    {
+        const float est = __uint_as_float((u32)(old_key >> 32));
+        const float err = (rq + p.cd[(u32)old_key]) * 1.0001f + 2.0e-6f * (fabsf(est) + 1.0f);
+        const float dev = fabsf(neg_score - est);
+        ++n_chk;
+        if (!(dev <= err * p.chk_scale)) ++n_bad;
+        const float ratio = dev / err;
+        worst = fmaxf(worst, ratio == ratio ? ratio : __builtin_inff());
+    }
+    __device__ __forceinline__ void flush(const NwkMsRescoreParams& p) const
+    {
+        if (!p.chk || !n_chk) return;
+        atomicAdd(p.chk, (u64)n_chk);
+        if (n_bad) atomicAdd(p.chk + 1, (u64)n_bad);
+        atomicMax((u32*)(p.chk + 2), __float_as_uint(worst));
+    }
+};
+
 template <bool QLDS>      // the query's token rows are staged in LDS (a generic pointer would make every read a flat_load)
 __global__ __launch_bounds__(256) void nwk_maxsim_rescore_kernel(const NwkMsRescoreParams p)
 {
@@ -600,9 +624,12 @@ __global__ __launch_bounds__(256) void nwk_maxsim_rescore_kernel(const NwkMsResc
         __builtin_amdgcn_wave_barrier();
     }
 
+    MsCheck chk;
+    const float rq_mine = p.rq[q];
     for (u32 i = slice * 2; i < nsurv; i += slices * 2) {                               // survivors i and i+1 (wave-uniform)
         const u32 e0 = surv[i], e1 = (i + 1 < nsurv) ? surv[i + 1] : e0;
-        const u32 doc0 = (u32)list[e0], doc1 = (u32)list[e1];
+        const u64 old0 = list[e0], old1 = list[e1];
+        const u32 doc0 = (u32)old0, doc1 = (u32)old1;
         const float* __restrict__ br0 = p.bp + ((long long)doc0 * NWK_MS_TOKENS_PER_DOC + lane) * p.dp;
         const float* __restrict__ br1 = p.bp + ((long long)doc1 * NWK_MS_TOKENS_PER_DOC + lane) * p.dp;
         float a0[NWK_MS_TOKENS_PER_QUERY], a1[NWK_MS_TOKENS_PER_QUERY];
@@ -660,9 +687,11 @@ __global__ __launch_bounds__(256) void nwk_maxsim_rescore_kernel(const NwkMsResc
         }
         if (lane == 0) {
             list[e0] = ((u64)sortable_u32(-s0) << 32) | doc0;
-            if (e1 != e0) list[e1] = ((u64)sortable_u32(-s1) << 32) | doc1;
+            chk.pair(p, rq_mine, old0, -s0);
+            if (e1 != e0) { list[e1] = ((u64)sortable_u32(-s1) << 32) | doc1; chk.pair(p, rq_mine, old1, -s1); }
         }
     }
+    if (lane == 0) chk.flush(p);
 }
 
 
@@ -694,9 +723,12 @@ __global__ __launch_bounds__(256) void nwk_maxsim_rescore_mfma_kernel(const NwkM
     u64* list = p.buf + q * p.cap;
     const u32* surv = p.surv + q * p.cap;
     const int ngroups = dp / 8;                                      // multiple of 4
+    MsCheck chk;
+    const float rq_mine = p.rq[q];
     for (u32 i = blockIdx.y * 4 + wv; i < nsurv; i += gridDim.y * 4) {                   // wave-uniform
         const u32 e = surv[i];
-        const u32 doc = (u32)list[e];
+        const u64 old = list[e];
+        const u32 doc = (u32)old;
         const float* __restrict__ a0p = p.bp + ((long long)doc * NWK_MS_TOKENS_PER_DOC + c32) * dp + 4 * h;   // token rows 0..31
         const float* __restrict__ a1p = a0p + 32 * dp;                                                      // token rows 32..63
         f32x16 acc0, acc1;
@@ -732,8 +764,9 @@ __global__ __launch_bounds__(256) void nwk_maxsim_rescore_mfma_kernel(const NwkM
 #pragma unroll
         for (int r = 0; r < 16; ++r) v = fmaxf(v, acc1[r]);
         const float sum = ms_token_sum(v);                           // max over the two half-waves, then the kernel's pairwise tree over the 32 query tokens
-        if (lane == 0) list[e] = ((u64)sortable_u32(-sum) << 32) | doc;
+        if (lane == 0) { list[e] = ((u64)sortable_u32(-sum) << 32) | doc; chk.pair(p, rq_mine, old, -sum); }
     }
+    if (lane == 0) chk.flush(p);
 }
 
 // ------------------------------------------------------------------------------------------------

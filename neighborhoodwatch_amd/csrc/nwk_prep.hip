@@ -80,8 +80,18 @@ __global__ __launch_bounds__(256) void nwk_prep_tiled_kernel(const TIN* __restri
     constexpr int OP = OB / 16;                           // 16-B output pieces per row per step
     constexpr int PITCH = 144;                            // 128 + 16: lane-per-row ds_read_b128 / ds_write_b128 stay conflict-free
     constexpr int RPP = 256 / SEGS;                       // rows per load pass
+    // round 4: ONE 36 KiB tile, rewritten in place by the lane that owns the row (it reads all of its row's pieces into registers before it
+    // writes the permuted / converted ones back), so FOUR workgroups fit a CU instead of two: twice the loads in flight for a kernel whose
+    // only business is HBM (PREP_ALIAS=0 builds the two-tile form for A/B: tools/mk_variant_lib.sh)
+#ifndef PREP_ALIAS
+#define PREP_ALIAS 1
+#endif
     __shared__ __attribute__((aligned(16))) char tile_in[256 * PITCH];
+#if PREP_ALIAS
+    char* const tile_out = tile_in;
+#else
     __shared__ __attribute__((aligned(16))) char tile_out[256 * PITCH];
+#endif
 
     const int tid = threadIdx.x;
     const long long r0 = (long long)blockIdx.x * 256;
@@ -158,6 +168,9 @@ __global__ __launch_bounds__(256) void nwk_prep_tiled_kernel(const TIN* __restri
                 *(u32x4*)((char*)prepared + (size_t)(r0 + row) * out_row_bytes + (size_t)k0 * OES + seg * 16) =
                     *(const u32x4*)(tile_out + row * PITCH + seg * 16);
         }
+#if PREP_ALIAS
+        __syncthreads();                                  // the tile has been read out: the next step may overwrite it
+#endif
     }
     if (r0 + tid < rows_pad) norms[r0 + tid] = acc;
 }

@@ -1213,6 +1213,7 @@ static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq
         rp.dp = h->dp; rp.cap = cap; rp.k = k; rp.prune = (h->opt_pre_prune && !dedupe) ? 1 : 0;
         rp.dbg = h->opt_dbg_ptr ? (unsigned long long*)(uintptr_t)h->opt_dbg_ptr : nullptr;
         rp.surv = h->ms_surv.as<u32>(); rp.nsurv = h->ms_nsurv.as<u32>(); rp.rescore_valu = (int)h->opt_ms_rescore_valu;
+        rp.chk_scale = (float)((double)h->opt_pre_check_ppm * 1e-6); rp.chk = h->chk.as<u64>();
         // enough (query, slice) waves to fill the chip a few times over
         const int slices = (int)std::max<long long>(1, std::min<long long>(32, (8ll * h->num_cu * 4 + nq_pad - 1) / nq_pad));
         e = ev_begin(h, 3);
@@ -1234,9 +1235,10 @@ static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq
     return NWKNN_OK;
 }
 
-static int maxsim_search_impl(nwknn_handle h, const void* query_tokens, int64_t n_queries, int32_t tokens_per_query, int dtype, int location,
-                              int32_t k, int64_t doc_offset, float* out_score, int64_t* out_doc, int out_location)
+static int maxsim_search_attempt(nwknn_handle h, const void* query_tokens, int64_t n_queries, int32_t tokens_per_query, int dtype, int location,
+                                 int32_t k, int64_t doc_offset, float* out_score, int64_t* out_doc, int out_location, int attempt, long long* violations)
 {
+    *violations = 0;
     if (!h || !query_tokens || !out_score || !out_doc) return fail(NWKNN_EINVAL, "nwknn_maxsim_search: null argument");
     if (h->ms_docs <= 0) return fail(NWKNN_ESTATE, "nwknn_maxsim_search: call nwknn_maxsim_set_docs first");
     if (tokens_per_query != NWK_MS_TOKENS_PER_QUERY) return fail(NWKNN_EINVAL, "nwknn_maxsim_search: tokens_per_query must be %d", NWK_MS_TOKENS_PER_QUERY);
@@ -1261,8 +1263,10 @@ static int maxsim_search_impl(nwknn_handle h, const void* query_tokens, int64_t 
     h->ev_used = 0;
     if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_begin, h->stream));
     RCCHK(stage_and_prep(h, query_tokens, location, 0, 0, qrows, h->d, qrows_pad, h->dp, h->qraw, h->qp.p, h->qn.as<float>()));
-    bool pre = h->ms_pre != 0;
+    bool pre = h->ms_pre != 0 && attempt == 0;                     // a later attempt follows a failed invariant: the direct fp32 MaxSim kernel
     if (pre) {
+        RCCHK(h->chk.ensure(32));
+        HIPCHK(hipMemsetAsync(h->chk.p, 0, 32, h->stream));
         float q_maxabs = 0.f;
         bool usable = false;
         RCCHK(matrix_maxabs(h, h->qp.as<float>(), qrows_pad * (long long)h->dp, &q_maxabs, &usable));
@@ -1339,6 +1343,17 @@ static int maxsim_search_impl(nwknn_handle h, const void* query_tokens, int64_t 
         HIPCHK(hipStreamSynchronize(h->stream));
         if (any) return fail(NWKNN_EHIP, "internal: MaxSim list overflow on a safe range");
     }
+    if (pre) {                                                     // the pre-screen's invariant, counted by every rescoring launch (as in search_attempt)
+        u64 chk[3] = {0, 0, 0};
+        HIPCHK(hipMemcpyAsync(chk, h->chk.p, sizeof chk, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->stats.prescreen_checked = (int64_t)chk[0];
+        float w;
+        const u32 wb = (u32)chk[2];
+        memcpy(&w, &wb, 4);
+        h->stats.prescreen_worst = (double)w;
+        if (chk[1] != 0) { *violations = (long long)chk[1]; return NWKNN_OK; }
+    }
     float* od = out_score;
     long long* oi = (long long*)out_doc;
     if (out_location == NWKNN_HOST) {
@@ -1365,8 +1380,22 @@ static int maxsim_search_impl(nwknn_handle h, const void* query_tokens, int64_t 
 extern "C" int nwknn_maxsim_search(nwknn_handle h, const void* query_tokens, int64_t n_queries, int32_t tokens_per_query, int dtype, int location,
                                    int32_t k, int64_t doc_offset, float* out_score, int64_t* out_doc, int out_location)
 {
-    return guarded([&] { return maxsim_search_impl(h, query_tokens, n_queries, tokens_per_query, dtype, location, k, doc_offset, out_score, out_doc,
-                                                   out_location); });
+    return guarded([&]() -> int {
+        long long discarded = 0;
+        for (int attempt = 0;; ++attempt) {
+            long long bad = 0;
+            RCCHK(maxsim_search_attempt(h, query_tokens, n_queries, tokens_per_query, dtype, location, k, doc_offset, out_score, out_doc, out_location, attempt, &bad));
+            if (bad == 0) {
+                h->stats.prescreen_fallbacks = attempt;
+                h->stats.prescreen_violations = discarded;
+                return NWKNN_OK;
+            }
+            discarded += bad;
+            fprintf(stderr, "libnwknn: MaxSim pre-screen invariant failed on %lld of %lld rescored pairs (|estimate - exact| above %lld ppm of the bound): "
+                            "attempt discarded, searching again on the direct fp32 kernel\n", bad, (long long)h->stats.prescreen_checked, (long long)h->opt_pre_check_ppm);
+            if (attempt >= 1) return fail(NWKNN_EHIP, "MaxSim pre-screen invariant violated on the direct path (%lld pairs): internal error", bad);
+        }
+    });
 }
 
 // ---- merge ------------------------------------------------------------------------------------------

@@ -60,6 +60,7 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*GetVersion)(int*) = nullptr;
+    bool shares_one_device = false;               // the loaded transport says its ranks may live on one GPU (tests/fake_rccl: not RCCL)
 };
 
 static int load_rccl(Rccl* r)
@@ -70,8 +71,16 @@ static int load_rccl(Rccl* r)
         tried = true;
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         void* lib = nullptr;
-        for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (lib) break; }     // a copy already in the process first
-        for (const char* n : names) { if (lib) break; lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); }
+        // NWKNN_RCCL_LIBRARY: a site's own build of RCCL, by path (the test suite points it at tests/fake_rccl, a stand-in whose ranks share
+        // one GPU, to execute the N > 1 orchestration on a one-GPU box)
+        const char* forced = getenv("NWKNN_RCCL_LIBRARY");
+        if (forced && *forced) {
+            lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            fprintf(stderr, "libnwknn: NWKNN_RCCL_LIBRARY=%s %s\n", forced, lib ? "loaded as the collective transport" : "could not be loaded");      // never silent
+        } else {
+            for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (lib) break; }     // a copy already in the process first
+            for (const char* n : names) { if (lib) break; lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); }
+        }
         if (lib) {
             cached.lib = lib;
             cached.CommInitAll = (decltype(cached.CommInitAll))dlsym(lib, "ncclCommInitAll");
@@ -81,6 +90,7 @@ static int load_rccl(Rccl* r)
             cached.GroupEnd = (decltype(cached.GroupEnd))dlsym(lib, "ncclGroupEnd");
             cached.GetErrorString = (decltype(cached.GetErrorString))dlsym(lib, "ncclGetErrorString");
             cached.GetVersion = (decltype(cached.GetVersion))dlsym(lib, "ncclGetVersion");
+            cached.shares_one_device = dlsym(lib, "nwknn_test_transport_shares_one_device") != nullptr;
         }
     }
     if (!cached.lib) return cfail(NWKNN_EHIP, "RCCL is not available: dlopen(librccl.so.1) failed: %s", dlerror());
@@ -188,14 +198,19 @@ extern "C" int nwknn_comm_create(nwknn_comm_handle* out, const int* devices, int
 {
     if (!out || !devices || n_dev <= 0) return cfail(NWKNN_EINVAL, "nwknn_comm_create: null argument or n_dev <= 0");
     if (n_dev > 64) return cfail(NWKNN_EINVAL, "nwknn_comm_create: at most 64 devices");
+    bool twice = false;
+    int dup = -1;
     for (int a = 0; a < n_dev; ++a)
         for (int b = a + 1; b < n_dev; ++b)
-            if (devices[a] == devices[b]) return cfail(NWKNN_EINVAL, "nwknn_comm_create: device %d listed twice (one shard per GPU)", devices[a]);
+            if (devices[a] == devices[b]) { twice = true; dup = devices[a]; }
+    if (twice && !(getenv("NWKNN_RCCL_LIBRARY") && *getenv("NWKNN_RCCL_LIBRARY")))          // refused before anything is loaded (RCCL refuses it too)
+        return cfail(NWKNN_EINVAL, "nwknn_comm_create: device %d listed twice (one shard per GPU)", dup);
     nwknn_comm* c = new (std::nothrow) nwknn_comm();
     if (!c) return cfail(NWKNN_ENOMEM, "out of host memory");
     memset(&c->stats, 0, sizeof c->stats);
     int rc = load_rccl(&c->rccl);
     if (rc != NWKNN_OK) { delete c; return rc; }
+    if (twice && !c->rccl.shares_one_device) { delete c; return cfail(NWKNN_EINVAL, "nwknn_comm_create: device %d listed twice (one shard per GPU)", dup); }
     try { c->dev.resize((size_t)n_dev); } catch (...) { delete c; return cfail(NWKNN_ENOMEM, "out of host memory"); }
     auto fail_with = [&](int code) { (void)nwknn_comm_destroy(c); return code; };
     for (int g = 0; g < n_dev; ++g) {

@@ -86,6 +86,8 @@ struct NwkMsRescoreParams {
     unsigned long long* dbg;       // dev: [0] += listed pairs, [1] += rescored pairs
     int q_in_lds;                  // set by the launcher: the query's token rows fit in LDS next to the list arrays
     int rescore_valu;              // 1: the vector-pipe rescoring kernel even where the MFMA one applies (option "ms_rescore_valu")
+    float chk_scale;               // the invariant |estimate - exact score| <= R(query) + C(doc), checked as for kNN (NwkRescoreParams::chk)
+    unsigned long long* chk;
 };
 
 struct NwkCompactParams {

@@ -34,6 +34,7 @@ def _prescreen_invariant_holds_after_every_search(request, monkeypatch):
         return call
     monkeypatch.setattr(E.KnnEngine, "search", checked(E.KnnEngine.search))
     monkeypatch.setattr(E.KnnEngine, "search_columns", checked(E.KnnEngine.search_columns))
+    monkeypatch.setattr(E.KnnEngine, "maxsim_search", checked(E.KnnEngine.maxsim_search))
     yield
 
 

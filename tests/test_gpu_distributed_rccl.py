@@ -80,3 +80,102 @@ def test_the_sliced_and_two_level_merge_of_a_multi_device_search(oracle, n_lists
         od, oi = eng.merge_lists(dists, idx, k, n_slices)
     assert np.array_equal(oi, ri)
     assert np.array_equal(od.view(np.uint32), rd.view(np.uint32))
+
+
+VIRTUAL = r'''
+import os, sys, json
+sys.path.insert(0, os.environ["NW_ROOT"])
+import numpy as np
+from neighborhoodwatch_amd import KnnEngine, ShardedKnnEngine
+from oracle import cpu_oracle as orc                      # the checker (tests may use it)
+out = {}
+base, queries = orc.gen(0xE1, 0, 20011, 72), orc.gen(0xE2, 0, 203, 72)
+base[5000:5040] = base[15000:15040]                       # equal rows on different shards: cross-shard ties go to the lower global id
+for n_dev, k in ((3, 50), (5, 1000), (8, 100), (2, 7)):
+    with ShardedKnnEngine([0] * n_dev, profile=True) as eng:
+        assert len(eng.devices) == n_dev
+        eng.set_base(base)                                # shard g = rows [B g / N, B (g+1) / N) on virtual device g
+        d, i = eng.search(queries, k)
+        st = eng.stats()
+        pre = None
+        if n_dev == 3:
+            eng.set_prescreen(True); eng.set_base(base)
+            pre = eng.search(queries, k)
+    rd, ri = orc.knn_canonical(base, queries, k)
+    assert np.array_equal(i, ri) and np.array_equal(d.view(np.uint32), rd.view(np.uint32)), (n_dev, k)
+    if pre is not None:
+        assert np.array_equal(pre[1], ri) and np.array_equal(pre[0].view(np.uint32), rd.view(np.uint32))
+    assert st["n_devices"] == n_dev and st["allgather_bytes_per_device"] == n_dev * 203 * k * 12 and st["merge_ms"] > 0.0
+    out[f"{n_dev}x{k}"] = [st["allgather_ms"], st["merge_ms"]]
+# fp16 input (exact fp16 mode) over 4 virtual devices, generated on the devices like bench.py --collective inlib does
+with ShardedKnnEngine([0, 0, 0, 0]) as eng:
+    eng.generate_base(orc.SEED_BASE, 30000, 128, "f16")
+    q16 = orc.gen_f16_numpy(orc.SEED_QUERY, 0, 64, 128)
+    d, i = eng.search(q16, 20)
+b16 = orc.gen_f16_numpy(orc.SEED_BASE, 0, 30000, 128)
+rd, ri = orc.knn_canonical(b16.astype(np.float32), q16.astype(np.float32), 20)
+assert np.array_equal(i, ri) and np.array_equal(d.view(np.uint32), rd.view(np.uint32))
+# MaxSim: documents sharded over 3 virtual devices, descending merge
+docs, qs = orc.gen(0xE3, 0, 1900 * 64, 128).reshape(1900, 64, 128), orc.gen(0xE4, 0, 21 * 32, 128).reshape(21, 32, 128)
+with ShardedKnnEngine([0, 0, 0]) as eng:
+    eng.maxsim_set_docs(docs)
+    s, dd = eng.maxsim_search(qs, 100)
+rs, rdoc = orc.maxsim_canonical(docs, qs, 100)
+assert np.array_equal(dd, rdoc) and np.array_equal(s.view(np.uint32), rs.view(np.uint32))
+import ctypes
+calls = ctypes.CDLL(os.environ["NWKNN_RCCL_LIBRARY"]).nwknn_test_transport_allgather_calls
+calls.restype = ctypes.c_longlong
+print(json.dumps({"ok": True, "allgather_calls": int(calls()), "timings": out}))
+'''
+
+
+@pytest.mark.gpu
+def test_n_device_path_of_the_c_abi_collective_on_virtual_devices(tmp_path):
+    """nwknn_search_sharded with N > 1 has never run on N GPUs (no such box).  Here it runs END TO END with N = 2, 3, 5 and 8 virtual devices
+    that all live on the box's one GPU: a host thread per device, uneven shard bounds, global ids by index offset, the all-gather's
+    [N][Q][k] layout, every device merging ITS slice of the queries (two-level at 5 x 1000), the per-slice copies into the caller's arrays,
+    the pre-screened and the exact-fp16 engines under it, MaxSim's descending merge -- everything real except the transport:
+    NWKNN_RCCL_LIBRARY points the library at tests/fake_rccl (ncclAllGather = N device-to-device copies per rank, and a marker that
+    lets one GPU be listed N times, which real RCCL refuses).  Results must be the single-engine / oracle bits."""
+    import json
+    shim = tmp_path / "libfake_rccl.so"
+    hipcc = "/opt/rocm/bin/hipcc"
+    subprocess.run([hipcc, "-O2", "-shared", "-fPIC", "-x", "hip", "--offload-arch=gfx950", str(ROOT / "tests" / "fake_rccl" / "fake_rccl.cpp"), "-o", str(shim)],
+                   check=True, capture_output=True, timeout=300)
+    script = tmp_path / "virtual_devices.py"
+    script.write_text(VIRTUAL)
+    env = dict(os.environ, NW_ROOT=str(ROOT), NWKNN_RCCL_LIBRARY=str(shim), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "NWKNN_RCCL_LIBRARY=" in r.stderr and "loaded as the collective transport" in r.stderr          # never silent
+    line = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")][-1]
+    # two all-gathers (distances, indices) per virtual device and search: (3 + 3 + 5 + 8 + 2) + 4 + 3 devices = 28 device-searches
+    assert line["ok"] is True and line["allgather_calls"] == 2 * 28
+
+
+@pytest.mark.gpu
+def test_real_rccl_still_refuses_a_device_listed_twice():
+    from neighborhoodwatch_amd import ShardedKnnEngine
+    with pytest.raises(ValueError, match="listed twice"):
+        ShardedKnnEngine([0, 0])
+
+
+@pytest.mark.gpu
+def test_bench_in_library_collective_rehearsed_on_four_virtual_devices(tmp_path):
+    """`bench.py --gpus 4 --collective inlib` on the one-GPU box: the line a scaling run would produce through the C ABI's collective, with
+    the stand-in transport (labelled REHEARSAL in the line), verified against a single-engine search."""
+    import json
+    shim = tmp_path / "libfake_rccl.so"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-shared", "-fPIC", "-x", "hip", "--offload-arch=gfx950", str(ROOT / "tests" / "fake_rccl" / "fake_rccl.cpp"),
+                    "-o", str(shim)], check=True, capture_output=True, timeout=300)
+    env = dict(os.environ, NWKNN_RCCL_LIBRARY=str(shim), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(var, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--collective", "inlib", "--workload", "dev", "--steps", "2", "--warmup", "1", "--verify"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2000:])
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    b = [x for x in lines if "metric" in x][0]
+    assert [x for x in lines if "verify" in x][0]["ok"] is True
+    assert b["n_gpus"] == 4 and len(b["devices"]) == 4 and "REHEARSAL" in b["collective"]["backend"] and b["collective"]["merge_ms"] > 0.0
+    assert b["collective"]["allgather_bytes_per_rank"] == 4 * 4096 * 100 * 12

@@ -222,3 +222,28 @@ def test_descending_merge_of_score_lists(n_lists, k, n_slices):
     with ShardedKnnEngine([0]) as eng:
         s, d = eng.merge_lists(scores, docs, k, n_slices, descending=True)
     assert np.array_equal(d, ed) and np.array_equal(s.view(np.uint32), es.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.drives_fallback
+def test_maxsim_invariant_is_counted_and_its_failure_falls_back_to_the_direct_kernel(oracle, capfd):
+    """The MaxSim rescoring kernels hold every rescored (query, doc) pair's fp16 score estimate against its canonical score and the bound
+    R(query) + C(doc) it was kept under (nwknn_stats.prescreen_*), like the kNN path; with the invariant held against a sliver of the bound
+    (pre_check_ppm) the attempt is discarded and the direct fp32 MaxSim kernel gives the same bits."""
+    from neighborhoodwatch_amd import KnnEngine
+    docs, qs = _tokens(oracle, 0xD1, 6000, 64, 128), _tokens(oracle, 0xD2, 37, 32, 128)
+    rs, ri = oracle.maxsim_canonical(docs, qs, 50)
+    with KnnEngine(0) as eng:
+        eng.set_prescreen(True)
+        eng.maxsim_set_docs(docs)
+        s, i = eng.maxsim_search(qs, 50)
+        st = eng.stats()
+        assert st["prescreen"] == 1 and st["prescreen_checked"] > 37 * 50 and st["prescreen_violations"] == 0 and st["prescreen_fallbacks"] == 0
+        assert 0.0 < st["prescreen_worst"] < 0.9, st["prescreen_worst"]
+        assert np.array_equal(i, ri) and np.array_equal(s.view(np.uint32), rs.view(np.uint32))
+        eng.set_option("pre_check_ppm", max(1, int(st["prescreen_worst"] * 1e6 / 4)))
+        s, i = eng.maxsim_search(qs, 50)
+        st = eng.stats()
+        assert st["prescreen"] == 0 and st["prescreen_fallbacks"] == 1 and st["prescreen_violations"] > 0, st
+        assert np.array_equal(i, ri) and np.array_equal(s.view(np.uint32), rs.view(np.uint32))
+        assert "MaxSim pre-screen invariant failed" in capfd.readouterr().err
