@@ -782,6 +782,8 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
             tp.n_btiles = (int)std::min<long long>(per_launch, bt_total - done);
             if (prescreen || h->f16) HIPCHK(nwk_launch_tile_f16(h->stream, tp, metric, dense, prescreen ? 1 : 0));
             else HIPCHK(nwk_launch_tile(h->stream, tp, metric, dense, pl.tile_rows, (int)h->opt_diag, (int)h->opt_tile_occ));
+            h->stats.tile_launches += 1;                  // HIP launches, as a kernel trace counts them (a chunk of very many tiles is several)
+            if (rescan) h->stats.rescan_launches += 1;
         }
         tp.bt0 = bt_first; tp.n_btiles = bt_total;
     }
@@ -804,8 +806,10 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         rp.buf = h->buf.as<u64>(); rp.cnt = h->cnt.as<u32>(); rp.cnt0 = h->cnt0.as<u32>();
         rp.dp = h->dp; rp.cap = pl.cap; rp.k = k;
         // no pruning on a repair pass: it re-finds pairs that are already listed, and the k-th smallest upper bound over a list
-        // with duplicates can lie below the k-th distinct distance
-        rp.prune = (h->opt_pre_prune && !dedupe && !dense) ? 1 : 0;
+        // with duplicates can lie below the k-th distinct distance.  (Round 4: the dense first chunk of exact fp16 mode IS pruned -- all of
+        // its cap/2 slots carry estimates, and only the ~k of them whose lower bound reaches the k-th smallest upper bound can be among
+        // the k nearest: 512 -> ~110 rescored pairs per query, a third of a C4 search's rescoring.)
+        rp.prune = (h->opt_pre_prune && !dedupe) ? 1 : 0;
         rp.rows16 = pl.native16 ? 1 : 0;
         rp.eps_half = pl.pre_eps_half; rp.aq = pl.pre_aq; rp.ab = pl.pre_ab; rp.cst = pl.pre_cst;
         rp.chk_scale = (float)((double)h->opt_pre_check_ppm * 1e-6);
@@ -814,9 +818,7 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         HIPCHK(nwk_launch_rescore(h->stream, rp, metric, nq_pad));
         ev_end(h, e);
     }
-    h->stats.tile_launches += 1;
-    if (rescan) h->stats.rescan_launches += 1;
-    {   // algorithmic FLOPs of this launch: real (unpadded) query rows x real base rows x 2d
+    {   // algorithmic FLOPs of this chunk: real (unpadded) query rows x real base rows x 2d
         const long long real_rows = std::max<long long>(0, std::min<long long>(lo + rows, h->nb) - lo);
         const double q_rows = qtile_list ? (double)n_list_tiles * pl.tile_rows : (double)h->stats.nq;
         h->stats.tile_flops += 2.0 * q_rows * (double)real_rows * (double)h->d;
