@@ -65,6 +65,9 @@ def test_comm_stats_layout_and_argument_errors(tmp_path):
     assert L.nwknn_comm_create(ctypes.byref(h), two, 0) == -1
     assert L.nwknn_search_sharded(None, None, 1, 0, 1, 0, None, None) == -1
     assert L.nwknn_comm_destroy(None) == 0 and L.nwknn_comm_device_count(None) == 0
+    assert L.nwknn_comm_merge_lists(None, None, None, 2, 1, 1, 1, 0, None, None) == -1 and b"null" in L.nwknn_last_error()
+    assert L.nwknn_comm_maxsim_set_docs(None, None, 1, 64, 8, 0) == -1
+    assert L.nwknn_maxsim_search_sharded(None, None, 1, 32, 0, 1, None, None) == -1
 
 
 def test_argument_errors_do_not_need_a_gpu():
@@ -74,6 +77,12 @@ def test_argument_errors_do_not_need_a_gpu():
     assert b"null" in L.nwknn_last_error()
     assert L.nwknn_set_option(None, b"capacity", 1024) == -1
     assert L.nwknn_search(None, None, 1, 0, 0, 1, 0, 0, None, None, 0) == -1
+    assert L.nwknn_pair_distances(None, None, 1, 0, 0, None, 1, 0, 0, None, 0) == -1 and b"null" in L.nwknn_last_error()
+    assert L.nwknn_pair_dots(None, None, 1, 0, 0, None, 1, 0, None, 0) == -1
+    import ctypes as _c
+    tf = _c.c_double()
+    assert L.nwknn_mfma_ceiling(None, 1, 1.0, _c.byref(tf), None) == -1
+    assert L.nwknn_set_option(None, b"pre_check_ppm", 1000000) == -1 and b"null handle" in L.nwknn_last_error()    # a shipped option: gets as far as the handle check
     assert L.nwknn_destroy(None) == 0
 
 

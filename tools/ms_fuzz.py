@@ -12,7 +12,7 @@ bad = 0
 for c in range(cases):
     nd = int(rng.integers(520, 40000)); nq = int(rng.integers(1, 90)); d = int(rng.choice([32, 64, 96, 128, 128, 128]))
     k = int(min(nd, rng.choice([1, 10, 100, 333, 1000])))
-    ring = int(rng.choice([1, 1, 1, 0])); strip = int(rng.choice([0, 0, 2, 5, 16, 64])); mfma = int(rng.integers(0, 2))
+    strip = int(rng.choice([0, 0, 1, 2, 5, 16, 64])); valu = int(rng.integers(0, 2))          # ms_strip 1 = the any-d kernel; ms_rescore_valu: vector-pipe rescoring
     kind = int(rng.integers(0, 3))
     g = torch.Generator(device="cuda"); g.manual_seed(int(rng.integers(1 << 30)))
     docs = torch.randn((nd, 64, d), device="cuda", generator=g); qs = torch.randn((nq, 32, d), device="cuda", generator=g)
@@ -25,16 +25,16 @@ for c in range(cases):
     for pre in (0, 1):
         with KnnEngine(0, profile=True) as eng:
             eng.set_prescreen(bool(pre))
-            eng.set_option("ms_ring", ring); eng.set_option("ms_strip", strip); eng.set_option("ms_mfma", mfma)
+            eng.set_option("ms_strip", strip); eng.set_option("ms_rescore_valu", valu)
             if rng.integers(0, 4) == 0:
                 eng.set_option("capacity", 4096 if k > 256 else 1024); eng.set_option("first_chunk", 256)
             eng.maxsim_set_docs(docs)
             s, i = eng.maxsim_search(qs, k)
             st = eng.stats()
-            res.append((s.clone(), i.clone(), st["prescreen"]))
-    ok = torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+            res.append((s.clone(), i.clone(), st["prescreen"], st["prescreen_violations"], st["prescreen_fallbacks"], st["prescreen_worst"]))
+    ok = torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and res[1][3] == 0 and res[1][4] == 0 and res[1][5] < 1.0      # + the invariant held
     if not ok:
         bad += 1
-    print(f"case {c:3d}: docs {nd:6d} queries {nq:3d} d {d:3d} k {k:4d} kind {kind} ring {ring} strip {strip:2d} mfma {mfma} prescreened {res[1][2]} -> {'ok' if ok else 'MISMATCH'}", flush=True)
+    print(f"case {c:3d}: docs {nd:6d} queries {nq:3d} d {d:3d} k {k:4d} kind {kind} strip {strip:2d} rescore_valu {valu} prescreened {res[1][2]} worst {res[1][5]:.4f} -> {'ok' if ok else 'MISMATCH'}", flush=True)
 print(f"{cases - bad} of {cases} equal", flush=True)
 sys.exit(1 if bad else 0)
