@@ -76,6 +76,80 @@ __global__ __launch_bounds__(MODE == 1 ? 256 : 512, MODE == 1 ? 1 : 2) void prob
     if (sum == 12345.678f) out[blockIdx.x].sink = sum;
 }
 
+// modes 3 / 4: the ping-pong phase structure (two groups of four waves alternate, one barrier per phase) with the fragment reads moved INTO the
+// compute phase, software-pipelined one k-step ahead (two register buffers of 8 A + 4 B fragments), so that the other phase holds nothing but the
+// LDS-DMA issue: mode 3 leaves it empty, mode 4 issues the wave's share of the next slab (8 x 1 KiB from an L2-resident buffer into the other
+// stage) and waits for its own previous share first.  Data are random either way: what is measured is the rate of the structure.
+template <int DMA>
+__global__ __launch_bounds__(512, 2) void probe_pp(const _Float16* __restrict__ rnd, const _Float16* __restrict__ stream, int slabs, Out* out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // two 64 KiB stages
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, c16 = l & 15;
+    for (int i = tid; i < 2 * STAGE / 16; i += 512) ((f16x8*)smem)[i] = ((const f16x8*)rnd)[(blockIdx.x % 4) * (2 * STAGE / 16) + i];
+    __syncthreads();
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int grp = wu >> 2, wr = wu >> 2, wc = wu & 3;
+    const int swz = (c16 >> 1) & 7;
+    const int offA0 = (wr * 128 + c16) * 128 + ((g ^ swz) << 4);
+    const int offB0 = 32768 + (wc * 64 + c16) * 128 + ((g ^ swz) << 4);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)stream, 0, 0x7FFFFFFF, 0x00020000);
+    f32x4 acc[8][4];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = zero;
+    f16x8 fa[2][8], fb[2][4];
+    auto read_k = [&](int buf, int stage, int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) fa[buf][m] = *(const f16x8*)(smem + stage * STAGE + (offA0 ^ (ks << 6)) + m * 2048);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) fb[buf][n] = *(const f16x8*)(smem + stage * STAGE + (offB0 ^ (ks << 6)) + n * 2048);
+    };
+    auto mfma_k = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][m], fb[buf][n], acc[m][n], 0, 0, 0);
+    };
+    read_k(0, 0, 0);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    if (grp == 1) __builtin_amdgcn_s_barrier();                      // group 1 starts one phase later
+    for (int s = 0; s < slabs; ++s) {
+        const int st = s & 1;
+        // ---- COMPUTE: reads of the next k-step in flight under this k-step's MFMAs
+        __builtin_amdgcn_s_setprio(2);
+        read_k(1, st, 1);
+        mfma_k(0);
+        read_k(0, st ^ 1, 0);
+        mfma_k(1);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- the other phase: nothing (mode 3) or this wave's share of the LDS-DMA stream (mode 4)
+        if (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // its share of the slab the partner is about to read: requested a slab period ago
+            const int soff = ((s * 8 + wu) & 127) * 65536;           // an 8 MiB window of the stream buffer: L2 / Infinity-Cache resident
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + (st ^ 1) * STAGE + (wu * 8 + i) * 1024), 16,
+                                                         (unsigned)(l * 16), soff + i * 1024, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) sum += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+    if (tid == 0) { out[blockIdx.x].cycles = t1 - t0; out[blockIdx.x].realtime = r1 - r0; }
+    if (sum == 12345.678f) out[blockIdx.x].sink = sum;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 template <int MODE>
@@ -107,6 +181,34 @@ static int run(const _Float16* rnd, Out* out, int cus, int slabs, const char* wh
     return 0;
 }
 
+template <int DMA>
+static int run_pp(const _Float16* rnd, const _Float16* stream, Out* out, int cus, int slabs, const char* what)
+{
+    const unsigned grid = (unsigned)cus * 4;
+    const size_t lds = 2 * STAGE + 1024;
+    const double flops = (double)grid * 8 * slabs * 64.0 * (2.0 * 16 * 16 * 32);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 30; ++i) hipLaunchKernelGGL(probe_pp<DMA>, dim3(grid), dim3(512), lds, 0, rnd, stream, slabs, out);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    const int reps = 40;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(probe_pp<DMA>, dim3(grid), dim3(512), lds, 0, rnd, stream, slabs, out);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<Out> h(grid);
+    CK(hipMemcpy(h.data(), out, grid * sizeof(Out), hipMemcpyDeviceToHost));
+    std::vector<double> clk;
+    for (auto& o : h) if (o.realtime) clk.push_back((double)o.cycles / (double)o.realtime * 0.1);
+    std::sort(clk.begin(), clk.end());
+    const double tf = flops * reps / (ms * 1e-3) / 1e12;
+    printf("%-58s %8.1f TFLOP/s  clock %.3f GHz  = %.2f us per slab and CU\n", what, tf, clk.empty() ? 0.0 : clk[clk.size() / 2],
+           2.0 * 256 * 256 * 64 * cus / (tf * 1e12) * 1e6);
+    fflush(stdout);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     const int slabs = argc > 1 ? atoi(argv[1]) : 4000;
@@ -120,11 +222,17 @@ int main(int argc, char** argv)
     unsigned long long z = 0x6E77CA11ull;
     for (size_t i = 0; i < n; ++i) { z = z * 6364136223846793005ull + 1442695040888963407ull; h[i] = (_Float16)((float)(int)((z >> 40) & 2047) / 1024.0f - 1.0f); }
     CK(hipMemcpy(rnd, h.data(), n * 2, hipMemcpyHostToDevice));
+    _Float16* stream;                                                // 8 MiB + slack of random halves: the LDS-DMA source of mode 4
+    const size_t sn = (size_t)(128 * 65536 + 65536) / 2;
+    CK(hipMalloc(&stream, sn * 2));
+    for (size_t off = 0; off < sn; off += n) CK(hipMemcpy(stream + off, h.data(), std::min(n, sn - off) * 2, hipMemcpyHostToDevice));
     printf("%s, %d CUs, %d slabs of 64 halves per workgroup, one workgroup per CU, random operands\n", prop.gcnArchName, cus, slabs);
     for (int r = 0; r < 2; ++r) {
         if (run<2>(rnd, out, cus, slabs, "bare: 8 waves, 128 x 64 per wave, fragments kept in registers")) return 1;
         if (run<0>(rnd, out, cus, slabs, "shipped tile: 8 waves (2 / SIMD), 128 x 64 per wave, reads + MFMAs")) return 1;
         if (run<1>(rnd, out, cus, slabs, "alternative: 4 waves (1 / SIMD), 128 x 128 per wave, reads + MFMAs")) return 1;
+        if (run_pp<0>(rnd, stream, out, cus, slabs, "ping-pong phases, reads pipelined INTO the compute phase, no DMA")) return 1;
+        if (run_pp<1>(rnd, stream, out, cus, slabs, "... + the LDS-DMA stream issued in the other phase (64 KiB per slab)")) return 1;
     }
     return 0;
 }
