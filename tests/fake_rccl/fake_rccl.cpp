@@ -16,6 +16,7 @@ static std::mutex g_mu;
 static std::vector<Call> g_pending;
 static int g_depth = 0;
 static long long g_allgathers = 0;
+static long long g_fail_at = -1;                 // nwknn_test_transport_fail_call(n): the n-th ncclAllGather from now fails once (error-path tests)
 
 static size_t elem_bytes(ncclDataType_t t)
 {
@@ -71,13 +72,16 @@ ncclResult_t ncclGroupEnd()
     std::lock_guard<std::mutex> l(g_mu);
     if (g_depth <= 0) return ncclInvalidUsage;
     if (--g_depth > 0) return ncclSuccess;
-    return flush_locked();
+    const ncclResult_t r = flush_locked();
+    g_pending.clear();
+    return r;
 }
 
 ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataType_t dt, ncclComm_t comm, hipStream_t stream)
 {
     std::lock_guard<std::mutex> l(g_mu);
     const FakeComm* c = (const FakeComm*)comm;
+    if (g_fail_at > 0 && --g_fail_at == 0) { g_fail_at = -1; return ncclInternalError; }
     g_pending.push_back(Call{send, recv, count * elem_bytes(dt), c->rank, c->n, stream});
     ++g_allgathers;
     if (g_depth == 0) return c->n == 1 ? flush_locked() : ncclInvalidUsage;       // several ranks in one process must be grouped
@@ -85,5 +89,8 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
 }
 
 long long nwknn_test_transport_allgather_calls() { return g_allgathers; }
+void nwknn_test_transport_fail_call(long long n) { std::lock_guard<std::mutex> l(g_mu); g_fail_at = n; }
+int nwknn_test_transport_group_depth() { std::lock_guard<std::mutex> l(g_mu); return g_depth; }
+long long nwknn_test_transport_pending() { std::lock_guard<std::mutex> l(g_mu); return (long long)g_pending.size(); }
 
 }  // extern "C"
