@@ -86,6 +86,9 @@ __global__ __launch_bounds__(256) void nwk_prep_tiled_kernel(const TIN* __restri
 #ifndef PREP_ALIAS
 #define PREP_ALIAS 1
 #endif
+#ifndef PREP_NT
+#define PREP_NT 0                                         // build-time A/B: 1 = non-temporal stores of the prepared rows, 2 = non-temporal loads of the raw rows too
+#endif
     __shared__ __attribute__((aligned(16))) char tile_in[256 * PITCH];
 #if PREP_ALIAS
     char* const tile_out = tile_in;
@@ -105,8 +108,10 @@ __global__ __launch_bounds__(256) void nwk_prep_tiled_kernel(const TIN* __restri
         for (int pass = 0; pass < SEGS; ++pass) {
             const int row = pass * RPP + (tid / SEGS), seg = tid % SEGS;
             v[pass] = (u32x4){0u, 0u, 0u, 0u};
-            if (k0 < dp && r0 + row < rows && k0 + seg * EIN < d)
-                v[pass] = *(const u32x4*)((const char*)raw + (size_t)(r0 + row) * in_row_bytes + (size_t)k0 * sizeof(TIN) + seg * 16);
+            if (k0 < dp && r0 + row < rows && k0 + seg * EIN < d) {
+                const u32x4* src = (const u32x4*)((const char*)raw + (size_t)(r0 + row) * in_row_bytes + (size_t)k0 * sizeof(TIN) + seg * 16);
+                v[pass] = PREP_NT >= 2 ? __builtin_nontemporal_load(src) : *src;
+            }
         }
     };
     fetch(0);
@@ -164,9 +169,11 @@ __global__ __launch_bounds__(256) void nwk_prep_tiled_kernel(const TIN* __restri
         for (int pass = 0; pass < OP; ++pass) {
             const int idx = pass * 256 + tid;
             const int row = idx / OP, seg = idx % OP;
-            if (r0 + row < rows_pad)
-                *(u32x4*)((char*)prepared + (size_t)(r0 + row) * out_row_bytes + (size_t)k0 * OES + seg * 16) =
-                    *(const u32x4*)(tile_out + row * PITCH + seg * 16);
+            if (r0 + row < rows_pad) {
+                u32x4* dst = (u32x4*)((char*)prepared + (size_t)(r0 + row) * out_row_bytes + (size_t)k0 * OES + seg * 16);
+                const u32x4 val = *(const u32x4*)(tile_out + row * PITCH + seg * 16);
+                if (PREP_NT >= 1) __builtin_nontemporal_store(val, dst); else *dst = val;
+            }
         }
 #if PREP_ALIAS
         __syncthreads();                                  // the tile has been read out: the next step may overwrite it
