@@ -517,10 +517,12 @@ def main_inlib(args):
     from neighborhoodwatch_amd import KnnEngine, ShardedKnnEngine
     n = args.gpus
     have = torch.cuda.device_count()
-    virtual = have < n and bool(os.environ.get("NWKNN_RCCL_LIBRARY"))          # rehearsal: a stand-in transport whose ranks share GPUs (tests/fake_rccl)
+    # rehearsal: a stand-in transport whose ranks share GPUs (tests/fake_rccl) under a DEVELOPER build of the library (NWKNN_LIB_PATH =
+    # ab/libnwknn_devcomm.so, `python -m neighborhoodwatch_amd.build --dev-comm`); the shipped library refuses a GPU listed twice
+    virtual = have < n and bool(os.environ.get("NWKNN_RCCL_LIBRARY")) and bool(os.environ.get("NWKNN_LIB_PATH"))
     if have < n and not virtual:
         raise SystemExit(f"--gpus {n} --collective inlib needs {n} GPUs, this node shows {have} "
-                         "(NWKNN_RCCL_LIBRARY=<tests/fake_rccl build> rehearses the N-device path on fewer)")
+                         "(NWKNN_RCCL_LIBRARY=<tests/fake_rccl build> with NWKNN_LIB_PATH=ab/libnwknn_devcomm.so rehearses the N-device path on fewer)")
     dev_list = [g % max(have, 1) for g in range(n)]
     Q, B, d, k, metric, dtype, desc = WORKLOADS[args.workload]
     if metric == "maxsim":
@@ -569,7 +571,7 @@ def main_inlib(args):
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                          "kernel": "per-device rate: tile FLOPs summed over the devices / tile-kernel time summed over the devices"},
             "collective": {"kind": "in-library (C ABI nwknn_search_sharded: one process, N GPUs, ncclCommInitAll)",
-                           "backend": "REHEARSAL: stand-in transport, virtual devices sharing GPUs (NWKNN_RCCL_LIBRARY)" if virtual else "rccl",
+                           "backend": "REHEARSAL: stand-in transport, virtual devices sharing GPUs (NWKNN_RCCL_LIBRARY + developer build of the library)" if virtual else "rccl",
                            "search_ms": agg["search_ms"] / args.steps, "allgather_ms": agg["allgather_ms"] / args.steps,
                            "merge_ms": agg["merge_ms"] / args.steps, "allgather_bytes_per_rank": n * Q * k * 12,
                            "timing": "per step, HIP events, maxima over the devices (nwknn_comm_stats)"}}

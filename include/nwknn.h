@@ -187,7 +187,8 @@ typedef struct nwknn_comm_stats {
     double tile_flops, tile_ms;           /* sums over the devices (option "profile"): tile_flops / tile_ms = per-GPU kernel rate */
 } nwknn_comm_stats;
 /* An engine handle + an RCCL communicator per listed device (ncclCommInitAll: all ranks live in this process).  devices: distinct HIP
- * device ordinals, all gfx950.  n_dev = 1 is valid (the exchange is then a copy) and gives the result of nwknn_search. */
+ * device ordinals, all gfx950 (a device listed twice is refused: one shard per GPU, whatever transport NWKNN_RCCL_LIBRARY names).  n_dev = 1
+ * is valid (the exchange is then a copy) and gives the result of nwknn_search. */
 int nwknn_comm_create(nwknn_comm_handle* out, const int* devices, int n_dev);
 int nwknn_comm_destroy(nwknn_comm_handle c);
 int nwknn_comm_device_count(nwknn_comm_handle c);
@@ -208,8 +209,10 @@ int nwknn_comm_get_stats(nwknn_comm_handle c, nwknn_comm_stats* out);
 /* The exchange's merge step for partial lists the CALLER gathered (another transport, the partial files of merge.py:56-101, a test):
  * dists / idx are HOST arrays [n_lists][nq][k] (idx < 0 marks an empty slot).  The query rows are cut into n_slices contiguous slices the
  * way nwknn_search_sharded cuts them over its devices; slice s is merged on device s mod N of the communicator straight from the lists'
- * own stride, and more than 4096 (list, rank) entries per query are folded in two levels -- the code path of a multi-device search,
- * reachable with any number of lists on any number of devices.  Writes the k best by (distance, index) to HOST out_dist / out_idx [nq][k]. */
+ * own stride, and more than 4096 (list, rank) entries per query are folded in groups of lists, level after level until one merge takes
+ * the rest -- the code path of a multi-device search, reachable with any number of lists on any number of devices.  Limit (checked before
+ * anything is uploaded or searched, here and in the *_sharded calls): n_lists * k > 4096 needs k <= 2048, because a fold level merges at
+ * least two lists of k entries in one 4096-entry sort.  Writes the k best by (distance, index) to HOST out_dist / out_idx [nq][k]. */
 int nwknn_comm_merge_lists(nwknn_comm_handle c, const float* dists_host, const int64_t* idx_host, int32_t n_lists, int64_t nq, int32_t k,
                            int32_t n_slices, int descending, float* out_dist, int64_t* out_idx);
 /* (descending != 0: the values are SCORES, higher first, ties to the lower id -- the order of nwknn_maxsim_search.) */

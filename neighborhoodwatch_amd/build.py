@@ -64,6 +64,28 @@ def build_dev(verbose: bool = False) -> Path:
     return out
 
 
+def build_dev_comm(verbose: bool = False) -> Path:
+    """ab/libnwknn_devcomm.so = the product's objects with ONE file, nwknn_comm.cpp, recompiled under -DNWKNN_DEV: the only build in which a
+    collective transport that announces itself as a test stand-in (tests/fake_rccl) may place several shards on one GPU.  The virtual-device
+    tests and the bench rehearsal load it through NWKNN_LIB_PATH; the shipped library refuses a device listed twice whatever is loaded."""
+    build(force=False, verbose=verbose)
+    hipcc = hipcc_path()
+    out_dir = PKG.parent / "ab"
+    out_dir.mkdir(exist_ok=True)
+    out = out_dir / "libnwknn_devcomm.so"
+    src = CSRC / "nwknn_comm.cpp"
+    if not _stale(out, [OUT, src, *HEADERS, Path(__file__)]):
+        return out
+    obj = out_dir / "nwknn_comm_dev.o"
+    cmd = [hipcc, *FLAGS[:-2], "-DNWKNN_DEV", "-x", "hip", "-c", str(src), "-o", str(obj)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, capture_output=True)
+    objs = [str(_obj(s)) for s in SOURCES if s.name != "nwknn_comm.cpp"] + [str(obj)]
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(out)], check=True, capture_output=True)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return OUT
@@ -93,4 +115,4 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
 
 if __name__ == "__main__":
-    print(build_dev(verbose=True) if "--dev" in sys.argv else build(force="--force" in sys.argv, verbose=True))
+    print(build_dev(verbose=True) if "--dev" in sys.argv else build_dev_comm(verbose=True) if "--dev-comm" in sys.argv else build(force="--force" in sys.argv, verbose=True))

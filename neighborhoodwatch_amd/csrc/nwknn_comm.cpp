@@ -60,7 +60,9 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*GetVersion)(int*) = nullptr;
-    bool shares_one_device = false;               // the loaded transport says its ranks may live on one GPU (tests/fake_rccl: not RCCL)
+#ifdef NWKNN_DEV
+    bool shares_one_device = false;               // developer builds only: the loaded transport says its ranks may live on one GPU (tests/fake_rccl: not RCCL)
+#endif
 };
 
 static int load_rccl(Rccl* r)
@@ -71,8 +73,9 @@ static int load_rccl(Rccl* r)
         tried = true;
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         void* lib = nullptr;
-        // NWKNN_RCCL_LIBRARY: a site's own build of RCCL, by path (the test suite points it at tests/fake_rccl, a stand-in whose ranks share
-        // one GPU, to execute the N > 1 orchestration on a one-GPU box)
+        // NWKNN_RCCL_LIBRARY: a site's own build of RCCL, by path.  (The test suite points a DEVELOPER build of this library -- -DNWKNN_DEV,
+        // ab/libnwknn_devcomm.so -- at tests/fake_rccl, a stand-in whose ranks share one GPU, to execute the N > 1 orchestration on a one-GPU
+        // box; the shipped library has no such relaxation: one shard per GPU, whatever transport is loaded.)
         const char* forced = getenv("NWKNN_RCCL_LIBRARY");
         if (forced && *forced) {
             lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
@@ -90,7 +93,11 @@ static int load_rccl(Rccl* r)
             cached.GroupEnd = (decltype(cached.GroupEnd))dlsym(lib, "ncclGroupEnd");
             cached.GetErrorString = (decltype(cached.GetErrorString))dlsym(lib, "ncclGetErrorString");
             cached.GetVersion = (decltype(cached.GetVersion))dlsym(lib, "ncclGetVersion");
+#ifdef NWKNN_DEV
             cached.shares_one_device = dlsym(lib, "nwknn_test_transport_shares_one_device") != nullptr;
+            if (cached.shares_one_device)
+                fprintf(stderr, "libnwknn (DEVELOPER build): the loaded transport is a TEST stand-in whose ranks share one GPU; the one-shard-per-GPU guard is off\n");
+#endif
         }
     }
     if (!cached.lib) return cfail(NWKNN_EHIP, "RCCL is not available: dlopen(librccl.so.1) failed: %s", dlerror());
@@ -203,14 +210,18 @@ extern "C" int nwknn_comm_create(nwknn_comm_handle* out, const int* devices, int
     for (int a = 0; a < n_dev; ++a)
         for (int b = a + 1; b < n_dev; ++b)
             if (devices[a] == devices[b]) { twice = true; dup = devices[a]; }
-    if (twice && !(getenv("NWKNN_RCCL_LIBRARY") && *getenv("NWKNN_RCCL_LIBRARY")))          // refused before anything is loaded (RCCL refuses it too)
+#ifndef NWKNN_DEV
+    if (twice)                                                        // refused before anything is loaded (RCCL refuses it too)
         return cfail(NWKNN_EINVAL, "nwknn_comm_create: device %d listed twice (one shard per GPU)", dup);
+#endif
     nwknn_comm* c = new (std::nothrow) nwknn_comm();
     if (!c) return cfail(NWKNN_ENOMEM, "out of host memory");
     memset(&c->stats, 0, sizeof c->stats);
     int rc = load_rccl(&c->rccl);
     if (rc != NWKNN_OK) { delete c; return rc; }
+#ifdef NWKNN_DEV
     if (twice && !c->rccl.shares_one_device) { delete c; return cfail(NWKNN_EINVAL, "nwknn_comm_create: device %d listed twice (one shard per GPU)", dup); }
+#endif
     try { c->dev.resize((size_t)n_dev); } catch (...) { delete c; return cfail(NWKNN_ENOMEM, "out of host memory"); }
     auto fail_with = [&](int code) { (void)nwknn_comm_destroy(c); return code; };
     for (int g = 0; g < n_dev; ++g) {
@@ -292,27 +303,51 @@ extern "C" int nwknn_comm_generate_base(nwknn_comm_handle c, uint64_t seed, int6
 }
 
 // device g: the k best of its query slice over the N gathered lists.  One merge sorts at most 4096 (list, rank) entries per query in
-// LDS; more (8 shards x k = 1000) are folded in groups of lists first, which gives the same k smallest.
+// LDS; more (8 shards x k = 1000, 8 x 2048, 64 lists x 1000) are folded in groups of lists, level after level until one merge takes what
+// is left -- the same k smallest, as KnnEngine.merge folds in the torch flavour.  A level needs at least two lists per merge: k <= 2048.
+static int merge_levels(int n, int k)                                 // 0: one merge; >= 1: that many group levels before it; -1: cannot fold
+{
+    if ((long long)n * k <= 4096) return 0;
+    const int per = 4096 / k;
+    if (per < 2) return -1;
+    int levels = 0;
+    while ((long long)n * k > 4096) { n = (n + per - 1) / per; ++levels; }
+    return levels;
+}
+
+static int check_merge_plan(const char* what, int n, int k)
+{
+    if (merge_levels(n, k) >= 0) return NWKNN_OK;
+    return cfail(NWKNN_EINVAL, "%s: %d lists of k=%d cannot be merged: more than 4096 entries per query need k <= 2048 (a fold level merges at least two lists)", what, n, k);
+}
+
 static int merge_slice(nwknn_comm* c, DevPart& p, int n, long long nq, int k, long long qlo, long long qn, int descending = 0)
 {
+    (void)c;
     if (qn <= 0) return NWKNN_OK;
-    const long long stride = nq * k;                                  // entries between two gathered lists
     const float* src_d = p.all_d + qlo * k;
     const long long* src_i = p.all_i + qlo * k;
-    if ((long long)n * k <= 4096) {
-        hipError_t e = nwk_launch_merge(p.stream, src_d, src_i, n, stride, qn, k, k, p.out_d, p.out_i, descending);
-        if (e != hipSuccess) return cfail(NWKNN_EHIP, "merge launch failed: %s", hipGetErrorString(e));
-        return NWKNN_OK;
+    long long stride = nq * k;                                        // entries between two lists of the current level
+    if (merge_levels(n, k) < 0) return check_merge_plan("merge", n, k);
+    const int per = std::max(2, 4096 / k);
+    // fold buffer: region 0 takes the groups of level 1, region 1 those of level 2, region 0 again those of level 3 (level 1 is consumed by then) ...
+    const int g1 = (n + per - 1) / per;
+    float* reg_d[2] = {p.grp_d, p.grp_d + (long long)g1 * qn * k};
+    long long* reg_i[2] = {p.grp_i, p.grp_i + (long long)g1 * qn * k};
+    int level = 0;
+    while ((long long)n * k > 4096) {
+        const int groups = (n + per - 1) / per;
+        float* dst_d = reg_d[level & 1];
+        long long* dst_i = reg_i[level & 1];
+        for (int gidx = 0; gidx < groups; ++gidx) {
+            const int l0 = gidx * per, ln = std::min(per, n - l0);
+            hipError_t e = nwk_launch_merge(p.stream, src_d + (long long)l0 * stride, src_i + (long long)l0 * stride, ln, stride, qn, k, k,
+                                            dst_d + (long long)gidx * qn * k, dst_i + (long long)gidx * qn * k, descending);
+            if (e != hipSuccess) return cfail(NWKNN_EHIP, "merge launch failed: %s", hipGetErrorString(e));
+        }
+        src_d = dst_d; src_i = dst_i; stride = qn * k; n = groups; ++level;
     }
-    const int per = std::max(1, 4096 / k), groups = (n + per - 1) / per;
-    if ((long long)groups * k > 4096) return cfail(NWKNN_EINVAL, "nwknn_search_sharded: %d devices x k=%d exceeds the two-level merge", n, k);
-    for (int gidx = 0; gidx < groups; ++gidx) {
-        const int l0 = gidx * per, ln = std::min(per, n - l0);
-        hipError_t e = nwk_launch_merge(p.stream, src_d + (long long)l0 * stride, src_i + (long long)l0 * stride, ln, stride, qn, k, k,
-                                        p.grp_d + (long long)gidx * qn * k, p.grp_i + (long long)gidx * qn * k, descending);
-        if (e != hipSuccess) return cfail(NWKNN_EHIP, "merge launch failed: %s", hipGetErrorString(e));
-    }
-    hipError_t e = nwk_launch_merge(p.stream, p.grp_d, p.grp_i, groups, qn * k, qn, k, k, p.out_d, p.out_i, descending);
+    hipError_t e = nwk_launch_merge(p.stream, src_d, src_i, n, stride, qn, k, k, p.out_d, p.out_i, descending);
     if (e != hipSuccess) return cfail(NWKNN_EHIP, "merge launch failed: %s", hipGetErrorString(e));
     return NWKNN_OK;
 }
@@ -328,8 +363,9 @@ static int ensure_exchange_buffers(DevPart& p, int n_lists, long long nq, int k,
         (rc = p.b_out_i.ensure(slice * 8)))
         return rc;
     if ((long long)n_lists * k > 4096) {
-        const int per = std::max(1, 4096 / k);
-        const size_t grp = slice * (size_t)((n_lists + per - 1) / per);
+        const int per = std::max(2, 4096 / k);
+        const size_t g1 = (size_t)((n_lists + per - 1) / per), g2 = (g1 + per - 1) / per;      // the two regions merge_slice alternates between
+        const size_t grp = slice * (g1 + g2);
         if ((rc = p.b_grp_d.ensure(grp * 4)) || (rc = p.b_grp_i.ensure(grp * 8))) return rc;
     }
     p.part_d = (float*)p.b_part_d.p; p.part_i = (long long*)p.b_part_i.p;
@@ -376,6 +412,7 @@ extern "C" int nwknn_comm_merge_lists(nwknn_comm_handle c, const float* dists_ho
     if (!c || !dists_host || !idx_host || !out_dist || !out_idx) return cfail(NWKNN_EINVAL, "nwknn_comm_merge_lists: null argument");
     if (n_lists <= 0 || nq <= 0 || k <= 0 || n_slices <= 0 || n_slices > 4096) return cfail(NWKNN_EINVAL, "nwknn_comm_merge_lists: n_lists, nq, k, n_slices must be positive");
     if (k > 4096) return cfail(NWKNN_EINVAL, "nwknn_comm_merge_lists: k=%d exceeds 4096 entries per merge", k);
+    if (check_merge_plan("nwknn_comm_merge_lists", n_lists, k) != NWKNN_OK) return NWKNN_EINVAL;      // before anything is uploaded
     const int n = (int)c->dev.size();
     const size_t total = (size_t)n_lists * nq * k;
     int rc = NWKNN_OK;
@@ -489,7 +526,9 @@ extern "C" int nwknn_search_sharded(nwknn_comm_handle c, const void* queries_hos
         if (k <= 0 || k > p.row_hi - p.row_lo)
             return cfail(NWKNN_EINVAL, "nwknn_search_sharded: k=%d must satisfy 0 < k <= %lld rows of the smallest shard (cu_knn.py:177-178,237)", k,
                          (long long)(p.row_hi - p.row_lo));
-    int rc = prepare_exchange(c, nq, k);
+    int rc = check_merge_plan("nwknn_search_sharded", (int)c->dev.size(), k);      // before any shard is searched
+    if (rc != NWKNN_OK) return rc;
+    rc = prepare_exchange(c, nq, k);
     if (rc != NWKNN_OK) return rc;
     // 1. every device searches its shard; ids are global (index_offset = first row of the shard: "+ batch_offset", cu_knn.py:273)
     rc = on_every_device(c, [&](int g) {
@@ -530,7 +569,9 @@ extern "C" int nwknn_maxsim_search_sharded(nwknn_comm_handle c, const void* quer
         if (k <= 0 || k > p.row_hi - p.row_lo)
             return cfail(NWKNN_EINVAL, "nwknn_maxsim_search_sharded: k=%d must satisfy 0 < k <= %lld documents of the smallest shard", k,
                          (long long)(p.row_hi - p.row_lo));
-    int rc = prepare_exchange(c, n_queries, k);
+    int rc = check_merge_plan("nwknn_maxsim_search_sharded", (int)c->dev.size(), k);
+    if (rc != NWKNN_OK) return rc;
+    rc = prepare_exchange(c, n_queries, k);
     if (rc != NWKNN_OK) return rc;
     rc = on_every_device(c, [&](int g) {
         DevPart& p = c->dev[g];

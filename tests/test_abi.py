@@ -96,6 +96,25 @@ def test_wrong_result_switches_are_not_in_the_shipped_library():
         assert b"developer builds" in L.nwknn_last_error(), (name, L.nwknn_last_error())
     assert L.nwknn_set_option(None, b"pre_eps_pct", 100) == -1 and b"null handle" in L.nwknn_last_error()   # a legal value gets as far as the handle check
     assert not any("NWKNN_DEV" in f for f in build.FLAGS)
+    # ... and neither is the test seam of the collective: the marker symbol by which a stand-in transport (tests/fake_rccl) may place several
+    # shards on one GPU is looked up by developer builds of nwknn_comm.cpp only (ab/libnwknn_devcomm.so), never by the product
+    blob = _lib.LIB_PATH.read_bytes()
+    assert b"nwknn_test_transport_shares_one_device" not in blob and b"TEST stand-in" not in blob
+    assert b"NWKNN_RCCL_LIBRARY" in blob                                    # a site's own RCCL by path stays
+    # a device listed twice is refused before anything is loaded, whatever NWKNN_RCCL_LIBRARY says (no GPU needed: the check comes first)
+    import ctypes as _c
+    h = _c.c_void_p()
+    devs = (_c.c_int * 2)(0, 0)
+    import os as _os
+    old = _os.environ.get("NWKNN_RCCL_LIBRARY")
+    _os.environ["NWKNN_RCCL_LIBRARY"] = "/nonexistent/libfake_rccl.so"
+    try:
+        assert L.nwknn_comm_create(_c.byref(h), devs, 2) == -1 and b"listed twice" in L.nwknn_last_error()
+    finally:
+        if old is None:
+            _os.environ.pop("NWKNN_RCCL_LIBRARY", None)
+        else:
+            _os.environ["NWKNN_RCCL_LIBRARY"] = old
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

@@ -53,10 +53,11 @@ def test_rccl_allgather_branch_runs_on_the_gpu_box(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_lists,k,n_slices", [(8, 1000, 3), (5, 100, 4), (64, 64, 7), (2, 10, 1), (3, 33, 50)])
+@pytest.mark.parametrize("n_lists,k,n_slices", [(8, 1000, 3), (5, 100, 4), (64, 64, 7), (2, 10, 1), (3, 33, 50), (8, 2048, 3), (64, 1000, 5)])
 def test_the_sliced_and_two_level_merge_of_a_multi_device_search(oracle, n_lists, k, n_slices):
     """What devices 1..N-1 of nwknn_search_sharded do has never run on hardware (one-GPU boxes): a query slice that does not start at row
-    0, lists whose stride is not the slice's own size, and -- from 4096 (list, rank) entries per query on -- the two-level fold.  The same
+    0, lists whose stride is not the slice's own size, and -- from 4096 (list, rank) entries per query on -- the fold in groups of lists,
+    level after level (8 x 2048: groups of two, three levels; 64 x 1000: groups of four, three levels).  The same
     code (merge_slice behind nwknn_comm_merge_lists) is driven here on one device with caller-built lists: random partial lists with
     cross-list equal distances (ties go to the lower index), empty slots, more slices than rows in one case; checked against the oracle's
     merge (= the reference's fold, tests/golden/merge_*.npz) bit for bit."""
@@ -91,7 +92,7 @@ from oracle import cpu_oracle as orc                      # the checker (tests m
 out = {}
 base, queries = orc.gen(0xE1, 0, 20011, 72), orc.gen(0xE2, 0, 203, 72)
 base[5000:5040] = base[15000:15040]                       # equal rows on different shards: cross-shard ties go to the lower global id
-for n_dev, k in ((3, 50), (5, 1000), (8, 100), (2, 7)):
+for n_dev, k in ((3, 50), (5, 1000), (8, 100), (2, 7), (8, 2048)):
     with ShardedKnnEngine([0] * n_dev, profile=True) as eng:
         assert len(eng.devices) == n_dev
         eng.set_base(base)                                # shard g = rows [B g / N, B (g+1) / N) on virtual device g
@@ -153,8 +154,9 @@ def test_n_device_path_of_the_c_abi_collective_on_virtual_devices(tmp_path):
     that all live on the box's one GPU: a host thread per device, uneven shard bounds, global ids by index offset, the all-gather's
     [N][Q][k] layout, every device merging ITS slice of the queries (two-level at 5 x 1000), the per-slice copies into the caller's arrays,
     the pre-screened and the exact-fp16 engines under it, MaxSim's descending merge -- everything real except the transport:
-    NWKNN_RCCL_LIBRARY points the library at tests/fake_rccl (ncclAllGather = N device-to-device copies per rank, and a marker that
-    lets one GPU be listed N times, which real RCCL refuses).  Results must be the single-engine / oracle bits."""
+    NWKNN_RCCL_LIBRARY points a DEVELOPER build of the library (ab/libnwknn_devcomm.so: nwknn_comm.cpp under -DNWKNN_DEV, everything else the
+    product's objects) at tests/fake_rccl (ncclAllGather = N device-to-device copies per rank, and a marker that lets one GPU be listed N
+    times, which real RCCL and the shipped library refuse).  Results must be the single-engine / oracle bits."""
     import json
     shim = tmp_path / "libfake_rccl.so"
     hipcc = "/opt/rocm/bin/hipcc"
@@ -162,13 +164,15 @@ def test_n_device_path_of_the_c_abi_collective_on_virtual_devices(tmp_path):
                    check=True, capture_output=True, timeout=300)
     script = tmp_path / "virtual_devices.py"
     script.write_text(VIRTUAL)
-    env = dict(os.environ, NW_ROOT=str(ROOT), NWKNN_RCCL_LIBRARY=str(shim), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from neighborhoodwatch_amd import build
+    env = dict(os.environ, NW_ROOT=str(ROOT), NWKNN_RCCL_LIBRARY=str(shim), NWKNN_LIB_PATH=str(build.build_dev_comm()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "NWKNN_RCCL_LIBRARY=" in r.stderr and "loaded as the collective transport" in r.stderr          # never silent
+    assert "DEVELOPER build" in r.stderr and "TEST stand-in" in r.stderr
     line = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")][-1]
-    # two all-gathers (distances, indices) per virtual device and search: (3 + 3 + 5 + 8 + 2) + 4 + 3 devices = 28 device-searches
-    assert line["ok"] is True and line["allgather_calls"] == 2 * 28
+    # two all-gathers (distances, indices) per virtual device and search: (3 + 3 + 5 + 8 + 2 + 8) + 4 + 3 devices = 36 device-searches
+    assert line["ok"] is True and line["allgather_calls"] == 2 * 36
 
 
 @pytest.mark.gpu
@@ -179,6 +183,22 @@ def test_real_rccl_still_refuses_a_device_listed_twice():
 
 
 @pytest.mark.gpu
+def test_the_shipped_library_refuses_a_device_listed_twice_under_the_stand_in_transport_too(tmp_path):
+    """Round 4's library relaxed the one-shard-per-GPU guard whenever the transport named by NWKNN_RCCL_LIBRARY carried a marker symbol: test
+    scaffolding in the shipped code.  The relaxation now exists under -DNWKNN_DEV only; the product refuses before it loads anything."""
+    shim = tmp_path / "libfake_rccl.so"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-shared", "-fPIC", "-x", "hip", "--offload-arch=gfx950", str(ROOT / "tests" / "fake_rccl" / "fake_rccl.cpp"),
+                    "-o", str(shim)], check=True, capture_output=True, timeout=300)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from neighborhoodwatch_amd import ShardedKnnEngine\n"
+            "try:\n    ShardedKnnEngine([0, 0])\nexcept ValueError as e:\n    print('REFUSED', e)\n") % str(ROOT)
+    env = dict(os.environ, NWKNN_RCCL_LIBRARY=str(shim), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("NWKNN_LIB_PATH", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "REFUSED" in r.stdout and "listed twice" in r.stdout, (r.stdout[-800:], r.stderr[-800:])
+
+
+@pytest.mark.gpu
 def test_bench_in_library_collective_rehearsed_on_four_virtual_devices(tmp_path):
     """`bench.py --gpus 4 --collective inlib` on the one-GPU box: the line a scaling run would produce through the C ABI's collective, with
     the stand-in transport (labelled REHEARSAL in the line), verified against a single-engine search."""
@@ -186,7 +206,8 @@ def test_bench_in_library_collective_rehearsed_on_four_virtual_devices(tmp_path)
     shim = tmp_path / "libfake_rccl.so"
     subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-shared", "-fPIC", "-x", "hip", "--offload-arch=gfx950", str(ROOT / "tests" / "fake_rccl" / "fake_rccl.cpp"),
                     "-o", str(shim)], check=True, capture_output=True, timeout=300)
-    env = dict(os.environ, NWKNN_RCCL_LIBRARY=str(shim), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from neighborhoodwatch_amd import build
+    env = dict(os.environ, NWKNN_RCCL_LIBRARY=str(shim), NWKNN_LIB_PATH=str(build.build_dev_comm()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(var, None)
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--collective", "inlib", "--workload", "dev", "--steps", "2", "--warmup", "1", "--verify"],
