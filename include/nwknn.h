@@ -112,8 +112,10 @@ int nwknn_set_stream(nwknn_handle h, void* hip_stream);
  * "upload_slab_mib" (slab size of that pipeline, default 128),
  * "pre_eps_pct" (>= 100: percent of the proven pre-screen error bound to apply; larger = more pairs rescored, same result),
  * "pre_check_ppm" (1..1000000, default 1000000: the invariant |estimate - exact| <= bound of nwknn_stats is checked against this many
- * millionths of the bound; a violation sends the search down its fallback, whose result is the same bits -- so a small value only costs
- * time; tests use it to drive the fallback),
+ * millionths of the bound ON THE FIRST ATTEMPT of a search; a violation discards the attempt and sends the search down its fallback --
+ * fp32 data: the direct fp32 kernel; fp16 data (exact fp16 mode): the same search under a 16x wider bound, held against the whole of that
+ * bound -- whose result is the same bits, so a small value only costs time; tests use it to drive the fallback.  A deviation that exceeds
+ * even 16^3 x the proven bound -- no summation order of the products can produce one -- ends in NWKNN_EHIP, never in a wrong result),
  * MaxSim pre-screen tile kernel, d <= 128: "ms_strip" (document tiles a workgroup of the ring kernel walks: 0 = auto, 1 = the any-d
  * kernel), "ms_rescore_valu" (1: rescoring on the vector pipes).
  * No option changes a result: every switch that does (timing ablations, in-kernel stamps, a shrunken error bound) exists only in

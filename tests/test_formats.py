@@ -80,3 +80,12 @@ def test_generate_output_files_and_validator(tmp_path, oracle):
     bad = ptf.read_vectors(data_dir, dv).copy(); bad[5, 2] += 0.01
     ptf.write_ivec_fvec_from_dataframe(data_dir, "m", dv, bad, "f", 10)
     assert ptf.validate_files_v0(data_dir, qv, bv, iv, dv) == 1
+    import torch
+    if not torch.cuda.is_available():
+        # a GPU check that cannot run (here: no GPU behind the ordinal; on a GPU box: out of memory, device busy) must not take the
+        # validator down with it -- the reference's would have completed: the host check of record takes the job and says why
+        import io, contextlib
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            assert ptf.validate_files_v0(data_dir, qv, bv, iv, dv, device=0) == 1
+        assert "checking on the host" in out.getvalue()

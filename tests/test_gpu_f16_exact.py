@@ -183,3 +183,11 @@ def test_a_failed_invariant_widens_the_bound_and_keeps_the_bits(oracle, metric, 
         assert st["prescreen"] == 1 and 1 <= st["prescreen_fallbacks"] <= 3 and st["prescreen_violations"] > 0, st
         assert np.array_equal(idx, ri) and _bitwise(dist, rd)
         assert "16x wider bound" in capfd.readouterr().err
+        # the smallest value the option takes used to fail EVERY attempt (16^3 ppm of the bound is still below a healthy MFMA's deviations)
+        # and end in NWKNN_EHIP: a shipped option that turned a correct search into an error.  Attempts after the first are now held
+        # against the whole of their own, 16x wider bound.
+        eng.set_option("pre_check_ppm", 1)
+        dist, idx = eng.search(queries16, 40, metric)
+        st = eng.stats()
+        assert st["prescreen"] == 1 and st["prescreen_fallbacks"] == 1 and st["prescreen_violations"] > 0, st
+        assert np.array_equal(idx, ri) and _bitwise(dist, rd)
