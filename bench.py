@@ -70,7 +70,7 @@ WORKLOADS = {
 }
 # (workload, timed steps, timed steps of its pre-screened leg, queries of the one warm-up step (0: all), estimated wall seconds)
 SECONDARY = (("c4gpu", 1, 0, 50_000, 42), ("refcli", 2, 2, 0, 8), ("c2", 10, 2, 0, 4), ("c3shard", 3, 2, 0, 10))
-SECONDARY_BUDGET_S = 465.0          # wall clock since process start after which no further secondary leg is started (the driver allows 600 s)
+SECONDARY_BUDGET_S = 440.0          # wall clock since process start after which no further secondary leg is started (the driver allows 600 s)
 REF_PUBLISHED = {"knn_stage_s": 103.46, "queries_per_s": 96.7, "tflops": 1.19, "hardware": "1x NVIDIA RTX A5500 Laptop GPU 16 GB",
                  "source": "docs/cli.png (BASELINE.md section 1): kNN stage incl. parquet load, 9 x 9 knn() calls"}
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
@@ -161,7 +161,7 @@ def cpu_baseline(base_dev, queries_dev, k, metric, full_b, flop_budget=0.45e13):
     return out
 
 
-REF_FILES_EST_S = 45               # the file leg of the reference's published run: write a 24.6 GB parquet file, run compute_knn from it
+REF_FILES_EST_S = 75               # the file legs of the reference's published run: write a 24.6 GB parquet file, run compute_knn / compute_knn_ds from it; then a 3 GB file in pyarrow's default encoding
 REF_FILES_BASE_ROWS = 4_000_000
 
 
@@ -174,21 +174,35 @@ def ref_published_block(value_qps, pre):
     return out
 
 
-def ref_cli_through_files(eng, base_rows=REF_FILES_BASE_ROWS, q_rows=10_000, d=1536, k=100):
+FILE_ENCODINGS = {
+    # bench.py's first file leg since round 2: the cheapest bytes to decode
+    "uncompressed": dict(compression="NONE", use_dictionary=False, write_statistics=False),
+    # what the reference's own writer produces: ParquetStreamer opens pq.ParquetWriter(filename, schema) with pyarrow's defaults
+    # (generate_dataset.py:241-242,255-256), i.e. snappy + dictionary pages + statistics; synth.py writes the same way
+    "pyarrow_defaults": {},
+}
+REF_FILES_DEFAULTS_ROWS = 500_000  # rows of the default-encoding leg: pyarrow writes snappy + dictionary at ~0.15 GB/s on one thread (no writer threads in
+                                   # pyarrow 25), so the 4M-row file would take ~170 s to WRITE (not timed, but inside the bench's wall clock)
+
+
+def ref_cli_through_files(eng, base_rows=REF_FILES_BASE_ROWS, q_rows=10_000, d=1536, k=100, encoding="uncompressed", legs=("direct", "prescreened"), via=("compute_knn",)):
     """The reference's published run as its CLI does it: compute_knn(data_dir, ...) from parquet files with one float32 column per
     dimension (cu_knn.py:151-180), load included, then merge_indices_and_distances -- what docs/cli.png times at 103.46 s + 2.02 s.
     The synthetic source files are written first (not timed: the reference's stage 1-2 is not in its figure either), to /dev/shm when it
-    is there (no disk in the picture), 100 000-row row groups, uncompressed."""
+    is there (no disk in the picture), 100 000-row row groups, in the named ENCODING (FILE_ENCODINGS: uncompressed, or pyarrow's defaults
+    as the reference's ParquetStreamer writes).  `via` adds compute_knn_ds (the dataset flavour, cu_knn_ds.py:136-146) over the same files."""
     import shutil
     import tempfile
     import numpy as np
     import pyarrow as pa
     import pyarrow.parquet as pq
     import torch
-    from neighborhoodwatch_amd import cu_knn, merge
+    from neighborhoodwatch_amd import cu_knn, cu_knn_ds, merge
     root = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     tmp = tempfile.mkdtemp(prefix="nwk_refcli_", dir=root)
-    out = {"data_dir": tmp, "base_rows": base_rows, "queries": q_rows, "dim": d, "k": k}
+    out = {"data_dir": tmp, "base_rows": base_rows, "queries": q_rows, "dim": d, "k": k, "encoding": encoding,
+           "encoding_note": ("pyarrow defaults (snappy, dictionary, statistics): what the reference's ParquetStreamer writes, generate_dataset.py:241-242"
+                             if encoding == "pyarrow_defaults" else "compression NONE, no dictionary, no statistics: the cheapest bytes to decode, NOT what the reference writes")}
     try:
         t0 = time.perf_counter()
         names = [f"embedding_{j}" for j in range(d)]
@@ -200,7 +214,7 @@ def ref_cli_through_files(eng, base_rows=REF_FILES_BASE_ROWS, q_rows=10_000, d=1
                 cols = eng.generate(seed, r0, n, d).t().contiguous().cpu().numpy()          # [d, n]: one contiguous array per column
                 t = pa.Table.from_arrays([pa.array(cols[j]) for j in range(d)], names=names)
                 if writer is None:
-                    writer = pq.ParquetWriter(os.path.join(tmp, fname), t.schema, compression="NONE", use_dictionary=False, write_statistics=False)
+                    writer = pq.ParquetWriter(os.path.join(tmp, fname), t.schema, **FILE_ENCODINGS[encoding])
                 writer.write_table(t)
             writer.close()
         write("base.parquet", SEED_BASE, base_rows)
@@ -208,23 +222,43 @@ def ref_cli_through_files(eng, base_rows=REF_FILES_BASE_ROWS, q_rows=10_000, d=1
         torch.cuda.synchronize()
         out["write_s_not_timed"] = time.perf_counter() - t0
         out["file_gb"] = os.path.getsize(os.path.join(tmp, "base.parquet")) / 1e9
-        for label, pre in (("direct", False), ("prescreened", True)):
-            shutil.rmtree(os.path.join(tmp, "partial"), ignore_errors=True)
-            os.makedirs(os.path.join(tmp, "partial"))                    # the CLI creates it (nw_utils.py:67-73)
-            with contextlib.redirect_stdout(sys.stderr):                 # the drivers print progress like the reference; stdout carries the JSON line only
-                t0 = time.perf_counter()
-                cu_knn.compute_knn(tmp, "synthetic", d, "query.parquet", q_rows, "base.parquet", base_rows, mem_tune=True, k=k, prescreen=pre)
-                t1 = time.perf_counter()
-                merge.merge_indices_and_distances(tmp, k)
-                t2 = time.perf_counter()
-            out[label] = {"knn_stage_s": t1 - t0, "merge_s": t2 - t1, "queries_per_s": q_rows / (t1 - t0),
-                          "pairwise_tflops": 2.0 * q_rows * base_rows * d / (t1 - t0) / 1e12,
-                          "vs_reference_knn_stage": REF_PUBLISHED["knn_stage_s"] / (t1 - t0)}
-        out["label"] = "cross-hardware (reference: RTX A5500 laptop GPU); parquet decode + PCIe upload + search + partial files, as the reference's figure"
+        out["float_gb"] = base_rows * d * 4 / 1e9
+        for how in via:
+            for label in legs:
+                pre = label == "prescreened"
+                shutil.rmtree(os.path.join(tmp, "partial"), ignore_errors=True)
+                os.makedirs(os.path.join(tmp, "partial"))                    # the CLI creates it (nw_utils.py:67-73)
+                with contextlib.redirect_stdout(sys.stderr):                 # the drivers print progress like the reference; stdout carries the JSON line only
+                    t0 = time.perf_counter()
+                    if how == "compute_knn":
+                        cu_knn.compute_knn(tmp, "synthetic", d, "query.parquet", q_rows, "base.parquet", base_rows, mem_tune=True, k=k, prescreen=pre)
+                    else:
+                        cu_knn_ds.compute_knn_ds(tmp, d, "query.parquet", q_rows, "base.parquet", base_rows, mem_tune=True, k=k, prescreen=pre)
+                    t1 = time.perf_counter()
+                    merge.merge_indices_and_distances(tmp, k)
+                    t2 = time.perf_counter()
+                key = label if how == "compute_knn" else f"{label}_compute_knn_ds"
+                out[key] = {"knn_stage_s": t1 - t0, "merge_s": t2 - t1, "queries_per_s": q_rows / (t1 - t0),
+                            "pairwise_tflops": 2.0 * q_rows * base_rows * d / (t1 - t0) / 1e12,
+                            "decode_upload_gb_per_s": out["float_gb"] / (t1 - t0)}
+                if base_rows == REF_FILES_BASE_ROWS:
+                    out[key]["vs_reference_knn_stage"] = REF_PUBLISHED["knn_stage_s"] / (t1 - t0)
+        out["label"] = ("cross-hardware (reference: RTX A5500 laptop GPU) AND, unless encoding says pyarrow_defaults, cross-encoding; parquet decode + PCIe "
+                        "upload + search + partial files, as the reference's figure; row groups are decoded by reader threads and handed to the GPU as they "
+                        "arrive (nwknn_base_begin / _append_column_chunks / _end)")
     except Exception as e:
         out["error"] = f"{type(e).__name__}: {e}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def ref_cli_file_legs(eng, base_rows):
+    """Both file legs of the refcli workload: the reference's size on uncompressed files (both engines' paths, compute_knn and compute_knn_ds)
+    and a smaller file in the encoding the reference's own writer produces."""
+    out = ref_cli_through_files(eng, base_rows, via=("compute_knn", "compute_knn_ds"))
+    small = min(base_rows, REF_FILES_DEFAULTS_ROWS)
+    out["reference_encoding"] = ref_cli_through_files(eng, small, encoding="pyarrow_defaults", legs=("direct",))
     return out
 
 
@@ -643,7 +677,7 @@ def main():
     if world == 1 and args.workload == "refcli" and rank == 0:
         line["vs_reference_published"] = ref_published_block(line["value"], line.get("exact_prescreen"))
         if args.files:
-            line["through_files"] = ref_cli_through_files(b.eng, args.files_base_rows)
+            line["through_files"] = ref_cli_file_legs(b.eng, args.files_base_rows)
     if world == 1 and args.workload == "c3" and not args.no_secondary and not args.opt and not args.metric:
         sec = {}
         for name, s_steps, s_pre, s_warm_q, est_s in SECONDARY:
@@ -657,7 +691,7 @@ def main():
                 if name == "refcli":
                     s_out["vs_reference_published"] = ref_published_block(s_out["value"], s_out.get("exact_prescreen"))
                     if time.perf_counter() - T_PROCESS_START + REF_FILES_EST_S <= SECONDARY_BUDGET_S:
-                        s_out["through_files"] = ref_cli_through_files(b.eng, args.files_base_rows)
+                        s_out["through_files"] = ref_cli_file_legs(b.eng, args.files_base_rows)
                     else:
                         s_out["through_files"] = {"skipped": f"time box ({REF_FILES_EST_S} s needed); run `python bench.py --workload refcli --files`"}
                 s_out["wall_s"] = time.perf_counter() - t0

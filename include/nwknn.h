@@ -165,6 +165,26 @@ int nwknn_search_column_chunks(nwknn_handle h, const void* const* chunks, const 
                                int dtype, int32_t k, int metric, int64_t index_offset, float* out_dist, int64_t* out_idx,
                                int out_location);
 
+/* ---- a base tile handed over in pieces: the row groups of the tile loop's `base_table.slice(...)`, cu_knn.py:201-211 ----------------
+ * The reference uploads a tile after it has read ALL of it (whole file first: cu_knn.py:112-114).  With 288 GB of HBM a tile is the file,
+ * so nothing would reach the GPU before the last row group is decoded.  These three calls take a tile as it is decoded:
+ *   nwknn_base_begin(h, rows, d, dtype)   announces a base of `rows` rows (dtype as in nwknn_set_base: it selects the compute path) and
+ *                                         allocates it; the previous base is gone from this point on;
+ *   nwknn_base_append*(...)               the next n rows, in row order -- row-major (host or device), or per-dimension column chunks
+ *                                         exactly as nwknn_set_base_column_chunks takes them (chunk c of column j at chunks[c*d + j]).
+ *                                         A column append returns once the caller's arrays have been gathered into the library's pinned
+ *                                         slabs: the arrays may be released, and the piece's H2D copy and layout kernel run under whatever
+ *                                         the caller does next (decoding the following row group);
+ *   nwknn_base_end(h)                     all announced rows must have arrived; pads the last tile, runs the checks and copies of
+ *                                         nwknn_set_base and makes the base current.
+ * The prepared layout is made row by row, so the base -- and every search on it -- is bit for bit what nwknn_set_base* builds from the
+ * concatenation of the pieces.  An error in an append abandons the half-built base (NWKNN_ESTATE from then on until the next begin). */
+int nwknn_base_begin(nwknn_handle h, int64_t rows, int32_t d, int dtype);
+int nwknn_base_append(nwknn_handle h, const void* rows_ptr, int64_t n, int dtype, int location);
+int nwknn_base_append_column_chunks(nwknn_handle h, const void* const* chunks, const int64_t* chunk_rows, int32_t n_chunks, int64_t n,
+                                    int dtype);
+int nwknn_base_end(nwknn_handle h);
+
 /* ---- merge of partial top-k lists: merge_indices_and_distances(), merge.py:56-101 ----------------------- */
 /* dists/idx: [n_lists][nq][k_in] (partial list l of query q at ((l*nq)+q)*k_in); idx < 0 marks an empty
  * slot.  Writes the k_out smallest by (distance, index) into out_dist/out_idx [nq][k_out].

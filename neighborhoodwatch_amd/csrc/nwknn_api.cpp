@@ -105,8 +105,12 @@ struct nwknn_ctx {
     void* pin[2] = {nullptr, nullptr};
     size_t pin_bytes = 0;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_prepped[2] = {nullptr, nullptr};
+    long long up_seq = 0;           // slabs the column upload pipeline has sent so far (never reset: the two pinned / device slabs alternate across calls)
     // base shard
     DevBuf bp, bn, braw;
+    // a base that is being handed over in pieces (nwknn_base_begin / _append* / _end): rows expected, rows laid out so far; 0 = none
+    long long sb_rows = 0, sb_done = 0, sb_rows_pad = 0;
+    int sb_d = 0, sb_dp = 0, sb_f16 = 0, sb_pre = 0;
     long long nb = 0, nb_pad = 0;
     int d = 0, dp = 0;
     long long ms_docs = 0;          // > 0: the base holds ms_docs documents of NWK_MS_TOKENS_PER_DOC token rows each (MaxSim)
@@ -449,8 +453,11 @@ static int ensure_upload_pipeline(nwknn_ctx* h, size_t slab_bytes)
     return NWKNN_OK;
 }
 
+// finish = false (a piece of a streamed base, nwknn_base_append_column_chunks): the call returns as soon as the caller's arrays have been
+// gathered into the pinned slabs -- the H2D copy and the layout kernel of the last slab(s) are still in flight on the copy / compute
+// streams, ordered against the next call's by the same events that order slab s against slab s+2 inside one call.
 static int stage_and_prep_columns(nwknn_ctx* h, const ColumnSource& src, int in_dtype, int out_f16, long long rows, int d, long long rows_pad,
-                                  int dp, DevBuf& raw, void* dst, float* norms)
+                                  int dp, DevBuf& raw, void* dst, float* norms, bool finish = true)
 {
     const size_t in_es = in_dtype == NWKNN_DTYPE_F64 ? 8 : (in_dtype == NWKNN_DTYPE_F16 ? 2 : 4), out_es = out_f16 ? 2 : 4;
     if (in_dtype == NWKNN_DTYPE_F16 && !out_f16) return fail(NWKNN_EINVAL, "fp16 columns need the fp16 compute path");
@@ -467,16 +474,23 @@ static int stage_and_prep_columns(nwknn_ctx* h, const ColumnSource& src, int in_
     const long long slab_rows = std::max<long long>(256, (long long)(((size_t)h->opt_upload_slab_mib << 20) / ((size_t)d * in_es)) / 256 * 256);
     const long long stage_rows = std::min(slab_rows, round_up(std::max<long long>(rows, 1), 256));
     const size_t slab_bytes = (size_t)stage_rows * d * in_es;
+    if (raw.bytes < 2 * slab_bytes || h->pin_bytes < slab_bytes || finish) {
+        // whatever the streams still do with the slabs (a previous call's copy or layout kernel) must finish before they are re-allocated;
+        // a one-call upload also starts from idle streams, as it always did
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->copy_stream) HIPCHK(hipStreamSynchronize(h->copy_stream));
+    }
     RCCHK(raw.ensure(2 * slab_bytes));
     RCCHK(ensure_upload_pipeline(h, slab_bytes));
-    // whatever the compute stream still does with the device slabs (a previous call's layout kernel) must finish first
-    HIPCHK(hipStreamSynchronize(h->stream));
-    int s = 0;
-    for (long long r0 = 0; r0 < rows_pad; r0 += slab_rows, ++s) {
-        const int b = s & 1;
+    // device slab b of THIS call's geometry: the second one starts where the first one of the LARGEST slab size seen ends, so that pieces of
+    // different lengths (a short last row group) never overlap a slab that is still being read
+    const size_t dev_half = raw.bytes / 2 / 256 * 256;
+    for (long long r0 = 0; r0 < rows_pad; r0 += slab_rows) {
+        const long long s = h->up_seq++;
+        const int b = (int)(s & 1);
         const long long pad_here = std::min(slab_rows, rows_pad - r0);
         const long long real_here = std::max<long long>(0, std::min(slab_rows, rows - r0));
-        char* dev_slab = (char*)raw.p + (size_t)b * slab_bytes;
+        char* dev_slab = (char*)raw.p + (size_t)b * dev_half;
         if (real_here > 0) {
             if (s >= 2) HIPCHK(hipEventSynchronize(h->ev_h2d[b]));            // the copy of slab s-2 has left this pinned buffer
             {   // gather: column j of the slab at offset j * stage_rows (the layout kernel's row stride 1, column stride stage_rows)
@@ -529,7 +543,7 @@ static int stage_and_prep_columns(nwknn_ctx* h, const ColumnSource& src, int in_
         ev_end(h, e);
         HIPCHK(hipEventRecord(h->ev_prepped[b], h->stream));
     }
-    HIPCHK(hipStreamSynchronize(h->stream));        // the caller may reuse its columns, and the device slabs, right away
+    if (finish) HIPCHK(hipStreamSynchronize(h->stream));        // the device slabs are idle again; (the caller's columns were free after the last gather)
     return NWKNN_OK;
 }
 
@@ -585,26 +599,35 @@ static int ensure_base_copy(nwknn_ctx* h, int kind)
     return NWKNN_OK;
 }
 
-static int set_base_common(nwknn_ctx* h, const void* base, const ColumnSource* columns, int64_t rows, int32_t d, int dtype, int location)
+// geometry of a prepared base and its buffers (what set_base decides before a byte is moved)
+struct BasePlan { long long rows, rows_pad; int d, dp, f16; bool pre; };
+
+static int base_plan(nwknn_ctx* h, int64_t rows, int32_t d, int dtype, bool cols, BasePlan* bp)
 {
-    if (!h || (!base && !columns)) return fail(NWKNN_EINVAL, "nwknn_set_base: null handle or base pointer");
-    const bool cols = columns != nullptr;
     if (dtype != NWKNN_DTYPE_F32 && dtype != NWKNN_DTYPE_F16 && !(cols && dtype == NWKNN_DTYPE_F64))
         return fail(NWKNN_EINVAL, "nwknn_set_base: unsupported dtype %d", dtype);
     if (rows <= 0 || d <= 0) return fail(NWKNN_EINVAL, "nwknn_set_base: rows=%lld d=%d must be positive", (long long)rows, d);
     if (rows >= (1ll << 32) - 512) return fail(NWKNN_EINVAL, "nwknn_set_base: a shard holds at most 2^32-513 rows");
-    if (!cols && location != NWKNN_HOST && location != NWKNN_DEVICE) return fail(NWKNN_EINVAL, "bad location %d", location);
     RCCHK(use_device(h));
-    const int f16 = (dtype == NWKNN_DTYPE_F16 || h->opt_compute_f16) ? 1 : 0;
-    const bool pre = h->opt_prescreen && !f16;
-    const long long rows_pad = round_up(rows, (f16 || pre) ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS);
-    const int dp = (int)round_up(d, f16 ? NWK_K_ALIGN_F16 : NWK_K_ALIGN);
-    RCCHK(h->bp.ensure((size_t)rows_pad * dp * (f16 ? 2 : 4)));
-    RCCHK(h->bn.ensure((size_t)rows_pad * 4));
+    bp->rows = rows; bp->d = d;
+    bp->f16 = (dtype == NWKNN_DTYPE_F16 || h->opt_compute_f16) ? 1 : 0;
+    bp->pre = h->opt_prescreen && !bp->f16;
+    bp->rows_pad = round_up(rows, (bp->f16 || bp->pre) ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS);
+    bp->dp = (int)round_up(d, bp->f16 ? NWK_K_ALIGN_F16 : NWK_K_ALIGN);
+    h->sb_rows = 0;                                                 // a half-streamed base is abandoned by any new base
+    h->nb = 0;                                                      // ... and the previous base is gone as soon as its buffers may move
+    RCCHK(h->bp.ensure((size_t)bp->rows_pad * bp->dp * (bp->f16 ? 2 : 4)));
+    RCCHK(h->bn.ensure((size_t)bp->rows_pad * 4));
     h->ev_used = 0;
-    if (cols) RCCHK(stage_and_prep_columns(h, *columns, dtype, f16, rows, d, rows_pad, dp, h->braw, h->bp.p, h->bn.as<float>()));
-    else RCCHK(stage_and_prep(h, base, location, dtype == NWKNN_DTYPE_F16, f16, rows, d, rows_pad, dp, h->braw, h->bp.p, h->bn.as<float>()));
-    h->nb = rows; h->nb_pad = rows_pad; h->d = d; h->dp = dp; h->f16 = f16; h->ms_docs = 0;
+    return NWKNN_OK;
+}
+
+// the rows are laid out (bp / bn complete, padding included): checks and copies the searches need, then the base becomes current
+static int base_finish(nwknn_ctx* h, const BasePlan& b)
+{
+    const long long rows_pad = b.rows_pad;
+    const int d = b.d, dp = b.dp, f16 = b.f16;
+    h->nb = b.rows; h->nb_pad = rows_pad; h->d = d; h->dp = dp; h->f16 = f16; h->ms_docs = 0;
     h->pre_ok = 0;
     h->f16_finite = 0;
     if (f16 && h->opt_f16_exact) {
@@ -613,7 +636,7 @@ static int set_base_common(nwknn_ctx* h, const void* base, const ColumnSource* c
         h->f16_finite = finite ? 1 : 0;
         h->nb_pad_for_copy = rows_pad; h->dp_for_copy = dp; h->dp16 = dp; h->pre_kind = -1;      // cosine builds unit-row copies on demand
     }
-    if (pre) {
+    if (b.pre) {
         bool usable = false;
         RCCHK(matrix_maxabs(h, h->bp.as<float>(), rows_pad * (long long)dp, &h->b_maxabs, &usable));
         h->nb_pad_for_copy = rows_pad; h->dp_for_copy = dp;
@@ -636,6 +659,90 @@ static int set_base_common(nwknn_ctx* h, const void* base, const ColumnSource* c
     return NWKNN_OK;
 }
 
+static int set_base_common(nwknn_ctx* h, const void* base, const ColumnSource* columns, int64_t rows, int32_t d, int dtype, int location)
+{
+    if (!h || (!base && !columns)) return fail(NWKNN_EINVAL, "nwknn_set_base: null handle or base pointer");
+    const bool cols = columns != nullptr;
+    if (!cols && location != NWKNN_HOST && location != NWKNN_DEVICE) return fail(NWKNN_EINVAL, "bad location %d", location);
+    BasePlan b;
+    RCCHK(base_plan(h, rows, d, dtype, cols, &b));
+    if (cols) RCCHK(stage_and_prep_columns(h, *columns, dtype, b.f16, rows, d, b.rows_pad, b.dp, h->braw, h->bp.p, h->bn.as<float>()));
+    else RCCHK(stage_and_prep(h, base, location, dtype == NWKNN_DTYPE_F16, b.f16, rows, d, b.rows_pad, b.dp, h->braw, h->bp.p, h->bn.as<float>()));
+    return base_finish(h, b);
+}
+
+// ---- a base handed over in pieces ---------------------------------------------------------------------------------------------------
+// The reference's tile loop uploads a tile after it has been read whole (cu_knn.py:201-211).  With mem_tune on 288 GB a "tile" is the
+// whole file, so nothing reached the GPU before the last row group was decoded (round 4: kNN stage 8.4 s through files, 0.87 s from
+// memory).  Here a tile is announced (begin), its row groups are appended as the reader threads finish them -- an append returns once the
+// piece has been gathered into the pinned slabs, its H2D copy and layout kernel run under the decoding of the next piece -- and end pads
+// the last tile, runs the checks / copies of nwknn_set_base and makes the base current.  The prepared layout is per-row, so the result is
+// the layout nwknn_set_base* would have built from the concatenation: the same bits.
+static int base_begin_common(nwknn_ctx* h, int64_t rows, int32_t d, int dtype)
+{
+    if (!h) return fail(NWKNN_EINVAL, "nwknn_base_begin: null handle");
+    BasePlan b;
+    RCCHK(base_plan(h, rows, d, dtype, false, &b));
+    h->sb_rows = rows; h->sb_done = 0; h->sb_rows_pad = b.rows_pad; h->sb_d = d; h->sb_dp = b.dp; h->sb_f16 = b.f16; h->sb_pre = b.pre ? 1 : 0;
+    return NWKNN_OK;
+}
+
+static int base_append_check(nwknn_ctx* h, const char* what, int64_t n)
+{
+    if (!h) return fail(NWKNN_EINVAL, "%s: null handle", what);
+    if (h->sb_rows <= 0) return fail(NWKNN_ESTATE, "%s: call nwknn_base_begin first", what);
+    if (n <= 0) return fail(NWKNN_EINVAL, "%s: a piece holds at least one row", what);
+    if (h->sb_done + n > h->sb_rows) return fail(NWKNN_EINVAL, "%s: %lld + %lld rows exceed the %lld announced", what, h->sb_done, (long long)n, h->sb_rows);
+    return use_device(h);
+}
+
+static int base_append_columns_common(nwknn_ctx* h, const ColumnSource& src, int64_t n, int dtype)
+{
+    RCCHK(base_append_check(h, "nwknn_base_append_column_chunks", n));
+    if (dtype != NWKNN_DTYPE_F32 && dtype != NWKNN_DTYPE_F16 && dtype != NWKNN_DTYPE_F64) return fail(NWKNN_EINVAL, "nwknn_base_append_column_chunks: unsupported dtype %d", dtype);
+    const size_t out_es = h->sb_f16 ? 2 : 4;
+    const int rc = stage_and_prep_columns(h, src, dtype, h->sb_f16, n, h->sb_d, n, h->sb_dp, h->braw, (char*)h->bp.p + (size_t)h->sb_done * h->sb_dp * out_es,
+                                          h->bn.as<float>() + h->sb_done, false);
+    if (rc != NWKNN_OK) { h->sb_rows = 0; return rc; }              // a failed piece abandons the base (streams may hold half of it)
+    h->sb_done += n;
+    return NWKNN_OK;
+}
+
+static int base_append_rows_common(nwknn_ctx* h, const void* rows_ptr, int64_t n, int dtype, int location)
+{
+    RCCHK(base_append_check(h, "nwknn_base_append", n));
+    if (dtype != NWKNN_DTYPE_F32 && dtype != NWKNN_DTYPE_F16) return fail(NWKNN_EINVAL, "nwknn_base_append: unsupported dtype %d", dtype);
+    if (location != NWKNN_HOST && location != NWKNN_DEVICE) return fail(NWKNN_EINVAL, "bad location %d", location);
+    const size_t out_es = h->sb_f16 ? 2 : 4;
+    const int rc = stage_and_prep(h, rows_ptr, location, dtype == NWKNN_DTYPE_F16, h->sb_f16, n, h->sb_d, n, h->sb_dp, h->braw,
+                                  (char*)h->bp.p + (size_t)h->sb_done * h->sb_dp * out_es, h->bn.as<float>() + h->sb_done);
+    if (rc != NWKNN_OK) { h->sb_rows = 0; return rc; }
+    h->sb_done += n;
+    return NWKNN_OK;
+}
+
+static int base_end_common(nwknn_ctx* h)
+{
+    if (!h) return fail(NWKNN_EINVAL, "nwknn_base_end: null handle");
+    if (h->sb_rows <= 0) return fail(NWKNN_ESTATE, "nwknn_base_end: call nwknn_base_begin first");
+    RCCHK(use_device(h));
+    if (h->sb_done != h->sb_rows) {
+        const long long done = h->sb_done, want = h->sb_rows;
+        h->sb_rows = 0;
+        return fail(NWKNN_ESTATE, "nwknn_base_end: %lld of the %lld announced rows were appended", done, want);
+    }
+    BasePlan b{h->sb_rows, h->sb_rows_pad, h->sb_d, h->sb_dp, h->sb_f16, h->sb_pre != 0};
+    h->sb_rows = 0;
+    if (b.rows_pad > b.rows) {                                        // zero rows (norm 0) up to the tile granule, as a one-call set_base leaves them
+        const size_t out_es = b.f16 ? 2 : 4;
+        EvPair* e = ev_begin(h, 2);
+        HIPCHK(nwk_launch_prep_strided(h->stream, h->bp.p, NWKNN_DTYPE_F32, 1, 1, 0, b.d, b.rows_pad - b.rows, b.dp, b.f16,
+                                       (char*)h->bp.p + (size_t)b.rows * b.dp * out_es, h->bn.as<float>() + b.rows));
+        ev_end(h, e);
+    }
+    return base_finish(h, b);                                         // its first reduction synchronises the compute stream: every piece has landed
+}
+
 extern "C" int nwknn_set_base(nwknn_handle h, const void* base, int64_t rows, int32_t d, int dtype, int location)
 {
     if (!base) return fail(NWKNN_EINVAL, "nwknn_set_base: null handle or base pointer");
@@ -656,6 +763,29 @@ extern "C" int nwknn_set_base_column_chunks(nwknn_handle h, const void* const* c
     if (!chunks || !chunk_rows || n_chunks <= 0) return fail(NWKNN_EINVAL, "nwknn_set_base_column_chunks: null or empty chunk table");
     const ColumnSource src{chunks, chunk_rows, n_chunks};
     return guarded([&] { return set_base_common(h, nullptr, &src, rows, d, dtype, NWKNN_HOST); });
+}
+
+extern "C" int nwknn_base_begin(nwknn_handle h, int64_t rows, int32_t d, int dtype)
+{
+    return guarded([&] { return base_begin_common(h, rows, d, dtype); });
+}
+
+extern "C" int nwknn_base_append(nwknn_handle h, const void* rows_ptr, int64_t n, int dtype, int location)
+{
+    if (!rows_ptr) return fail(NWKNN_EINVAL, "nwknn_base_append: null rows");
+    return guarded([&] { return base_append_rows_common(h, rows_ptr, n, dtype, location); });
+}
+
+extern "C" int nwknn_base_append_column_chunks(nwknn_handle h, const void* const* chunks, const int64_t* chunk_rows, int32_t n_chunks, int64_t n, int dtype)
+{
+    if (!chunks || !chunk_rows || n_chunks <= 0) return fail(NWKNN_EINVAL, "nwknn_base_append_column_chunks: null or empty chunk table");
+    const ColumnSource src{chunks, chunk_rows, n_chunks};
+    return guarded([&] { return base_append_columns_common(h, src, n, dtype); });
+}
+
+extern "C" int nwknn_base_end(nwknn_handle h)
+{
+    return guarded([&] { return base_end_common(h); });
 }
 
 // ---- search -----------------------------------------------------------------------------------------

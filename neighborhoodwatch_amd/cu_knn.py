@@ -38,7 +38,7 @@ import pyarrow.parquet as pq
 from .engine import KnnEngine, default_engine, mem_info, resolve_metric
 from .nw_utils import (get_full_filename, get_partial_distances_filename, get_partial_indices_filename,
                        output_dimension_validity_check)
-from .parquet_stream import ParquetRows, Prefetch
+from .parquet_stream import ParquetRows, PieceReader, Prefetch
 
 PARQUET_ROW_GROUP = 100000          # cu_knn.py:284-285
 PREFETCH_SLOTS = 2                  # base tiles alive on the host at once per GPU: the one being searched + the one being decoded
@@ -176,6 +176,43 @@ def table_input(table):
 def engine_set_base(eng, kind_data):
     kind, data = kind_data
     eng.set_base(data) if kind == "matrix" else eng.set_base_columns(data)
+
+
+def base_geometry(schema):
+    """(dimension, 'f16' | 'f32') of the embedding columns of a schema: what ``KnnEngine.base_begin`` is told before any row arrives."""
+    lst = list_embedding_field(schema) or list_embedding_field(schema, "token_embedding_")
+    if lst is not None:
+        return lst.type.list_size, ("f16" if pa.types.is_float16(lst.type.value_type) else "f32")
+    fields = [f for f in schema if pa.types.is_floating(f.type)]
+    return len(fields), ("f16" if fields and all(pa.types.is_float16(f.type) for f in fields) else "f32")
+
+
+def stream_tiles(eng, rows: ParquetRows, tiles, readers=None):
+    """Load base tiles ``[(first row, rows), ...]`` of a lazy parquet window into ``eng`` one after the other, each PIECE BY PIECE: the
+    row groups of ALL the listed tiles are decoded in row order by a pool of reader threads (``PieceReader``: own memory-mapped handles, a
+    bounded number of pieces ahead), and every decoded piece goes straight to the GPU (``base_append*``: gather into pinned memory, H2D copy
+    and layout kernel asynchronous) while the next ones are decoded.  Yields the tile's position in ``tiles`` once the tile is resident
+    (``base_end`` done); while the consumer searches it, the readers are already decoding the first pieces of the next tile.
+    The reference reads the whole file, then uploads tile after tile (cu_knn.py:112-114,201-211)."""
+    dims, dtype = base_geometry(rows.schema)
+    counts, pieces = [], []
+    for off, length in tiles:
+        ps = rows.pieces(off, length)
+        counts.append(len(ps))
+        pieces.extend((rows, pc) for pc in ps)
+    with PieceReader(pieces, readers=readers) as reader:
+        for i, ((off, length), n_pieces) in enumerate(zip(tiles, counts)):
+            eng.base_begin(length, dims, dtype)
+            for _ in range(n_pieces):
+                t = next(reader)
+                kind, data = table_input(t)
+                if kind == "matrix":
+                    eng.base_append(data)
+                else:
+                    eng.base_append_columns(data)
+                del t, data
+            eng.base_end()
+            yield i
 
 
 def engine_search(eng, kind_data, k, metric, index_offset=0, out_device=False):
@@ -339,9 +376,9 @@ def process_batches(data_dir,
         eng.set_compute_dtype(dtype)
         eng.set_prescreen(prescreen)
 
-        def tiles():
-            """This slot's tiles, decoded on the prefetch thread: tile i+1 is read (base_table.slice reads just its row groups when the
-            base is a lazy ParquetRows; a pyarrow.Table slices for free) while tile i is on the GPU."""
+        def plan():
+            """This slot's tiles: (tile ordinal, first row, rows, provenance tag) -- minus the ones a resumed run already holds."""
+            out = []
             for start in range(slot, batch_count, len(devices)):
                 batch_offset = start * batch_size
                 batch_length = batch_size if start != batch_count - 1 else len(base_table) - batch_offset
@@ -349,8 +386,31 @@ def process_batches(data_dir,
                 if resume and _partial_pair_exists(data_dir, start, len(query_table), k, tag):
                     print(f"-- base tile {start}: partial files of the same metric/dtype/tile present, skipped")
                     continue
-                tile = base_table.slice(batch_offset, batch_length)
-                yield start, batch_offset, batch_length, tag, table_input(tile), tile
+                out.append((start, batch_offset, batch_length, tag))
+            return out
+
+        def resident_tiles():
+            """(tile ordinal, first row, rows, tag, dimension) with the tile loaded into the engine.  A lazy parquet window (how compute_knn
+            opens the base) is streamed piece by piece (stream_tiles); a pyarrow.Table -- process_batches called as the reference calls it
+            -- is sliced for free and uploaded tile by tile, the next slice prepared one tile ahead."""
+            todo = plan()
+            if isinstance(base_table, ParquetRows):
+                dims = base_geometry(base_table.schema)[0]
+                for i in stream_tiles(eng, base_table, [(off, length) for _, off, length, _ in todo]):
+                    start, batch_offset, batch_length, tag = todo[i]
+                    yield start, batch_offset, batch_length, tag, dims
+                return
+
+            def tiles():
+                for start, batch_offset, batch_length, tag in todo:
+                    tile = base_table.slice(batch_offset, batch_length)
+                    yield start, batch_offset, batch_length, tag, table_input(tile), tile
+            with Prefetch(tiles, slots=PREFETCH_SLOTS) as feed:
+                for start, batch_offset, batch_length, tag, dataset, tile in feed:
+                    dims = dataset[1].shape[1] if dataset[0] == "matrix" else len(dataset[1])
+                    engine_set_base(eng, dataset)
+                    del dataset, tile
+                    yield start, batch_offset, batch_length, tag, dims
 
         def write_pair(start, distances, indices, tag):
             stream_cudf_to_parquet(get_partial_distances_filename(data_dir, start), distances, PARQUET_ROW_GROUP, tag)
@@ -358,17 +418,15 @@ def process_batches(data_dir,
 
         writes = []
         try:
-            with Prefetch(tiles, slots=PREFETCH_SLOTS) as feed, ThreadPoolExecutor(max_workers=1) as writer:      # the pair of tile i is written while tile i+1 is searched
-                for start, batch_offset, batch_length, tag, dataset, tile in feed:
+            with ThreadPoolExecutor(max_workers=1) as writer:      # the pair of tile i is written while tile i+1 is loaded and searched
+                for start, batch_offset, batch_length, tag, dims in resident_tiles():
                     assert (k <= batch_length)                              # cu_knn.py:237
-                    dims = dataset[1].shape[1] if dataset[0] == "matrix" else len(dataset[1])
                     print(f"Dataset shape: ({batch_length}, {dims}), Query shape: ({len(query_table)}, {dims})")
-                    engine_set_base(eng, dataset)
                     distances, indices = engine_search(eng, queries, k, metric, index_offset=batch_offset)   # + batch_offset, cu_knn.py:273
                     assert (len(distances) == len(query_table))             # cu_knn.py:281-282
                     assert (len(indices) == len(query_table))
                     writes.append(writer.submit(write_pair, start, distances, indices, tag))
-                    del dataset, tile, distances, indices
+                    del distances, indices
                 for w in writes:
                     w.result()
         finally:

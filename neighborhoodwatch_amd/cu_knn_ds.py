@@ -24,7 +24,7 @@ import pyarrow.dataset as ds
 import pyarrow.parquet as pq
 
 from .cu_knn import (PARQUET_ROW_GROUP, cleanup, engine_search, engine_set_base, float_row_bytes, list_embedding_field, stream_cudf_to_parquet,
-                     table_columns, table_input)
+                     stream_tiles, table_columns, table_input)
 from .engine import default_engine, mem_info, resolve_metric
 from .nw_utils import get_full_filename, get_partial_distances_filename, get_partial_indices_filename
 from .parquet_stream import ParquetRows, Prefetch, TableRows
@@ -232,24 +232,38 @@ def process_dataset_batches(data_dir,
     else:
         _drop_checkpoint(data_dir)
 
-    def batches():
-        """(first row, rows, column views, arrow table) per base batch, decoded on the reader thread one batch ahead of the GPU."""
-        for off in range(start_row, n_base, batch_size):
-            t = base_rows.slice(off, batch_size)
-            yield off, len(t), table_input(t), t
+    todo = [(off, min(batch_size, n_base - off)) for off in range(start_row, n_base, batch_size)]
+
+    def resident_batches():
+        """(first row, rows) per base batch, with the batch loaded into the engine.  Parquet-backed rows are streamed piece by piece: the row
+        groups of all remaining batches are decoded in order by reader threads and handed to the GPU as they arrive (cu_knn.stream_tiles),
+        so decode, upload and -- across batches -- search overlap; in-memory rows are sliced and uploaded one batch ahead."""
+        if isinstance(base_rows, ParquetRows):
+            for i in stream_tiles(eng, base_rows, todo):
+                yield todo[i]
+            return
+
+        def batches():
+            for off, n in todo:
+                t = base_rows.slice(off, n)
+                yield off, len(t), table_input(t), t
+        with Prefetch(batches, slots=PREFETCH_SLOTS) as feed:
+            for off, n, base, table in feed:
+                engine_set_base(eng, base)
+                del base, table
+                yield off, n
 
     pending_write = None
     try:
-        with Prefetch(batches, slots=PREFETCH_SLOTS) as feed, ThreadPoolExecutor(max_workers=1) as writer:
-            for batch_offset, rows, base, table in feed:
+        with ThreadPoolExecutor(max_workers=1) as writer:
+            for batch_offset, rows in resident_batches():
                 assert (k <= rows)                                                # cu_knn_ds.py:203
-                engine_set_base(eng, base)
                 d, i = engine_search(eng, queries, k, metric, index_offset=batch_offset, out_device=True)   # + batch_offset, cu_knn_ds.py:216
                 if run_d is None:
                     run_d, run_i = d, i
                 else:                                                             # fold on the device: [2,Q,k] -> [Q,k]
                     run_d, run_i = eng.merge(torch.stack([run_d, d]), torch.stack([run_i, i]), k)
-                del base, table, d, i
+                del d, i
                 if resume and batch_offset + rows < n_base:
                     if pending_write is not None:
                         pending_write.result()                                    # one checkpoint in flight at a time

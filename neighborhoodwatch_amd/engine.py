@@ -229,6 +229,42 @@ class KnnEngine:
         self.rows, self.dim = rows, dim
         del keep
 
+    # -- a base handed over in pieces (the row groups of a tile, as they are decoded) ---------------------------------------------------
+    def base_begin(self, rows: int, dim: int, dtype: str = "f32") -> None:
+        """Announce a base of ``rows`` x ``dim`` that will arrive through ``base_append*`` in row order (``dtype`` 'f16': the pieces are
+        fp16 and the fp16 compute path is used, as ``set_base`` of a float16 matrix).  The previous base is gone from here on."""
+        if rows <= 0 or dim <= 0:
+            raise ValueError("dataset is empty")
+        dt = {"f32": DTYPE_F32, "fp32": DTYPE_F32, "f16": DTYPE_F16, "fp16": DTYPE_F16}[dtype]
+        self.rows = 0
+        check(self._L.nwknn_base_begin(self._h, int(rows), int(dim), dt), "nwknn_base_begin")
+        self._pending = (int(rows), int(dim))
+
+    def base_append(self, rows) -> None:
+        """The next rows as a row-major matrix (numpy, or a torch tensor on the host or on this engine's GPU)."""
+        ptr, n, dim, dt, loc, keep = self._matrix(rows, "piece")
+        if loc == DEVICE:
+            self._order_after_torch(keep, "piece")
+        if dim != self._pending[1]:
+            raise ValueError(f"piece has dimension {dim}, the announced base has {self._pending[1]}")
+        check(self._L.nwknn_base_append(self._h, ctypes.c_void_p(ptr), n, dt, loc), "nwknn_base_append")
+        if loc == DEVICE:
+            self.synchronize()
+        del keep
+
+    def base_append_columns(self, columns) -> None:
+        """The next rows as per-dimension arrays (or lists of chunks), like ``set_base_columns``.  Returns as soon as the arrays have
+        been gathered into pinned memory: the copy to the GPU and the layout kernel overlap whatever the caller does next."""
+        table, rows_arr, n_chunks, n, dim, dt, keep = self._columns(columns, "piece")
+        if dim != self._pending[1]:
+            raise ValueError(f"piece has dimension {dim}, the announced base has {self._pending[1]}")
+        check(self._L.nwknn_base_append_column_chunks(self._h, table, rows_arr, n_chunks, n, dt), "nwknn_base_append_column_chunks")
+        del keep
+
+    def base_end(self) -> None:
+        check(self._L.nwknn_base_end(self._h), "nwknn_base_end")
+        self.rows, self.dim = self._pending
+
     def search_columns(self, columns, k: int, metric: str = "sqeuclidean", index_offset: int = 0, out_device: bool = False):
         """Queries as per-dimension host arrays (or chunk lists).  -> (distances [q,k] f32, indices [q,k] i64): numpy arrays, or torch
         CUDA tensors on this engine's GPU with ``out_device=True`` (results that are folded on the device never visit the host)."""

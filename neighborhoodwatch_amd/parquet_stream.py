@@ -9,6 +9,10 @@ batches with ``dataset.to_batches`` (cu_knn_ds.py:190) but searches them strictl
   ``slice(offset, length)`` (a ``pyarrow.Table`` of exactly those rows, built from the row groups that overlap them -- nothing else
   is read, nothing is concatenated: the table keeps one chunk per row-group piece, which the engine's upload pipeline gathers from
   directly) and ``iter_tables(batch_rows, start)``.
+* ``PieceReader``  -- decodes the row-group pieces of one or more row windows on SEVERAL reader threads (a ``ParquetFile`` handle each,
+  memory-mapped) and hands them out in row order, a bounded number of pieces ahead of the consumer: the consumer appends piece g to the
+  GPU's base (``KnnEngine.base_append_columns``: gather + H2D + layout) while pieces g+1.. are being decoded, so a one-tile job -- with
+  ``mem_tune`` on 288 GB the whole file is ONE tile -- overlaps decode and upload too (round 4 decoded all 24.6 GB before the GPU saw a row).
 * ``Prefetch``     -- runs a generator on a background thread at most ``slots`` items ahead *including the one the consumer holds*:
   with two slots the reader decodes tile i+1 while tile i is on the GPU, and host memory never holds more than two tiles.
 
@@ -16,8 +20,11 @@ Nothing here touches the GPU; pyarrow releases the GIL while it decodes, and the
 """
 from __future__ import annotations
 
+import os
 import threading
-from typing import Callable, Iterable, Iterator, List, Optional, Sequence
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
+from typing import Callable, Iterable, Iterator, List, Optional, Sequence, Tuple
 
 import pyarrow as pa
 import pyarrow.parquet as pq
@@ -86,8 +93,38 @@ class ParquetRows:
             cache = self._tls.files = {}
         f = cache.get(fi)
         if f is None:
-            f = cache[fi] = pq.ParquetFile(self.paths[fi])
+            # memory-mapped: pyarrow decodes straight from the page cache instead of read()ing every column chunk into a buffer first --
+            # 5.3 -> 14.5 GB/s of floats on the GPU box's host for the reference's layout (1536 float columns, 100 000-row groups;
+            # tools/parquet_decode_probe.py, profiles/r05h_parquet_decode_probe.log), 3.5 -> 9.8 GB/s with pyarrow's default encoding
+            try:
+                f = pq.ParquetFile(self.paths[fi], memory_map=True)
+            except (OSError, pa.ArrowInvalid):
+                f = pq.ParquetFile(self.paths[fi])
+            cache[fi] = f
         return f
+
+    def pieces(self, offset: int = 0, length: Optional[int] = None) -> List[Tuple[int, int, int, int, int]]:
+        """The row-group pieces that make up rows [offset, offset + length) of the window, in row order:
+        ``(file index, row group, first row of the piece in the window's numbering, rows to skip inside the group, rows)``."""
+        offset = max(0, min(int(offset), self._count))
+        end = self._count if length is None else max(offset, min(offset + int(length), self._count))
+        out = []
+        for fi, g, first, n in self._groups:
+            if first + n <= offset:
+                continue
+            if first >= end:
+                break
+            lo = max(offset - first, 0)
+            hi = min(end - first, n)
+            if hi > lo:
+                out.append((fi, g, first + lo, lo, hi - lo))
+        return out
+
+    def read_piece(self, piece: Tuple[int, int, int, int, int]) -> pa.Table:
+        """One piece of ``pieces()`` as a table (decoded on the calling thread, with its own file handle)."""
+        fi, g, _first, lo, n = piece
+        t = self._file(fi).read_row_groups([g], columns=self._columns, use_threads=True)
+        return t if (lo == 0 and n == len(t)) else t.slice(lo, n)
 
     def slice(self, offset: int = 0, length: Optional[int] = None) -> pa.Table:
         """Rows [offset, offset + length) of the window as a pyarrow.Table (pyarrow's ``Table.slice`` semantics: clipped at the end)."""
@@ -174,6 +211,68 @@ class TableRows:
         """In-memory rows have no file identity: a checkpoint written over them is only good inside this process."""
         import os
         return f"memory:{os.getpid()}:{id(self._t)}:{len(self._t)}x{self._t.num_columns}"
+
+
+def default_readers() -> int:
+    """Reader threads of a PieceReader: 4 unless NWKNN_READERS says otherwise (on the GPU box's host 2-4 readers with pyarrow's column threads
+    inside each decode fastest -- 16-18 GB/s of floats; more readers fight for the same column-thread pool)."""
+    try:
+        return max(1, int(os.environ.get("NWKNN_READERS", "4")))
+    except ValueError:
+        return 4
+
+
+class PieceReader:
+    """Decode ``pieces`` (each ``(rows: ParquetRows, piece)``) on ``readers`` threads and iterate the tables IN ORDER, at most ``ahead``
+    pieces decoded or in flight beyond the one the consumer holds.  An exception in a reader surfaces at the position of its piece."""
+
+    def __init__(self, pieces: Sequence[Tuple["ParquetRows", tuple]], readers: Optional[int] = None, ahead: Optional[int] = None,
+                 ahead_bytes: int = 6 << 30):
+        self._pieces = list(pieces)
+        self._readers = readers or default_readers()
+        if ahead is None:
+            # bounded by host memory, not by count: a piece of the reference's published run is 100 000 rows x 1536 floats = 614 MB
+            biggest = 1
+            for rows, pc in self._pieces[:64]:
+                row_bytes = sum((f.type.bit_width // 8) if pa.types.is_floating(f.type) else
+                                (f.type.list_size * f.type.value_type.bit_width // 8 if pa.types.is_fixed_size_list(f.type) else 8) for f in rows.schema)
+                biggest = max(biggest, pc[4] * max(row_bytes, 1))
+            ahead = max(self._readers, min(16, ahead_bytes // biggest))
+        self._ahead = max(1, int(ahead))
+        self._pool = ThreadPoolExecutor(max_workers=self._readers, thread_name_prefix="nw-reader")
+        self._queue: deque = deque()
+        self._next = 0
+        self.max_inflight = 0
+        self._fill()
+
+    def _fill(self):
+        while self._next < len(self._pieces) and len(self._queue) < self._ahead:
+            rows, pc = self._pieces[self._next]
+            self._queue.append(self._pool.submit(rows.read_piece, pc))
+            self._next += 1
+        self.max_inflight = max(self.max_inflight, len(self._queue))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> pa.Table:
+        if not self._queue:
+            raise StopIteration
+        fut = self._queue.popleft()
+        self._fill()                                             # keep the readers busy while the consumer works on this piece
+        return fut.result()
+
+    def close(self):
+        for f in self._queue:
+            f.cancel()
+        self._queue.clear()
+        self._pool.shutdown(wait=True)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 class Prefetch:

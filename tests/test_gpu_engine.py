@@ -337,6 +337,61 @@ def test_upload_pipeline_reuses_its_buffers_over_many_slabs(oracle, dtype):
     assert np.array_equal(idx, ri) and _same_bits(dist, rd)
 
 
+@pytest.mark.parametrize("mode", ["direct", "prescreen", "f16"])
+def test_a_base_handed_over_in_pieces_gives_the_bits_of_the_whole(oracle, mode):
+    """nwknn_base_begin / _append* / _end (how the file API now feeds a base tile: row group by row group, each piece's H2D copy and
+    layout kernel under the decoding of the next): pieces of 1, 2 559, 1 and 18 440 rows as float32 columns, float64 columns, chunked
+    columns and row-major rows, small upload slabs so that pieces span several slabs and slabs several pieces.  The prepared base, and so
+    every search, must equal the one-call upload bit for bit -- direct fp32, pre-screened (the fp16 copy is made at the end) and the fp16
+    compute path (fp16 pieces)."""
+    from neighborhoodwatch_amd import KnnEngine
+    from neighborhoodwatch_amd._lib import NwknnError
+    B, Q, d, k = 21_001, 150, 96, 17
+    if mode == "f16":
+        base, queries = oracle.gen_f16_numpy(0xF1, 0, B, d), oracle.gen_f16_numpy(0xF2, 0, Q, d)
+    else:
+        base, queries = oracle.gen(0xF1, 0, B, d), oracle.gen(0xF2, 0, Q, d)
+    cuts = [0, 1, 2_560, 2_561, B]
+    with KnnEngine(0) as eng:
+        eng.set_option("upload_slab_mib", 1)
+        eng.set_prescreen(mode == "prescreen")
+        eng.base_begin(B, d, "f16" if mode == "f16" else "f32")
+        with pytest.raises(NwknnError):
+            eng.search(queries, k)                                     # not a base yet
+        for n, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+            piece = base[a:b]
+            if n == 0:
+                eng.base_append_columns([np.ascontiguousarray(piece[:, j]) for j in range(d)])
+            elif n == 1 and mode != "f16":
+                eng.base_append_columns([piece[:, j].astype(np.float64) for j in range(d)])
+            elif n == 2:
+                eng.base_append(piece)                                 # row-major rows
+            else:
+                half = (b - a) // 3
+                eng.base_append_columns([[np.ascontiguousarray(piece[:half, j]), np.ascontiguousarray(piece[half:, j])] for j in range(d)])
+        eng.base_end()
+        assert eng.stats is not None and eng.rows == B
+        for metric in ("sqeuclidean", "cosine"):
+            dist, idx = eng.search(queries, k, metric)
+            rd, ri = oracle.knn_canonical(base.astype(np.float32), queries.astype(np.float32), k, metric)
+            assert np.array_equal(idx, ri) and _same_bits(dist, rd), (mode, metric)
+        assert eng.stats()["prescreen"] == int(mode != "direct")
+        # misuse: more rows than announced, end before all rows, append without begin
+        eng.base_begin(10, d)
+        with pytest.raises(ValueError, match="exceed"):
+            eng.base_append(base[:11].astype(np.float32))
+        eng.base_begin(10, d)
+        eng.base_append(base[:4].astype(np.float32))
+        with pytest.raises(NwknnError, match="4 of the 10"):
+            eng.base_end()
+        with pytest.raises(NwknnError, match="nwknn_base_begin first"):
+            eng.base_append(base[:4].astype(np.float32))
+        eng.set_base(base)                                             # and the engine is as good as new
+        dist, idx = eng.search(queries, k)
+        rd, ri = oracle.knn_canonical(base.astype(np.float32), queries.astype(np.float32), k)
+        assert np.array_equal(idx, ri) and _same_bits(dist, rd)
+
+
 def test_plain_python_lists_are_columns_not_chunk_lists(engine, oracle):
     """A column passed as a plain Python list of numbers is ONE chunk (np.asarray), as before chunk lists existed; a column whose
     elements are neither scalars nor 1-D chunks is refused with a ValueError, not an IndexError."""

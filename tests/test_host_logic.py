@@ -271,6 +271,45 @@ def test_parquet_rows_reads_only_what_a_tile_needs(tmp_path):
         ParquetRows(f1, 10, ["no_such_column"])
 
 
+def test_piece_reader_hands_row_groups_over_in_order_a_bounded_number_ahead(tmp_path):
+    """ParquetRows.pieces / PieceReader: the row-group pieces of a row window (clipped at both ends, over two files) decoded by several
+    reader threads and handed out IN ROW ORDER, never more than `ahead` beyond the consumer; a reader's exception surfaces at its piece."""
+    import time
+    from neighborhoodwatch_amd.parquet_stream import ParquetRows, PieceReader
+    f1 = synth.write_source_parquet(str(tmp_path / "a.parquet"), 5, 50, 8, chunk_rows=16)
+    f2 = synth.write_source_parquet(str(tmp_path / "b.parquet"), 6, 30, 8, chunk_rows=7)
+    ref = np.concatenate([synth.gen_rows(5, 0, 50, 8), synth.gen_rows(6, 0, 30, 8)])
+    cols = [f"embedding_{i}" for i in range(8)]
+    rows = ParquetRows([f1, f2], 77, cols)
+    for off, ln in [(0, 77), (3, 9), (15, 20), (40, 30), (49, 3), (70, 100), (16, 16)]:
+        ps = rows.pieces(off, ln)
+        end = min(off + ln, 77)
+        assert ps[0][2] == off and sum(p[4] for p in ps) == end - off and all(a[2] + a[4] == b[2] for a, b in zip(ps[:-1], ps[1:]))
+        got = np.concatenate([cu_knn.table_to_matrix(rows.read_piece(p)) for p in ps])
+        assert np.array_equal(got, ref[off:end]), (off, ln)
+    assert rows.pieces(77, 5) == []
+    ps = rows.pieces(0, 77)
+    assert len(ps) == 4 + 4                                                     # 50 rows in groups of 16, then 27 of the 30 in groups of 7
+    with PieceReader([(rows, p) for p in ps], readers=3, ahead=2) as r:
+        out = []
+        for t in r:
+            time.sleep(0.005)
+            out.append(cu_knn.table_to_matrix(t))
+        assert np.array_equal(np.concatenate(out), ref[:77]) and r.max_inflight <= 2
+
+    class Broken(ParquetRows):
+        def read_piece(self, piece):
+            if piece[2] >= 32:
+                raise OSError("disk went away")
+            return ParquetRows.read_piece(self, piece)
+    bad = Broken([f1], 50, cols)
+    with PieceReader([(bad, p) for p in bad.pieces(0, 50)], readers=2) as r:
+        assert len(next(r)) == 16 and len(next(r)) == 16
+        with pytest.raises(OSError, match="disk went away"):
+            next(r)
+    assert cu_knn.base_geometry(rows.schema) == (8, "f32")
+
+
 def test_prefetch_keeps_two_items_alive_and_hands_errors_over():
     import time
     from neighborhoodwatch_amd.parquet_stream import Prefetch
