@@ -200,19 +200,31 @@ def stream_tiles(eng, rows: ParquetRows, tiles, readers=None):
         ps = rows.pieces(off, length)
         counts.append(len(ps))
         pieces.extend((rows, pc) for pc in ps)
-    with PieceReader(pieces, readers=readers) as reader:
+
+    def ready(t):
+        """On the reader thread, right behind the decode: the numpy views of the piece and the pointer table the library takes."""
+        kind, data = table_input(t)
+        return t, kind, (KnnEngine.prepare_columns(data) if kind == "columns" else data)
+
+    # a piece is hundreds of megabytes of arrow buffers: releasing them (munmap) is work too, and not the uploading thread's
+    with PieceReader(pieces, readers=readers, transform=ready) as reader, ThreadPoolExecutor(max_workers=1, thread_name_prefix="nw-drop") as dropper:
         for i, ((off, length), n_pieces) in enumerate(zip(tiles, counts)):
             eng.base_begin(length, dims, dtype)
             for _ in range(n_pieces):
-                t = next(reader)
-                kind, data = table_input(t)
-                if kind == "matrix":
-                    eng.base_append(data)
+                item = next(reader)
+                if item[1] == "matrix":
+                    eng.base_append(item[2])
                 else:
-                    eng.base_append_columns(data)
-                del t, data
+                    eng.base_append_columns(item[2])
+                dropper.submit(_drop, item)
+                del item
             eng.base_end()
             yield i
+
+
+def _drop(item):
+    """Runs on the drop thread: the last reference to a consumed piece dies here."""
+    del item
 
 
 def engine_search(eng, kind_data, k, metric, index_offset=0, out_device=False):
@@ -413,19 +425,20 @@ def process_batches(data_dir,
                     yield start, batch_offset, batch_length, tag, dims
 
         def write_pair(start, distances, indices, tag):
-            stream_cudf_to_parquet(get_partial_distances_filename(data_dir, start), distances, PARQUET_ROW_GROUP, tag)
-            stream_cudf_to_parquet(get_partial_indices_filename(data_dir, start), indices, PARQUET_ROW_GROUP, tag)
+            # the two files of a pair side by side (pyarrow releases the GIL while it encodes): the last tile's pair is the tail of the stage
+            return [writer.submit(stream_cudf_to_parquet, get_partial_distances_filename(data_dir, start), distances, PARQUET_ROW_GROUP, tag),
+                    writer.submit(stream_cudf_to_parquet, get_partial_indices_filename(data_dir, start), indices, PARQUET_ROW_GROUP, tag)]
 
         writes = []
         try:
-            with ThreadPoolExecutor(max_workers=1) as writer:      # the pair of tile i is written while tile i+1 is loaded and searched
+            with ThreadPoolExecutor(max_workers=2) as writer:      # the pair of tile i is written while tile i+1 is loaded and searched
                 for start, batch_offset, batch_length, tag, dims in resident_tiles():
                     assert (k <= batch_length)                              # cu_knn.py:237
                     print(f"Dataset shape: ({batch_length}, {dims}), Query shape: ({len(query_table)}, {dims})")
                     distances, indices = engine_search(eng, queries, k, metric, index_offset=batch_offset)   # + batch_offset, cu_knn.py:273
                     assert (len(distances) == len(query_table))             # cu_knn.py:281-282
                     assert (len(indices) == len(query_table))
-                    writes.append(writer.submit(write_pair, start, distances, indices, tag))
+                    writes.extend(write_pair(start, distances, indices, tag))
                     del distances, indices
                 for w in writes:
                     w.result()

@@ -252,10 +252,20 @@ class KnnEngine:
             self.synchronize()
         del keep
 
+    @classmethod
+    def prepare_columns(cls, columns):
+        """The pointer table ``base_append_columns`` hands to the library, made ahead of time (a reader thread does it next to the decode:
+        1536 columns are 1536 numpy views and ctypes pointers per piece, milliseconds the uploading thread does not have to spend)."""
+        return ("prepared",) + cls._columns(columns, "piece")
+
     def base_append_columns(self, columns) -> None:
-        """The next rows as per-dimension arrays (or lists of chunks), like ``set_base_columns``.  Returns as soon as the arrays have
-        been gathered into pinned memory: the copy to the GPU and the layout kernel overlap whatever the caller does next."""
-        table, rows_arr, n_chunks, n, dim, dt, keep = self._columns(columns, "piece")
+        """The next rows as per-dimension arrays (or lists of chunks), like ``set_base_columns`` -- or the result of ``prepare_columns``.
+        Returns as soon as the arrays have been gathered into pinned memory: the copy to the GPU and the layout kernel overlap whatever
+        the caller does next."""
+        if isinstance(columns, tuple) and columns and isinstance(columns[0], str) and columns[0] == "prepared":
+            table, rows_arr, n_chunks, n, dim, dt, keep = columns[1:]
+        else:
+            table, rows_arr, n_chunks, n, dim, dt, keep = self._columns(columns, "piece")
         if dim != self._pending[1]:
             raise ValueError(f"piece has dimension {dim}, the announced base has {self._pending[1]}")
         check(self._L.nwknn_base_append_column_chunks(self._h, table, rows_arr, n_chunks, n, dt), "nwknn_base_append_column_chunks")

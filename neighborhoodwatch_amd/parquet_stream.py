@@ -41,10 +41,13 @@ class ParquetRows:
         self._groups = []                      # (path index, row group, first row in the window's numbering, rows)
         total = 0
         schema = None
+        self._metadata = []                    # the parsed footer of every file: 1536 columns x 40 row groups is megabytes of Thrift, parsed ONCE
         for fi, path in enumerate(self.paths):
-            md = pq.read_metadata(path)
+            f = self._open(path)
+            md = f.metadata
+            self._metadata.append(md)
             if schema is None:
-                schema = pq.read_schema(path)
+                schema = f.schema_arrow
             for g in range(md.num_row_groups):
                 n = md.row_group(g).num_rows
                 if n > 0:
@@ -58,6 +61,16 @@ class ParquetRows:
         if missing:
             raise KeyError(f"columns not in {self.paths[0]}: {missing[:5]}")
         self._tls = threading.local()          # ParquetFile handles, one set per reading thread
+
+    @staticmethod
+    def _open(path, metadata=None) -> pq.ParquetFile:
+        # memory-mapped: pyarrow decodes straight from the page cache instead of read()ing every column chunk into a buffer first --
+        # 5.3 -> 14.5 GB/s of floats on the GPU box's host for the reference's layout (1536 float columns, 100 000-row groups;
+        # tools/parquet_decode_probe.py, profiles/r05h_parquet_decode_probe.log), 3.5 -> 9.8 GB/s with pyarrow's default encoding
+        try:
+            return pq.ParquetFile(path, memory_map=True, metadata=metadata)
+        except (OSError, pa.ArrowInvalid):
+            return pq.ParquetFile(path, metadata=metadata)
 
     # ---- table-like face (what compute_knn / tune_memory / process_batches use of a pyarrow.Table) ----
     def __len__(self) -> int:
@@ -93,14 +106,7 @@ class ParquetRows:
             cache = self._tls.files = {}
         f = cache.get(fi)
         if f is None:
-            # memory-mapped: pyarrow decodes straight from the page cache instead of read()ing every column chunk into a buffer first --
-            # 5.3 -> 14.5 GB/s of floats on the GPU box's host for the reference's layout (1536 float columns, 100 000-row groups;
-            # tools/parquet_decode_probe.py, profiles/r05h_parquet_decode_probe.log), 3.5 -> 9.8 GB/s with pyarrow's default encoding
-            try:
-                f = pq.ParquetFile(self.paths[fi], memory_map=True)
-            except (OSError, pa.ArrowInvalid):
-                f = pq.ParquetFile(self.paths[fi])
-            cache[fi] = f
+            f = cache[fi] = self._open(self.paths[fi], self._metadata[fi])       # a handle per reading thread, the footer parsed once for all
         return f
 
     def pieces(self, offset: int = 0, length: Optional[int] = None) -> List[Tuple[int, int, int, int, int]]:
@@ -227,8 +233,9 @@ class PieceReader:
     pieces decoded or in flight beyond the one the consumer holds.  An exception in a reader surfaces at the position of its piece."""
 
     def __init__(self, pieces: Sequence[Tuple["ParquetRows", tuple]], readers: Optional[int] = None, ahead: Optional[int] = None,
-                 ahead_bytes: int = 6 << 30):
+                 ahead_bytes: int = 6 << 30, transform: Optional[Callable] = None):
         self._pieces = list(pieces)
+        self._transform = transform              # applied to every decoded table ON ITS READER THREAD (the consumer gets the result)
         self._readers = readers or default_readers()
         if ahead is None:
             # bounded by host memory, not by count: a piece of the reference's published run is 100 000 rows x 1536 floats = 614 MB
@@ -248,14 +255,18 @@ class PieceReader:
     def _fill(self):
         while self._next < len(self._pieces) and len(self._queue) < self._ahead:
             rows, pc = self._pieces[self._next]
-            self._queue.append(self._pool.submit(rows.read_piece, pc))
+            self._queue.append(self._pool.submit(self._read, rows, pc))
             self._next += 1
         self.max_inflight = max(self.max_inflight, len(self._queue))
+
+    def _read(self, rows, pc):
+        t = rows.read_piece(pc)
+        return t if self._transform is None else self._transform(t)
 
     def __iter__(self):
         return self
 
-    def __next__(self) -> pa.Table:
+    def __next__(self):
         if not self._queue:
             raise StopIteration
         fut = self._queue.popleft()
@@ -266,7 +277,7 @@ class PieceReader:
         for f in self._queue:
             f.cancel()
         self._queue.clear()
-        self._pool.shutdown(wait=True)
+        self._pool.shutdown(wait=False)                          # idle readers wind down (and unmap their handles) behind the consumer's back
 
     def __enter__(self):
         return self

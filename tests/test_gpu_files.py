@@ -124,21 +124,23 @@ def test_dataset_api_streams_batches_and_resumes_from_its_checkpoint(dataset, or
 
     monkeypatch.setattr(eng_mod.KnnEngine, "search_columns", real_search)
     seen = []
-    real_prefetch = parquet_stream.Prefetch
+    real_reader = parquet_stream.PieceReader
 
-    class Watched(real_prefetch):
-        def __init__(self, *a, **kw):
-            super().__init__(*a, **kw)
+    class Watched(real_reader):
+        def __init__(self, pieces, **kw):
+            super().__init__(pieces, ahead=2, **kw)                                              # the bound under test (the default is sized by bytes)
             seen.append(self)
 
-    monkeypatch.setattr(cu_knn_ds, "Prefetch", Watched)
+    monkeypatch.setattr(cu_knn, "PieceReader", Watched)                                         # cu_knn.stream_tiles feeds both drivers
     calls2 = []
     monkeypatch.setattr(eng_mod.KnnEngine, "search_columns",
                         lambda self, columns, k, metric="sqeuclidean", index_offset=0, out_device=False:
                         (calls2.append(index_offset), real_search(self, columns, k, metric, index_offset, out_device))[1])
     cu_knn_ds.compute_knn_ds(data_dir, 384, qf, 300, bf, 2600, False, 10, 400, resume=True)
     assert calls2 == [1200, 1600, 2000, 2400]                                             # the first three batches were not searched again
-    assert len(seen) == 1 and seen[0].max_alive <= 2                                      # at most two batches in host memory
+    # ONE reader pool for the whole job: the row-group pieces of the remaining batches in row order (rows 1200..2599 over 700-row groups:
+    # 1200-1399 | 1400-1599, 1600-1999, 2000-2099 | 2100-2399, 2400-2599, cut at batch borders too), never more than two decoded ahead
+    assert len(seen) == 1 and seen[0].max_inflight <= 2 and len(seen[0]._pieces) == 6
     fd, fi = _final(data_dir)
     base = synth.gen_unit_rows(0x72, 0, 2600, 384); queries = synth.gen_unit_rows(0x71, 0, 300, 384)
     rd, ri = oracle.knn_canonical(base, queries, 10)
@@ -148,25 +150,34 @@ def test_dataset_api_streams_batches_and_resumes_from_its_checkpoint(dataset, or
 
 
 def test_compute_knn_reads_tiles_lazily_and_overlaps(dataset, oracle, monkeypatch):
-    """compute_knn opens the base file lazily: a tile is decoded from its own row groups on the prefetch thread while the previous
-    one is searched (two tiles alive at most), and the partial pairs -- written by a writer thread -- are the reference layout."""
+    """compute_knn opens the base file lazily and hands every tile to the GPU PIECE BY PIECE: the row groups that overlap a tile are decoded
+    by reader threads (each piece read once, nothing up front, a bounded number ahead) and appended to the engine's base as they arrive --
+    nwknn_base_begin / _append_column_chunks / _end -- while the previous tile is searched; the partial pairs -- written by a writer
+    thread -- are the reference layout."""
+    from neighborhoodwatch_amd import engine as eng_mod
     from neighborhoodwatch_amd import parquet_stream
     data_dir, qf, bf = dataset
     seen = []
-    real_prefetch = parquet_stream.Prefetch
+    real_reader = parquet_stream.PieceReader
 
-    class Watched(real_prefetch):
-        def __init__(self, *a, **kw):
-            super().__init__(*a, **kw)
+    class Watched(real_reader):
+        def __init__(self, pieces, **kw):
+            super().__init__(pieces, ahead=2, **kw)
             seen.append(self)
 
-    monkeypatch.setattr(cu_knn, "Prefetch", Watched)
-    read_calls = []
-    real_slice = parquet_stream.ParquetRows.slice
-    monkeypatch.setattr(parquet_stream.ParquetRows, "slice", lambda self, off=0, ln=None: (read_calls.append((off, ln)), real_slice(self, off, ln))[1])
+    monkeypatch.setattr(cu_knn, "PieceReader", Watched)
+    read_calls, begun, appended = [], [], []
+    real_read = parquet_stream.ParquetRows.read_piece
+    monkeypatch.setattr(parquet_stream.ParquetRows, "read_piece", lambda self, pc: (read_calls.append((pc[2], pc[4])), real_read(self, pc))[1])
+    real_begin, real_append = eng_mod.KnnEngine.base_begin, eng_mod.KnnEngine.base_append_columns
+    monkeypatch.setattr(eng_mod.KnnEngine, "base_begin", lambda self, rows, dim, dtype="f32": (begun.append(rows), real_begin(self, rows, dim, dtype))[1])
+    # (the pieces arrive prepared -- KnnEngine.prepare_columns on the reader thread: slot 4 of the tuple is the piece's row count)
+    monkeypatch.setattr(eng_mod.KnnEngine, "base_append_columns", lambda self, cols: (appended.append(cols[4]), real_append(self, cols))[1])
     cu_knn.compute_knn(data_dir, "intfloat/e5-small-v2", 384, qf, 300, bf, 2600, False, 10, 900)
-    assert read_calls == [(0, 900), (900, 900), (1800, 800)]                               # one read per tile, nothing up front
-    assert len(seen) == 1 and seen[0].max_alive <= 2
+    # tiles of 900 / 900 / 800 rows over 700-row groups: (first row, rows) of every piece, each decoded exactly once, in row order
+    assert sorted(read_calls) == [(0, 700), (700, 200), (900, 500), (1400, 400), (1800, 300), (2100, 500)]
+    assert begun == [900, 900, 800] and appended == [700, 200, 500, 400, 300, 500]
+    assert len(seen) == 1 and seen[0].max_inflight <= 2
     merge.merge_indices_and_distances(data_dir, k=10)
     fd, fi = _final(data_dir)
     base = synth.gen_unit_rows(0x72, 0, 2600, 384); queries = synth.gen_unit_rows(0x71, 0, 300, 384)
