@@ -313,6 +313,18 @@ class Bench:
                 self._ceil[dtype] = {"error": f"{type(e).__name__}: {e}"}
         return self._ceil[dtype]
 
+    def fabric(self):
+        """nwknn_fabric_probe, once per process: GB/s of a plain streaming read over 128 MiB (beyond L2, inside the Infinity Cache: where the tile
+        kernels' L2 misses are served) and over 4 GiB (HBM).  Round 4's driver box ran the fp32 tile kernel 2 % slower than the builder's boxes
+        at the SAME bare MFMA rate; this is the figure that says whether a box's fabric is what differs."""
+        if not hasattr(self, "_fabric"):
+            try:
+                self._fabric = {"fabric_probe_gbs": self.eng.fabric_probe(128 << 20, 0.05), "hbm_probe_gbs": self.eng.fabric_probe(4 << 30, 0.05),
+                                "fabric_probe_note": "plain streaming read kernel, 50 ms each: 128 MiB working set (Infinity Cache) / 4 GiB (HBM)"}
+            except Exception as e:
+                self._fabric = {"fabric_probe_error": f"{type(e).__name__}: {e}"}
+        return self._fabric
+
     # ---- what torch.distributed saw ---------------------------------------------------------------------------------------------
     def devices(self):
         torch, td = self.torch, self.td
@@ -365,7 +377,7 @@ class Bench:
             """n_warmup untimed + n_steps timed steps, fenced on both sides; MAX over ranks of the elapsed time, SUM of the kernel accounting."""
             agg = {"tile_ms": 0.0, "tile_flops": 0.0, "tile_launches": 0, "compact_ms": 0.0, "prep_ms": 0.0, "rescan_launches": 0,
                    "overflowed_queries": 0, "rescore_ms": 0.0, "prescreen": 0, "prescreen_checked": 0, "prescreen_violations": 0,
-                   "prescreen_fallbacks": 0}
+                   "prescreen_fallbacks": 0, "walk_calibrated": 0, "walk_query_fastest": 0, "walk_ms_base_fastest": 0.0, "walk_ms_query_fastest": 0.0}
             worst = [0.0]
             coll = {}
             last = None
@@ -436,6 +448,13 @@ class Bench:
                       "bare_loop_note": "nwknn_mfma_ceiling on this device: the same MFMA instruction back to back on random operands in registers, "
                                         "same register tile and waves per SIMD, no operand traffic, no epilogue"}
                      if bare.get("tflops") else ({"bare_loop_error": bare["error"]} if "error" in bare else {}))
+            if world == 1:
+                extra.update(self.fabric())
+            if agg_.get("walk_calibrated"):
+                n_c = agg_["walk_calibrated"]
+                extra["walk"] = {"calibrated_searches": n_c, "query_fastest_chosen": agg_["walk_query_fastest"],
+                                 "ms_base_fastest_8x8": agg_["walk_ms_base_fastest"] / n_c, "ms_query_fastest_2x32": agg_["walk_ms_query_fastest"] / n_c,
+                                 "note": "two full-size chunks of every search are timed, one under each super-tile walk; the rest of the walk runs the faster (nwknn_stats.walk_*)"}
             return {"bound": "mfma", "achieved": ach, "peak": pk, "unit": "TFLOP/s", "frac": ach / pk, **extra, "traffic": traffic,
                     "traffic_note": "bytes per launch, rocprofv3 PMC passes recorded in profiles/ (not sampled live; quoted only when recorded on this kernel)",
                     "kernel": kernel, "launches": n_l, "avg_launch_ms": agg_["tile_ms"] / n_l, "flops_per_launch": agg_["tile_flops"] / n_l}

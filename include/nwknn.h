@@ -75,6 +75,13 @@ typedef struct nwknn_stats {
     int64_t prescreen_checked;     /* pairs compared in the attempt that produced the result */
     int64_t prescreen_violations;  /* pairs outside the bound, summed over the DISCARDED attempts (the returned result has none by construction) */
     double prescreen_worst;        /* max |estimate - exact| / bound over the checked pairs of the returned result (< 1; ~0.05-0.3 measured) */
+    /* Walk calibration of the direct fp32 kernel (options super_q_shift / super_walk_q left at auto, at least six full-size chunks): two
+     * consecutive full-size chunks are timed, one under each walk order of an XCD's super-tile (8 x 8 tiles base-tile-fastest; 2 x 32
+     * query-tile-fastest, which moves ~38 % fewer bytes beyond L2), and the rest of the walk runs the faster one.  Which is faster depends
+     * on the device's fabric / Infinity Cache, not on the data; the result is the same bits either way. */
+    int32_t walk_calibrated;       /* 1 when the two timed chunks ran in this search */
+    int32_t walk_query_fastest;    /* the walk the remaining chunks ran: 0 = 8 x 8 base fastest, 1 = 2 x 32 query fastest */
+    double walk_ms_base_fastest, walk_ms_query_fastest;   /* the two timed chunks (equal row counts), milliseconds */
 } nwknn_stats;
 
 /* ---- library / device ------------------------------------------------------------------------------- */
@@ -84,6 +91,11 @@ int nwknn_device_count(void);
 /* free/total bytes of HBM on a device.  Replaces the NVML query in tune_memory(), cu_knn.py:62-71 and
  * get_gpu_memory(), cu_knn_ds.py:30-36. */
 int nwknn_mem_info(int device, size_t* free_bytes, size_t* total_bytes);
+/* Read rate, GB/s, of a plain streaming kernel over a working set of `bytes` read again and again for `seconds` (a multiple of 1 MiB, at most
+ * 16 GiB): 128 MiB sits beyond the 8 x 4 MiB of L2 and inside the 256 MiB Infinity Cache -- the path the tile kernels' L2 misses take, and the
+ * part of a device that differs between boxes when their MFMA pipes do not; 4 GiB measures HBM.  bench.py prints both next to the bare MFMA
+ * loop (roofline.fabric_probe_gbs / hbm_probe_gbs) so that a slow line can be told apart from a slow box.  No reference counterpart. */
+int nwknn_fabric_probe(nwknn_handle h, int64_t bytes, double seconds, double* out_gbs);
 
 /* ---- handle ------------------------------------------------------------------------------------------ */
 /* One handle = one GPU's share of the job (the reference hard-codes device 0, cu_knn.py:65). */

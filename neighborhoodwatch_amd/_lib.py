@@ -31,7 +31,7 @@ EXPORTS = [
     "nwknn_base_begin", "nwknn_base_append", "nwknn_base_append_column_chunks", "nwknn_base_end",
     "nwknn_maxsim_set_docs", "nwknn_maxsim_search", "nwknn_tile_kernel_name",
     "nwknn_comm_create", "nwknn_comm_destroy", "nwknn_comm_device_count", "nwknn_comm_engine", "nwknn_comm_set_option",
-    "nwknn_comm_set_base", "nwknn_comm_generate_base", "nwknn_search_sharded", "nwknn_comm_get_stats", "nwknn_comm_merge_lists", "nwknn_mfma_ceiling", "nwknn_pair_distances", "nwknn_pair_dots",
+    "nwknn_comm_set_base", "nwknn_comm_generate_base", "nwknn_search_sharded", "nwknn_comm_get_stats", "nwknn_comm_merge_lists", "nwknn_mfma_ceiling", "nwknn_fabric_probe", "nwknn_pair_distances", "nwknn_pair_dots",
     "nwknn_comm_maxsim_set_docs", "nwknn_maxsim_search_sharded",
 ]
 
@@ -44,6 +44,7 @@ class NwknnStats(ctypes.Structure):
         ("tile_ms", c_double), ("compact_ms", c_double), ("prep_ms", c_double), ("total_ms", c_double),
         ("tile_flops", c_double), ("rescore_ms", c_double), ("prescreen", c_int32), ("prescreen_fallbacks", c_int32),
         ("prescreen_checked", c_int64), ("prescreen_violations", c_int64), ("prescreen_worst", c_double),
+        ("walk_calibrated", c_int32), ("walk_query_fastest", c_int32), ("walk_ms_base_fastest", c_double), ("walk_ms_query_fastest", c_double),
     ]
 
     def as_dict(self) -> dict:
@@ -169,6 +170,7 @@ def load() -> ctypes.CDLL:
     L.nwknn_pair_distances.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int32, c_int, c_int64, c_void_p, c_int]
     L.nwknn_pair_dots.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int32, c_int64, c_void_p, c_int]
     L.nwknn_mfma_ceiling.argtypes = [c_void_p, c_int, c_double, POINTER(c_double), POINTER(c_double)]
+    L.nwknn_fabric_probe.argtypes = [c_void_p, c_int64, c_double, POINTER(c_double)]
     L.nwknn_comm_merge_lists.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int, c_void_p, c_void_p]
     L.nwknn_comm_maxsim_set_docs.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int]
     L.nwknn_maxsim_search_sharded.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int, c_int32, c_void_p, c_void_p]

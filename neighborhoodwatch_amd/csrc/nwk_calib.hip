@@ -104,7 +104,31 @@ __global__ __launch_bounds__(256, 3) void nwk_mfma_bare_f32_kernel(const float* 
     if (s == 12345.678f) out[blockIdx.x].sink = s;
 }
 
+// fabric / HBM probe: every lane streams 16-B loads over the working set, pass after pass; nothing is written but one word per workgroup
+__global__ __launch_bounds__(256) void nwk_stream_read_kernel(const f32x4* __restrict__ src, long long n16, int passes, float* __restrict__ sink)
+{
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const long long stride = (long long)gridDim.x * 256;
+    for (int p = 0; p < passes; ++p)
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += 4 * stride) {
+            // four independent loads in flight per lane
+            const f32x4 a = src[i];
+            const f32x4 b = i + stride < n16 ? src[i + stride] : acc;
+            const f32x4 c = i + 2 * stride < n16 ? src[i + 2 * stride] : acc;
+            const f32x4 d = i + 3 * stride < n16 ? src[i + 3 * stride] : acc;
+            acc += (a + b) + (c + d);
+        }
+    const float s = acc[0] + acc[1] + acc[2] + acc[3];
+    if (s == 12345.678f) sink[blockIdx.x] = s;                       // never true on the zero-filled buffer: keeps the loads alive
+}
+
 extern "C++" {
+
+hipError_t nwk_launch_stream_read(hipStream_t st, const void* src, long long bytes, int passes, unsigned grid, float* sink)
+{
+    hipLaunchKernelGGL(nwk_stream_read_kernel, dim3(grid), dim3(256), 0, st, (const f32x4*)src, bytes / 16, passes, sink);
+    return hipGetLastError();
+}
 
 // One launch: `grid` workgroups x `iters` loop iterations.  FLOPs per launch = grid x waves x iters x 64 MFMAs x 2 x M x N x K.
 // waves_per_simd: how many of these MFMA-only waves share a SIMD (f16: 1 = four-wave workgroups, one per CU; 2 = the eight-wave workgroup of

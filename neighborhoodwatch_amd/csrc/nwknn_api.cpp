@@ -105,6 +105,8 @@ struct nwknn_ctx {
     void* pin[2] = {nullptr, nullptr};
     size_t pin_bytes = 0;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_prepped[2] = {nullptr, nullptr};
+    hipEvent_t ev_cal[3] = {nullptr, nullptr, nullptr};      // walk calibration of the direct fp32 kernel (search_attempt)
+    int walk_auto_q = 0, walk_auto_sq = 3;                   // what "auto" means for the fp32 kernel's super-tile walk in the current search
     long long up_seq = 0;           // slabs the column upload pipeline has sent so far (never reset: the two pinned / device slabs alternate across calls)
     // base shard
     DevBuf bp, bn, braw;
@@ -266,6 +268,7 @@ extern "C" int nwknn_destroy(nwknn_handle h)
         if (h->ev_h2d[i]) (void)hipEventDestroy(h->ev_h2d[i]);
         if (h->ev_prepped[i]) (void)hipEventDestroy(h->ev_prepped[i]);
     }
+    for (int i = 0; i < 3; ++i) if (h->ev_cal[i]) (void)hipEventDestroy(h->ev_cal[i]);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
@@ -888,8 +891,8 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
     // 31 % fewer bytes and is 1 % slower).  Neither kernel is bound by that traffic (the Infinity Cache serves it), so speed
     // decides; options super_q_shift / super_walk_q select the other walks.
     const bool fp32_kernel = !(h->f16 || prescreen);
-    if (h->opt_sq_shift < 0) tp.sq_shift = fp32_kernel ? 3 : 4;
-    if (h->opt_walk_q < 0) tp.walk_q_fastest = 0;
+    if (h->opt_sq_shift < 0) tp.sq_shift = fp32_kernel ? h->walk_auto_sq : 4;
+    if (h->opt_walk_q < 0) tp.walk_q_fastest = fp32_kernel ? h->walk_auto_q : 0;
     // rows per base tile of the kernel the launchers below will pick: 128 for the fp32 kernel, 256 for the fp16 kernels
     const int btile = (h->f16 || prescreen) ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS;
     if (rows % btile != 0) return fail(NWKNN_EINVAL, "internal: chunk of %lld rows is not a whole number of %d-row tiles", rows, btile);
@@ -1161,12 +1164,41 @@ static int search_attempt(nwknn_ctx* h, const void* queries, const ColumnSource*
     long long growth = h->opt_chunk_growth;
     if (growth <= 0) growth = std::max<long long>(1, std::min<long long>(3, (long long)((0.8 * pl.cap / k - 1.0) / 1.5)));
     long long seen = std::min(h->nb_pad, pl.first);
+    h->walk_auto_q = 0; h->walk_auto_sq = 3;
     RCCHK(run_chunk(h, pl, metric, k, nq_pad, 0, seen, true, nullptr, 0, false, false));
+    // Walk calibration (direct fp32 kernel, walk options at auto).  Which super-tile walk is faster is decided by the device's fabric, not by
+    // the data: 8 x 8 base-fastest won by 0.27 % on the builder's boxes, 2 x 32 query-fastest moves 38 % fewer bytes beyond L2 -- and the
+    // driver's box of round 4 ran the same kernel 2 % slower with the same MFMA ceiling.  So the first two full-size chunks are timed, one
+    // under each walk, and the rest of the walk -- at least four more chunks, or it is not worth two event waits -- runs the faster.
+    bool calibrate = !h->f16 && !pl.pre && h->opt_walk_q < 0 && h->opt_sq_shift < 0;
     while (seen < h->nb_pad) {
         const long long m = std::min(std::min(pl.max_chunk, seen * growth), h->nb_pad - seen);
+        if (calibrate && m == pl.max_chunk && h->nb_pad - seen >= 6 * pl.max_chunk) {
+            calibrate = false;
+            for (int i = 0; i < 3; ++i) if (!h->ev_cal[i]) HIPCHK(hipEventCreate(&h->ev_cal[i]));
+            HIPCHK(hipEventRecord(h->ev_cal[0], h->stream));
+            RCCHK(run_chunk(h, pl, metric, k, nq_pad, seen, m, false, nullptr, 0, false, false));
+            HIPCHK(hipEventRecord(h->ev_cal[1], h->stream));
+            h->walk_auto_q = 1; h->walk_auto_sq = 1;
+            RCCHK(run_chunk(h, pl, metric, k, nq_pad, seen + m, m, false, nullptr, 0, false, false));
+            HIPCHK(hipEventRecord(h->ev_cal[2], h->stream));
+            HIPCHK(hipEventSynchronize(h->ev_cal[2]));
+            float a = 0.f, b = 0.f;
+            HIPCHK(hipEventElapsedTime(&a, h->ev_cal[0], h->ev_cal[1]));
+            HIPCHK(hipEventElapsedTime(&b, h->ev_cal[1], h->ev_cal[2]));
+            // (both spans hold one tile launch and one compaction of equal size; the later chunk filters under a slightly tighter
+            // threshold -- a few survivors fewer in a million rows -- which is far inside the differences this is after)
+            const bool q_fastest = b < a;
+            h->walk_auto_q = q_fastest ? 1 : 0; h->walk_auto_sq = q_fastest ? 1 : 3;
+            h->stats.walk_calibrated = 1; h->stats.walk_query_fastest = q_fastest ? 1 : 0;
+            h->stats.walk_ms_base_fastest = a; h->stats.walk_ms_query_fastest = b;
+            seen += 2 * m;
+            continue;
+        }
         RCCHK(run_chunk(h, pl, metric, k, nq_pad, seen, m, false, nullptr, 0, false, false));
         seen += m;
     }
+    h->walk_auto_q = 0; h->walk_auto_sq = 3;                       // repairs and later searches start from the default again
 
     u32 any = 0;
     HIPCHK(hipMemcpyAsync(&any, h->ovf_any.p, 4, hipMemcpyDeviceToHost, h->stream));
@@ -1632,6 +1664,45 @@ extern "C" int nwknn_pair_dots(nwknn_handle h, const void* queries, int64_t nq, 
 }
 
 // ---- device calibration ---------------------------------------------------------------------------------------------------------------
+extern "C" int nwknn_fabric_probe(nwknn_handle h, int64_t bytes, double seconds, double* out_gbs)
+{
+    if (!h || !out_gbs) return fail(NWKNN_EINVAL, "nwknn_fabric_probe: null argument");
+    if (bytes < (1ll << 20) || bytes > (16ll << 30) || bytes % (1ll << 20) != 0) return fail(NWKNN_EINVAL, "nwknn_fabric_probe: bytes must be a multiple of 1 MiB in [1 MiB, 16 GiB]");
+    if (!(seconds > 0.0) || seconds > 10.0) return fail(NWKNN_EINVAL, "nwknn_fabric_probe: seconds must be in (0, 10]");
+    RCCHK(use_device(h));
+    void* buf = nullptr;
+    hipError_t me = hipMalloc(&buf, (size_t)bytes + 4096 * 4);
+    if (me != hipSuccess) return fail(NWKNN_ENOMEM, "nwknn_fabric_probe: hipMalloc(%lld bytes) failed: %s", (long long)bytes, hipGetErrorString(me));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = NWKNN_OK;
+    auto done = [&](int code) { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); (void)hipFree(buf); return code; };
+    if (hipMemsetAsync(buf, 0, (size_t)bytes + 4096 * 4, h->stream) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return done(fail(NWKNN_EHIP, "nwknn_fabric_probe: setup failed: %s", hipGetErrorString(hipGetLastError())));
+    const unsigned grid = (unsigned)h->num_cu * 8u;
+    float* sink = (float*)((char*)buf + bytes);
+    // passes per launch: ~4 ms of work at 4 TB/s, so that a launch is long against its own start-up; launches until `seconds` have passed
+    const int passes = (int)std::max<long long>(1, (16ll << 30) / bytes / 1);
+    double total_bytes = 0.0;
+    // warm: one launch (brings the working set to where it will live), then timed launches
+    if (nwk_launch_stream_read(h->stream, buf, bytes, 1, grid, sink) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+        return done(fail(NWKNN_EHIP, "nwknn_fabric_probe: launch failed: %s", hipGetErrorString(hipGetLastError())));
+    const auto t_begin = std::chrono::steady_clock::now();
+    if (hipEventRecord(e0, h->stream) != hipSuccess) return done(fail(NWKNN_EHIP, "hipEventRecord failed"));
+    do {
+        if (nwk_launch_stream_read(h->stream, buf, bytes, passes, grid, sink) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+            rc = fail(NWKNN_EHIP, "nwknn_fabric_probe: launch failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+        total_bytes += (double)bytes * passes;
+    } while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() < seconds);
+    if (rc != NWKNN_OK) return done(rc);
+    float ms = 0.f;
+    if (hipEventRecord(e1, h->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+        return done(fail(NWKNN_EHIP, "nwknn_fabric_probe: timing failed"));
+    *out_gbs = ms > 0.f ? total_bytes / 1e9 / (ms * 1e-3) : 0.0;
+    return done(NWKNN_OK);
+}
+
 extern "C" int nwknn_mfma_ceiling(nwknn_handle h, int dtype, double seconds, double* out_tflops, double* out_clock_ghz)
 {
     if (!h || !out_tflops) return fail(NWKNN_EINVAL, "nwknn_mfma_ceiling: null argument");

@@ -140,5 +140,6 @@ hipError_t nwk_launch_pairs_to_keys(hipStream_t st, const long long* idx, long l
 hipError_t nwk_launch_pair_dots(hipStream_t st, int rows16, const void* qp, const void* bp, const long long* idx, long long nq, int k, int dp,
                                 long long index_offset, long long nb, double* out);
 hipError_t nwk_launch_keys_to_distances(hipStream_t st, const unsigned long long* buf, long long nq, int k, int cap, float* out);
+hipError_t nwk_launch_stream_read(hipStream_t st, const void* src, long long bytes, int passes, unsigned grid, float* sink);   // nwk_calib.hip: streaming read of `bytes`, `passes` times
 hipError_t nwk_launch_mfma_bare(hipStream_t st, int f16, int waves_per_simd, const void* rnd, int iters, unsigned grid, void* out);   // nwk_calib.hip: one launch of the bare MFMA loop; out: grid x {u64 cycles, u64 realtime (100 MHz), float}
 int nwknn_internal_fail(int code, const char* msg);        // sets the calling thread's nwknn_last_error() message, returns code

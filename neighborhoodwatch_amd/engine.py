@@ -515,6 +515,12 @@ class KnnEngine:
               "nwknn_mfma_ceiling")
         return {"tflops": tf.value, "clock_ghz": clk.value}
 
+    def fabric_probe(self, nbytes: int = 128 << 20, seconds: float = 0.05) -> float:
+        """GB/s a plain streaming read kernel gets over a working set of ``nbytes`` (128 MiB: beyond L2, inside the Infinity Cache; 4 GiB: HBM)."""
+        out = ctypes.c_double()
+        check(self._L.nwknn_fabric_probe(self._h, int(nbytes), float(seconds), ctypes.byref(out)), "nwknn_fabric_probe")
+        return out.value
+
     def generate(self, seed: int, row0: int, rows: int, dim: int, dtype: str = "f32"):
         """Seeded synthetic rows straight into HBM (torch CUDA tensor [rows, dim], float32 or float16)."""
         import torch

@@ -392,6 +392,46 @@ def test_a_base_handed_over_in_pieces_gives_the_bits_of_the_whole(oracle, mode):
         assert np.array_equal(idx, ri) and _same_bits(dist, rd)
 
 
+def test_walk_calibration_times_both_super_tile_walks_and_keeps_the_bits(oracle):
+    """The direct fp32 kernel times two consecutive full-size chunks, one under each walk of an XCD's super-tile (8 x 8 base-tile-fastest,
+    2 x 32 query-tile-fastest), and runs the rest under the faster one (nwknn_stats.walk_*): the walks differ in what they share through L2,
+    which of them wins is a property of the device's fabric.  With max_chunk = 2048 rows a 40 000-row base has 18 full-size chunks, so the
+    calibration runs; the result is the oracle's bits whichever walk was chosen, and a forced walk is left alone."""
+    from neighborhoodwatch_amd import KnnEngine
+    base, queries = oracle.gen(0xAB, 0, 40_000, 64), oracle.gen(0xAC, 0, 700, 64)
+    rd, ri = oracle.knn_canonical(base, queries, 30)
+    with KnnEngine(0) as eng:
+        eng.set_option("max_chunk", 2048)
+        eng.set_base(base)
+        dist, idx = eng.search(queries, 30)
+        st = eng.stats()
+        assert st["walk_calibrated"] == 1 and st["walk_query_fastest"] in (0, 1) and st["walk_ms_base_fastest"] > 0 and st["walk_ms_query_fastest"] > 0
+        assert (st["walk_ms_query_fastest"] < st["walk_ms_base_fastest"]) == bool(st["walk_query_fastest"])
+        assert np.array_equal(idx, ri) and _same_bits(dist, rd)
+        for walk in (0, 1):
+            eng.set_option("super_walk_q", walk)
+            dist, idx = eng.search(queries, 30)
+            assert eng.stats()["walk_calibrated"] == 0
+            assert np.array_equal(idx, ri) and _same_bits(dist, rd)
+        eng.set_option("super_walk_q", -1)
+        eng.set_prescreen(True); eng.set_base(base)
+        dist, idx = eng.search(queries, 30)                               # the pre-screened walk runs the fp16 kernels: nothing to calibrate
+        assert eng.stats()["walk_calibrated"] == 0 and np.array_equal(idx, ri) and _same_bits(dist, rd)
+        # a short walk (default chunk sizes: the whole base is three chunks) is not worth two event waits
+        eng.set_prescreen(False); eng.set_option("max_chunk", 1 << 20); eng.set_base(base)
+        dist, idx = eng.search(queries, 30)
+        assert eng.stats()["walk_calibrated"] == 0 and np.array_equal(idx, ri) and _same_bits(dist, rd)
+
+
+def test_fabric_probe_reports_a_plausible_rate(engine):
+    """nwknn_fabric_probe: a streaming read over 128 MiB (Infinity Cache) must beat one over 2 GiB (HBM), and both are TB/s, not GB/s."""
+    mall = engine.fabric_probe(128 << 20, 0.03)
+    hbm = engine.fabric_probe(2 << 30, 0.03)
+    assert 1500.0 < hbm < 8500.0 and mall > 0.9 * hbm, (mall, hbm)
+    with pytest.raises(ValueError):
+        engine.fabric_probe(12345, 0.01)
+
+
 def test_plain_python_lists_are_columns_not_chunk_lists(engine, oracle):
     """A column passed as a plain Python list of numbers is ONE chunk (np.asarray), as before chunk lists existed; a column whose
     elements are neither scalars nor 1-D chunks is refused with a ValueError, not an IndexError."""
