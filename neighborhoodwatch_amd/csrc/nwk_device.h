@@ -85,6 +85,22 @@ __device__ __forceinline__ float distance_epilogue(float dot, float qn, float bn
     return __fsub_rn(1.0f, __fdiv_rn(dot, __fmul_rn(sqrtf(qn), sqrtf(bn))));
 }
 
+// The same value from STAGED operands: for cosine the tile kernels keep the correctly rounded roots -- sqrtf(qn) per query row in LDS
+// (stage_query_side), sqrtf(bn) per column in a register, each computed once per tile -- so that a block's exact pass is one multiply, one
+// correctly rounded division and one subtraction per element instead of two more root sequences: the same operations on the same values
+// as the canonical expression above, hence the same bits.  (Not for the pre-screen kernels, PRE = 1: their keys are estimates.)
+template <int METRIC>
+__device__ __forceinline__ float distance_from_staged(float dot, float qs, float bs)
+{
+    if (METRIC == NWKNN_METRIC_COSINE) return __fsub_rn(1.0f, __fdiv_rn(dot, __fmul_rn(qs, bs)));
+    return distance_epilogue<METRIC>(dot, qs, bs);
+}
+template <int METRIC, int PRE>
+__device__ __forceinline__ float staged_norm(float n)
+{
+    return (METRIC == NWKNN_METRIC_COSINE && !PRE) ? sqrtf(n) : n;
+}
+
 // make a pointer provably wave-uniform (SGPR pair) so that global_load_lds takes the saddr + 32-bit voffset form
 __device__ __forceinline__ const char* uniform_ptr(const char* q)
 {
@@ -167,7 +183,15 @@ typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 //     one_minus_dot : 1 - dot <= tau_d           <=>  dot >= 1 - tau_d
 // so the common case costs one add and one compare per accumulator.  The row part is lowered by a margin that covers
 // every rounding of the canonical fp32 evaluation (a few ulps of the operands), which makes the test a strict superset of
-// the exact one; whatever passes it is re-evaluated exactly.  Cosine has no additive split and pre-tests on the distance.
+// the exact one; whatever passes it is re-evaluated exactly.
+// Cosine splits MULTIPLICATIVELY:  1 - dot / (sqrt(qn) sqrt(bn)) <= tau_d   <=>  dot >= (1 - tau_d) sqrt(qn) * sqrt(bn),  a row term times a
+// column term -- one multiply and one compare per accumulator.  (Rounds 1-4 pre-tested on the distance itself: two correctly rounded square
+// roots and a division per accumulator, 38 spilled registers at three workgroups per CU.)  The canonical evaluation rounds five times
+// (two roots, their product, the quotient, the subtraction: < 6e-7 relative on T = 1 - tau_d and on tau_d); the row term is lowered by
+// 2e-6 (|T| + |tau_d| + 1) and then by 4e-6 of its magnitude, which also covers the bare v_sqrt_f32 (1 ulp) used for the two terms and the
+// product in the test.  A row or column whose squared norm is outside [2^-80, 2^80] (zero rows, Inf, NaN) gets a term that makes every
+// comparison come out "maybe" (-inf, or NaN: the test is !(acc < thr)), so the canonical arithmetic decides those pairs, NaN and all.
+__device__ __forceinline__ bool cosine_norm_ok(float n);
 template <int METRIC>
 __device__ __forceinline__ float prefilter_row(float qn, u64 tau)
 {
@@ -175,12 +199,17 @@ __device__ __forceinline__ float prefilter_row(float qn, u64 tau)
     const float td = unsortable_f32((u32)(tau >> 32));
     if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) return 0.5f * (qn - td) - 1.0e-6f * (fabsf(qn) + fabsf(td)) - 1.0e-30f;
     if (METRIC == NWKNN_METRIC_ONE_MINUS_DOT) return (1.0f - td) - 1.0e-6f * (1.0f + fabsf(td));
-    return td;                                                        // cosine: compared against the distance itself
+    if (!cosine_norm_ok(qn)) return -__builtin_inff();
+    const float t = 1.0f - td;
+    const float tm = t - 2.0e-6f * (fabsf(t) + fabsf(td) + 1.0f);
+    const float sq = __builtin_amdgcn_sqrtf(qn);
+    return tm * sq - 4.0e-6f * fabsf(tm) * sq;                        // times prefilter_col = sqrt(bn): a lower bound of T sqrt(qn) sqrt(bn) whatever its sign
 }
 template <int METRIC>
 __device__ __forceinline__ float prefilter_col(float bn)
 {
     if (METRIC == NWKNN_METRIC_SQEUCLIDEAN) return 0.5f * bn - 1.0e-6f * fabsf(bn);
+    if (METRIC == NWKNN_METRIC_COSINE) return cosine_norm_ok(bn) ? __builtin_amdgcn_sqrtf(bn) : __builtin_nanf("");
     return 0.0f;
 }
 
@@ -225,10 +254,12 @@ __device__ __forceinline__ void tile_epilogue(const NwkTileParams& p, const f32x
                                               long long q0, int wrow0, int h, int c32)
 {
     const int cap = p.cap;
-    float cpre[2];
+    float cpre[2], bs[2];
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < 2; ++n) {
         cpre[n] = colok[n] ? (PRE ? prescreen_col<METRIC>(bnv[n], p) : prefilter_col<METRIC>(bnv[n])) : __builtin_inff();   // padding columns never pass
+        bs[n] = staged_norm<METRIC, PRE>(bnv[n]);                    // cosine: sqrtf(bn), once per tile (s_qn holds sqrtf(qn): stage_query_side)
+    }
     // PRE: acc = S*dot16 is tested against the scaled row + column terms of the pre-screen bound (carrying the column term in
     // the accumulators from the start saves one add per element but keeps 128 registers live through the prologue: it spilled)
 #pragma unroll
@@ -242,7 +273,7 @@ __device__ __forceinline__ void tile_epilogue(const NwkTileParams& p, const f32x
             for (int n = 0; n < 2; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float dist = distance_epilogue<METRIC>(acc[m][n][r], qn4[r >> 2][r & 3], bnv[n]);
+                    const float dist = distance_from_staged<METRIC>(acc[m][n][r], qn4[r >> 2][r & 3], bs[n]);
                     const int row = rb + (r & 3) + 8 * (r >> 2);
                     const u32 sd = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? (__float_as_uint(dist) | 0x80000000u) : sortable_u32(dist);
                     const long long slot = (long long)(colv[n] - (u32)p.dense_col0);
@@ -258,12 +289,9 @@ __device__ __forceinline__ void tile_epilogue(const NwkTileParams& p, const f32x
             bool maybe = false;
             if (METRIC == NWKNN_METRIC_COSINE && !PRE) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rb + (r & 3) + 8 * (r >> 2);
-                    const float dist = distance_epilogue<METRIC>(acc[m][n][r], s_qn[row], bnv[n]);
-                    maybe |= !(dist > pre4[r >> 2][r & 3]);
-                }
-                maybe &= colok[n];
+                for (int r = 0; r < 16; ++r)
+                    maybe |= !(acc[m][n][r] < pre4[r >> 2][r & 3] * cpre[n]);   // NaN (a degenerate row or column) falls through
+                maybe &= colok[n];                                   // (+inf times a negative row term would pass a padding column)
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -291,7 +319,7 @@ __device__ __forceinline__ void tile_epilogue(const NwkTileParams& p, const f32x
                         pass[i] = !(acc[m][n][4 * j + i] < pre4[j][i] + cpre[n]) & colok[n];
                         continue;
                     }
-                    const float dist = distance_epilogue<METRIC>(acc[m][n][4 * j + i], qn4[i], bnv[n]);
+                    const float dist = distance_from_staged<METRIC>(acc[m][n][4 * j + i], qn4[i], bs[n]);
                     const u32 sd = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? (__float_as_uint(dist) | 0x80000000u)   // dist >= +0, never NaN
                                                                          : sortable_u32(dist);
                     key[i] = ((u64)sd << 32) | colv[n];
@@ -327,14 +355,14 @@ __device__ __forceinline__ void stage_query_side(char* lds, int rows, int tid, f
     u64* s_tau = (u64*)(lds + rows * 4);
     float* s_pre = (float*)(lds + rows * 12);
     if (tid < rows) {
-        s_qn[tid] = my_qn;
+        s_qn[tid] = staged_norm<METRIC, PRE>(my_qn);                  // cosine (direct filter): the correctly rounded root, see distance_from_staged
         if (!DENSE) {
             s_tau[tid] = my_tau;
             float pre = PRE ? prescreen_row<METRIC>(my_qn, my_tau, p) : prefilter_row<METRIC>(my_qn, my_tau);
             // padding query rows (all zero) must list nothing: with one_minus_dot / cosine they tie with every base row, which
             // the pre-screen cannot break by index and would list wholesale.  (The direct cosine test is on the distance: -inf.)
             if (p.nq_valid > 0 && q0 + tid >= p.nq_valid)
-                pre = (METRIC == NWKNN_METRIC_COSINE && !PRE) ? -__builtin_inff() : __builtin_inff();
+                pre = __builtin_inff();
             s_pre[tid] = pre;
         }
     }

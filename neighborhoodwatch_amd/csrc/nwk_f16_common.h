@@ -200,6 +200,9 @@ __device__ __forceinline__ void tile_epilogue16(const NwkTileParams& p, const f3
                                                 u32 block_mask = 0xFFu)
 {
     const int cap = p.cap;
+    float bs[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) bs[n] = staged_norm<METRIC, PRE>(bnv[n]);   // cosine, direct filter: sqrtf(bn) once per tile (nwk_device.h, distance_from_staged)
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         if (!((block_mask >> m) & 1u)) continue;                     // wave-uniform: prescreen_block_mask cleared this block
@@ -217,7 +220,7 @@ __device__ __forceinline__ void tile_epilogue16(const NwkTileParams& p, const f3
                                                                                : 1.0f - sdot * p.pre_inv_scale;
                         hi = __float_as_uint(est);
                     } else {
-                        const float dist = distance_epilogue<METRIC>(acc[m][n][i], qn4[i], bnv[n]);
+                        const float dist = distance_from_staged<METRIC>(acc[m][n][i], qn4[i], bs[n]);
                         hi = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? (__float_as_uint(dist) | 0x80000000u) : sortable_u32(dist);
                     }
                     const long long slot = (long long)(colv[n] - (u32)p.dense_col0);
@@ -227,13 +230,12 @@ __device__ __forceinline__ void tile_epilogue16(const NwkTileParams& p, const f3
         }
         const f32x4 pre4 = *(const f32x4*)(s_pre + rb);
         bool maybe = false;
-        if (METRIC == NWKNN_METRIC_COSINE && !PRE) {
-            const f32x4 qn4 = *(const f32x4*)(s_qn + rb);
+        if (METRIC == NWKNN_METRIC_COSINE && !PRE) {              // the multiplicative split of prefilter_row / prefilter_col (nwk_device.h)
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 bool mn = false;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) mn |= !(distance_epilogue<METRIC>(acc[m][n][i], qn4[i], bnv[n]) > pre4[i]);
+                for (int i = 0; i < 4; ++i) mn |= !(acc[m][n][i] < pre4[i] * cpre[n]);
                 maybe |= mn & colok[n];
             }
         } else if (PRE) {
@@ -334,7 +336,7 @@ __device__ __forceinline__ void tile_epilogue16(const NwkTileParams& p, const f3
                     pass[i] = !(acc[m][n][i] < pre4[i] + cpre[n]) & colok[n];
                     continue;
                 }
-                const float dist = distance_epilogue<METRIC>(acc[m][n][i], qn4[i], bnv[n]);
+                const float dist = distance_from_staged<METRIC>(acc[m][n][i], qn4[i], bs[n]);
                 const u32 sd = (METRIC == NWKNN_METRIC_SQEUCLIDEAN) ? (__float_as_uint(dist) | 0x80000000u) : sortable_u32(dist);
                 key[i] = ((u64)sd << 32) | colv[n];
                 const u64 tau = (i & 2) ? th[i & 1] : tl[i & 1];

@@ -24,11 +24,15 @@ def metadata():
 
 def test_fp32_tile_kernel_keeps_three_workgroups_per_cu(metadata):
     md = metadata["f32"]
-    for metric, max_spill in ((0, 7), (1, 7), (2, 40)):       # cosine's epilogue (two square roots and a division per output) is the heavy one
+    # cosine pre-tested on the distance until round 5 -- two correctly rounded roots and a division per accumulator, 38 spilled registers;
+    # now a multiplicative split (row term x column term) with the roots staged once per tile: 10, every one of them stored in the prologue or
+    # the epilogue.  What the speed depends on is asserted directly: NO scratch access inside the loop that issues the MFMAs.
+    for metric, max_spill in ((0, 7), (1, 7), (2, 12)):
         k = md[f"nwk_tile_kernel<{metric}, false, 256, 16, 0, 3>"]
         assert k["vgpr"] <= 168 and k["agpr"] == 0, k          # 3 x 168 <= 512 registers per SIMD lane
         assert k["lds"] <= 160 * 1024 // 3, k                  # three 48 KiB workgroups share a CU's 160 KiB
         assert k["vgpr_spill"] <= max_spill and k["sgpr_spill"] == 0, k
+        assert k["scratch_in_k_loop"] == 0, k
         assert k["mfma"] == 64 and k["lds_dma"] == 12, k       # one 16-float slab = 2 x 4 k-pairs x (4 x 2) accumulators, unrolled once; 6 LDS-DMA per slab (prologue + loop)
     for name, k in md.items():
         if name.endswith(", 0, 2>"):                           # the two-per-CU builds (dense chunk, 128-row shape) never spill
@@ -40,6 +44,6 @@ def test_fp16_ping_pong_kernel_never_touches_scratch(metadata):
     md = metadata["f16x"]
     for metric in (0, 1, 2):
         k = md[f"nwk_tile_kernel_f16x<{metric}, 1>"]
-        assert k["vgpr"] <= 256 and k["vgpr_spill"] == 0 and k["sgpr_spill"] == 0 and k["scratch"] == 0, k      # two waves per SIMD: 256 registers each
+        assert k["vgpr"] <= 256 and k["vgpr_spill"] == 0 and k["sgpr_spill"] == 0 and k["scratch"] == 0 and k["scratch_in_k_loop"] == 0, k      # two waves per SIMD: 256 registers each
         assert k["lds"] <= 160 * 1024, k
         assert k["mfma"] == 256, k                              # 4 call sites x 64 MFMAs of one slab

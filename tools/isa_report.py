@@ -14,6 +14,23 @@ sys.path.insert(0, str(ROOT))
 from neighborhoodwatch_amd import build  # noqa: E402
 
 
+def scratch_in_k_loop(body: str) -> int:
+    """Scratch accesses inside a LOOP that issues MFMAs: the basic blocks between a label and a backward branch to it that hold a v_mfma.
+    A spilled register that is stored in the prologue and reloaded in the epilogue costs a tile a few hundred cycles; one touched in the K
+    loop costs every slab."""
+    lines = body.split("\n")
+    label_at = {m.group(1): i for i, ln in enumerate(lines) if (m := re.match(r"^(\.LBB\d+_\d+):", ln))}
+    hits = 0
+    for i, ln in enumerate(lines):
+        m = re.search(r"\bs_cbranch_\w+\s+(\.LBB\d+_\d+)", ln)
+        if not m or label_at.get(m.group(1), 10**9) > i:
+            continue                                              # forward branch
+        region = lines[label_at[m.group(1)]:i + 1]
+        if any("v_mfma_" in x for x in region):
+            hits += sum(1 for x in region if re.search(r"\bscratch_(load|store)", x))
+    return hits
+
+
 def kernel_metadata(src: Path, extra_flags=()):
     """{demangled-ish kernel name: {vgpr, agpr, vgpr_spill, sgpr_spill, lds, scratch, mfma}} for every kernel of one .hip file."""
     with tempfile.TemporaryDirectory() as tmp:
@@ -40,7 +57,8 @@ def kernel_metadata(src: Path, extra_flags=()):
         res[dem] = {"vgpr": int(field("vgpr_count")), "agpr": int(field("agpr_count")), "vgpr_spill": int(field("vgpr_spill_count")),
                     "sgpr_spill": int(field("sgpr_spill_count")), "lds": int(field("group_segment_fixed_size")),
                     "scratch": int(field("private_segment_fixed_size")), "mfma": len(re.findall(r"\bv_mfma_", body)),
-                    "lds_dma": len(re.findall(r"buffer_load_dword\S* .* lds\b", body))}
+                    "lds_dma": len(re.findall(r"buffer_load_dword\S* .* lds\b", body)),
+                    "scratch_in_k_loop": scratch_in_k_loop(body)}
     return res
 
 
@@ -50,4 +68,4 @@ if __name__ == "__main__":
         for src, md in zip(files, pool.map(kernel_metadata, files)):
             print(f"## {src.name}")
             for k, v in md.items():
-                print(f"  {k:70s} vgpr {v['vgpr']:3d} agpr {v['agpr']:3d} spill {v['vgpr_spill']:3d} sgpr_spill {v['sgpr_spill']:3d} scratch {v['scratch']:4d} B  lds {v['lds']:6d} B  mfma {v['mfma']:4d} lds-dma {v['lds_dma']:3d}")
+                print(f"  {k:70s} vgpr {v['vgpr']:3d} agpr {v['agpr']:3d} spill {v['vgpr_spill']:3d} sgpr_spill {v['sgpr_spill']:3d} scratch {v['scratch']:4d} B  lds {v['lds']:6d} B  mfma {v['mfma']:4d} lds-dma {v['lds_dma']:3d} scratch ops in the K loop {v['scratch_in_k_loop']}")
