@@ -19,8 +19,8 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 OBJ = CSRC / "build"
 OUT = PKG / "libnwknn.so"
-SOURCES = [CSRC / n for n in ("nwk_tile_f16x_pre.hip", "nwk_tile_f16x_raw.hip", "nwk_tile_f16.hip", "nwk_tile_f16p.hip", "nwk_maxsim.hip", "nwk_tile_f32.hip", "nwk_select.hip", "nwk_prep.hip", "nwk_calib.hip", "nwknn_api.cpp", "nwknn_comm.cpp")]
-HEADERS = [CSRC / "nwk_device.h", CSRC / "nwk_f16_common.h", CSRC / "nwk_tile_f16x.h", CSRC / "nwknn_internal.h", PKG.parent / "include" / "nwknn.h"]
+SOURCES = [CSRC / n for n in ("nwk_tile_f16x_pre.hip", "nwk_tile_f16x_raw.hip", "nwk_tile_f16y_pre.hip", "nwk_tile_f16y_raw.hip", "nwk_tile_f16.hip", "nwk_tile_f16p.hip", "nwk_maxsim.hip", "nwk_tile_f32.hip", "nwk_select.hip", "nwk_prep.hip", "nwk_calib.hip", "nwknn_api.cpp", "nwknn_comm.cpp")]
+HEADERS = [CSRC / "nwk_device.h", CSRC / "nwk_f16_common.h", CSRC / "nwk_tile_f16x.h", CSRC / "nwk_tile_f16y.h", CSRC / "nwknn_internal.h", PKG.parent / "include" / "nwknn.h"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=off", "-x", "hip"]
 
 

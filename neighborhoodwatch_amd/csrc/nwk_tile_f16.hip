@@ -252,7 +252,7 @@ static hipError_t launch_f16s(hipStream_t st, const NwkTileParams& p, int metric
 // pre = 0: raw fp16 sums against the thresholds (compute path with option f16_exact = 0, or inputs holding Inf/NaN);
 // pre = 1: the conservative pre-screen (p.qp/p.bp are the scaled copies, or the native fp16 rows in exact fp16 mode), keys carry estimates.
 // p.f16_shape: 1 = burst form (nwk_tile_kernel_f16s; the only build with a dense mode), 3 = streaming form (nwk_tile_kernel_f16p),
-// 4 = ping-pong form (nwk_tile_kernel_f16x).
+// 4 = ping-pong form (nwk_tile_kernel_f16x), 5 = two-issuing-waves form (nwk_tile_kernel_f16y).
 hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool dense, int pre)
 {
     if (p.n_qtiles <= 0 || p.n_btiles <= 0) return hipSuccess;
@@ -268,6 +268,7 @@ hipError_t nwk_launch_tile_f16(hipStream_t st, NwkTileParams p, int metric, bool
     if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
     if (p.f16_shape == 3) return nwk_launch_tile_f16p(st, p, metric, pre, (unsigned)grid);
     if (p.f16_shape == 4) return pre ? nwk_launch_tile_f16x_pre(st, p, metric, (unsigned)grid) : nwk_launch_tile_f16x_raw(st, p, metric, (unsigned)grid);
+    if (p.f16_shape == 5) return pre ? nwk_launch_tile_f16y_pre(st, p, metric, (unsigned)grid) : nwk_launch_tile_f16y_raw(st, p, metric, (unsigned)grid);
     if (p.f16_shape != 1) return hipErrorInvalidValue;
     return pre ? launch_f16s<1>(st, p, metric, dense, (unsigned)grid) : launch_f16s<0>(st, p, metric, dense, (unsigned)grid);
 }

@@ -345,7 +345,8 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
         if (value < 1 || value > 1000000) return fail(NWKNN_EINVAL, "pre_check_ppm must be 1..1000000 (millionths of the pre-screen bound the invariant is checked against)");
         h->opt_pre_check_ppm = value;
     } else if (!strcmp(name, "f16_mfma")) {
-        if (value != -1 && value != 1 && value != 3 && value != 4) return fail(NWKNN_EINVAL, "f16_mfma must be -1 (auto), 1 (burst form), 3 (streaming form) or 4 (ping-pong form)");
+        if (value != -1 && value != 1 && value != 3 && value != 4 && value != 5)
+            return fail(NWKNN_EINVAL, "f16_mfma must be -1 (auto), 1 (burst form), 3 (streaming form), 4 (ping-pong form) or 5 (two-issuing-waves form)");
         h->opt_f16_shape = value;
 #if NWK_DEV_BUILD
     } else if (!strcmp(name, "prescreen_prune")) {
@@ -884,7 +885,7 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
     const int f16_shape = agg ? 3 : f16_shape_auto;
     tp.f16_shape = f16_shape;
     tp.agg = agg ? 1 : 0;
-    tp.tiles_per_wg = h->opt_f16_strip > 0 ? (int)h->opt_f16_strip : (f16_shape == 4 ? 2 : 4);
+    tp.tiles_per_wg = h->opt_f16_strip > 0 ? (int)h->opt_f16_strip : (f16_shape >= 4 ? 2 : 4);
     // super-tile shape and walk order (see tile_from_block).  Auto = the fastest setting measured, base tile index fastest in both:
     // fp32 kernel 8 x 8 (same-box A/B on C3: 0.27 % faster than 2 x 32 / query fastest, which moves 38 % fewer bytes over the
     // fabric); fp16 kernels 16 x 4 (C3 pre-screen tile kernel: +1.4 % over 8 x 8, +0.7 % over 32 x 2; 4 x 16 / query fastest moves
@@ -928,6 +929,7 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
             snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel<%d,false,%d,%d,0,%d>", metric, pl.tile_rows, pl.tile_rows == 256 ? 16 : 32, occ3 ? 3 : 2);
         } else if (f16_shape == 3) snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel_f16p<%d,%d,%d>", metric, prescreen ? 1 : 0, agg ? 1 : 0);
         else if (f16_shape == 4) snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel_f16x<%d,%d>", metric, prescreen ? 1 : 0);
+        else if (f16_shape == 5) snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel_f16y<%d,%d>", metric, prescreen ? 1 : 0);
         else snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel_f16s<%d,false,%d>", metric, prescreen ? 1 : 0);
     }
     if (prescreen) {                                       // listed pairs -> canonical fp32 keys, in place

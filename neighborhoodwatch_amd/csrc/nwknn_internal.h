@@ -43,7 +43,7 @@ struct NwkTileParams {
     float pre_aq, pre_ab;          // absolute terms: pre_aq * sqrt(|b|^2) and pre_ab * sqrt(|q|^2)
     float pre_cst;
     float pre_inv_scale;           // 1 / pre_scale
-    int f16_shape;                 // fp16 tile kernel build (all on v_mfma_f32_16x16x32_f16): 1 = burst form, 3 = streaming form, 4 = ping-pong form
+    int f16_shape;                 // fp16 tile kernel build (all on v_mfma_f32_16x16x32_f16): 1 = burst form, 3 = streaming form, 4 = ping-pong form, 5 = two-issuing-waves form
     const float* ms_rq;            // MaxSim pre-screen: per-query and per-doc parts of the score bound
     const float* ms_cd;
     int walk_q_fastest;            // 1: inside a super-tile the QUERY tile index runs fastest (consecutive blocks share a base tile), 0: the base tile index
@@ -113,6 +113,8 @@ hipError_t nwk_launch_tile_f16p(hipStream_t st, const NwkTileParams& p, int metr
 hipError_t nwk_launch_tile_f16x_pre(hipStream_t st, const NwkTileParams& p, int metric, unsigned grid);          // ping-pong form (f16_mfma = 4), pre-screen
 hipError_t nwk_launch_col_terms(hipStream_t st, const NwkTileParams& p, int metric, long long rows_pad, float* out);  // out[b] = the pre-screen's column term of base row b
 hipError_t nwk_launch_tile_f16x_raw(hipStream_t st, const NwkTileParams& p, int metric, unsigned grid);          // ... raw fp16 sums
+hipError_t nwk_launch_tile_f16y_pre(hipStream_t st, const NwkTileParams& p, int metric, unsigned grid);          // two-issuing-waves form (f16_mfma = 5), pre-screen
+hipError_t nwk_launch_tile_f16y_raw(hipStream_t st, const NwkTileParams& p, int metric, unsigned grid);          // ... raw fp16 sums
 hipError_t nwk_launch_prep_strided(hipStream_t st, const void* raw, int in_dtype, long long rs, long long ks, long long rows, int d,
                                    long long rows_pad, int dp, int out_f16, void* prepared, float* norms);
 hipError_t nwk_launch_prep(hipStream_t st, const float* raw, long long rows, int d, long long rows_pad, int dp, float* prepared, float* norms);
