@@ -26,6 +26,9 @@
 //     (283 cycles in the barrier instead of 875);
 //   * the instruction stream of a chunk is pinned (sched_group_barrier): per four MFMAs one LDS-DMA instruction and two fragment reads,
 //     so that a wave's memory instructions fall into its partner's MFMA slots and the texture path sees an even stream.
+// (Tried at the tile boundaries and dropped: STAGGERING the two groups there -- waves 0-3 at priorities 3, 2, waves 4-7 at 1, 0 in the boundary
+// copies of the phases, so that each group's epilogue runs under the other's MFMAs instead of side by side with it: -0.4 % at d = 128, +0.5 %
+// at 384, -0.1 % at 768, +0.2 % at 1024, same-box A/B, profiles/r05s_f16y_stagger_ab.log -- nothing.)
 // A tile boundary (first slab of a tile): phase X carries no fragment reads -- both fragment sets are dead once its MFMAs are issued and
 // the epilogue of the finished tile takes their registers -- then the epilogue, then the reads of set 0 and phase Y from a zero C.
 //

@@ -873,7 +873,13 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
     // ping-pong form pays two phases per tile boundary); dense chunks run the burst form (the launcher sees to that).  Strips: 2 tiles
     // for the ping-pong form (1-3: equal within noise; 4: -2.5 %, 16: -5 %), 4 for the others.
     const int row_halves = (prescreen && pl.copies16) ? h->dp16 : h->dp;
-    const int f16_shape_auto = h->opt_f16_shape >= 0 ? (int)h->opt_f16_shape : (row_halves >= 768 ? 4 : 3);
+    // Round 5: below 768 halves per row the two-issuing-waves form (5: one program for all eight waves, one mid-slab barrier, priority ladder --
+    // nwk_tile_f16y.h) replaces the streaming form: same-box A/B on 32k x 4M pre-screened, forms 3 / 4 / 5 -- d = 128: 568 / 597 / 672 TF,
+    // 256: 831 / 905 / 944, 384: 944 / 1 037 / 1 054, 512: 1 000 / 1 120 / 1 135, 640: 1 045 / 1 173 / 1 180; from 768 on forms 4 and 5 tie
+    // within 0.2 % (768: 1 224 / 1 225, 1024: 1 268 / 1 267, 2048: 1 312 / 1 311; fp16 input d = 1536: 1 404 / 1 378) -- two different
+    // structures at one rate: busy x clock is what the power limit hands out (PMC: 0.689 x 1.760 GHz against 0.673 x 1.793 GHz), see
+    // tools/f16y_probe.hip and profiles/r05q_*, r05r_*.  The ping-pong form stays where it is not slower.
+    const int f16_shape_auto = h->opt_f16_shape >= 0 ? (int)h->opt_f16_shape : (row_halves >= 768 ? 4 : 5);
     // Loose-threshold chunks.  After `lo` rows tau admits ~k / lo of the next ones (x 1.4 pre-screened): 27 % of all pairs in the chunk
     // that follows the dense one, 7 %, 1.7 %, ... as the walk quadruples.  There the tile kernel is bound by the list-length atomics --
     // device scope, resolved beyond L2, ~8 G/s for the whole chip whatever the addresses (C2 pre-screened, tools/chunk_trace.sh: 0.82 ms

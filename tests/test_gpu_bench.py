@@ -40,7 +40,7 @@ def test_bench_line_has_the_contract_fields():
     assert sk["unit"] == "queries/s" and sk["value"] > 0 and sk["cores"] >= 1 and "NearestNeighbors" in sk["sample"]
     pre = b["exact_prescreen"]
     assert pre["identical_to_direct"] is True and pre["value"] > 0 and pre["roofline"]["peak"] == 2500.0
-    assert pre["roofline"]["kernel"] == "nwk_tile_kernel_f16p<0,1,0>"
+    assert pre["roofline"]["kernel"] == "nwk_tile_kernel_f16y<0,1>"
     assert b["ranks"] == 1 and len(b["devices"]) == 1 and b["devices"][0]["rank"] == 0 and "gfx950" in b["devices"][0]["gcn_arch"]
     assert "collective" not in b and "secondary" not in b                  # N = 1, not the default workload
     hbm = rf["hbm"]                                                         # north_star: achieved HBM GB/s on the streaming base read (the layout pass)

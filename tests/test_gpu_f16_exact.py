@@ -142,9 +142,9 @@ def test_random_cases_against_the_oracle(oracle, seed):
 
 
 @pytest.mark.parametrize("metric", EXACT)
-@pytest.mark.parametrize("form", [1, 3, 4])
+@pytest.mark.parametrize("form", [1, 3, 4, 5])
 def test_exact_mode_on_either_kernel_form(oracle, metric, form):
-    """Exact fp16 mode with the burst (1), the streaming (3) or the ping-pong (4) form selected: the dense first chunk always runs the
+    """Exact fp16 mode with the burst (1), the streaming (3), the ping-pong (4) or the two-issuing-waves (5) form selected: the dense first chunk always runs the
     burst build (the only one with a dense mode), the filtered chunks the selected one; the result is the oracle's bits either way."""
     from neighborhoodwatch_amd import KnnEngine
     rng = np.random.default_rng(11)
@@ -155,7 +155,7 @@ def test_exact_mode_on_either_kernel_form(oracle, metric, form):
         eng.set_base(base16)
         dist, idx = eng.search(queries16, 20, metric)
         assert eng.stats()["prescreen"] == 1
-        assert eng.tile_kernel_name().startswith({1: "nwk_tile_kernel_f16s", 3: "nwk_tile_kernel_f16p", 4: "nwk_tile_kernel_f16x"}[form])
+        assert eng.tile_kernel_name().startswith({1: "nwk_tile_kernel_f16s", 3: "nwk_tile_kernel_f16p", 4: "nwk_tile_kernel_f16x", 5: "nwk_tile_kernel_f16y"}[form])
     rd, ri = oracle.knn_canonical(base16.astype(np.float32), queries16.astype(np.float32), 20, metric)
     assert np.array_equal(idx, ri) and _bitwise(dist, rd)
 

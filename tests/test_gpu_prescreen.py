@@ -224,7 +224,7 @@ def test_row_aggregating_build_for_loose_threshold_chunks(oracle, agg, d):
             assert eng.stats()["prescreen"] == 1
             assert np.array_equal(idx, ri) and _bitwise(dist, rd), metric
         # the LAST filtered chunk of the last search (cosine = metric 2): its thresholds are loose only when forced
-        expect = "nwk_tile_kernel_f16p<2,1,1>" if agg == 1 else ("nwk_tile_kernel_f16p<2,1,0>" if d < 768 else "nwk_tile_kernel_f16x<2,1>")
+        expect = "nwk_tile_kernel_f16p<2,1,1>" if agg == 1 else ("nwk_tile_kernel_f16y<2,1>" if d < 768 else "nwk_tile_kernel_f16x<2,1>")
         if not os.environ.get("NWKNN_DEFAULT_OPTS"):                     # (a soak that forces a kernel form on every handle changes which one ran, not the bits)
             assert eng.tile_kernel_name() == expect
         eng.set_option("capacity", 512)                          # the 600 copies overflow a list: the repair pass re-walks with the non-aggregating build

@@ -98,7 +98,7 @@ def test_prescreened_search_equals_direct_search_long_rows(seed):
             if B > 1024:                                          # (a base of one dense chunk never reaches a filtered launch)
                 name = eng.tile_kernel_name()                     # (…,1,1>: the last chunk's thresholds were still loose -- few rows per k)
                 if not os.environ.get("NWKNN_DEFAULT_OPTS"):      # (a soak that forces a kernel form changes which one ran, not the bits)
-                    assert name.startswith("nwk_tile_kernel_f16x") or name.endswith(",1,1>"), name
+                    assert name.startswith("nwk_tile_kernel_f16x") or name.startswith("nwk_tile_kernel_f16y") or name.endswith(",1,1>"), name
             dd, di = direct[m]
             assert torch.equal(idx, di), f"seed {seed} {family} {m} Q={Q} B={B} d={d} k={k}: indices differ at {(idx != di).sum().item()} positions"
             assert torch.equal(dist.view(torch.int32), dd.view(torch.int32)), f"seed {seed} {family} {m}: distances differ"

@@ -16,10 +16,10 @@ sys.path.insert(0, str(ROOT / "tools"))
 @pytest.fixture(scope="module")
 def metadata():
     import isa_report
-    files = [CSRC / "nwk_tile_f32.hip", CSRC / "nwk_tile_f16x_pre.hip"]
-    with ThreadPoolExecutor(max_workers=2) as pool:
+    files = [CSRC / "nwk_tile_f32.hip", CSRC / "nwk_tile_f16x_pre.hip", CSRC / "nwk_tile_f16y_pre.hip", CSRC / "nwk_tile_f16y_raw.hip"]
+    with ThreadPoolExecutor(max_workers=4) as pool:
         md = list(pool.map(isa_report.kernel_metadata, files))
-    return {"f32": md[0], "f16x": md[1]}
+    return {"f32": md[0], "f16x": md[1], "f16y": {**md[2], **md[3]}}
 
 
 def test_fp32_tile_kernel_keeps_three_workgroups_per_cu(metadata):
@@ -47,3 +47,16 @@ def test_fp16_ping_pong_kernel_never_touches_scratch(metadata):
         assert k["vgpr"] <= 256 and k["vgpr_spill"] == 0 and k["sgpr_spill"] == 0 and k["scratch"] == 0 and k["scratch_in_k_loop"] == 0, k      # two waves per SIMD: 256 registers each
         assert k["lds"] <= 160 * 1024, k
         assert k["mfma"] == 256, k                              # 4 call sites x 64 MFMAs of one slab
+
+
+def test_fp16_two_issuing_waves_kernel_keeps_its_k_loop_in_registers_and_in_one_block(metadata):
+    """nwk_tile_kernel_f16y holds 128 accumulators and two fragment sets of 48 registers: 32 are left.  Its first build spilled LDS addresses,
+    reloaded them through scratch inside the K loop -- and the compiler waits vmcnt(0) for a scratch reload, i.e. for the LDS-DMA in flight,
+    five times per slab; the cause was a scalar branch around the DMA issue (it also ends the basic block the pinned instruction stream
+    lives in).  Asserted here: no spill at all, and no scratch access in any loop that issues MFMAs."""
+    md = metadata["f16y"]
+    for metric in (0, 1, 2):
+        for pre in (0, 1):
+            k = md[f"nwk_tile_kernel_f16y<{metric}, {pre}>"]
+            assert k["vgpr"] <= 256 and k["vgpr_spill"] == 0 and k["scratch"] == 0 and k["scratch_in_k_loop"] == 0, k
+            assert k["lds"] <= 160 * 1024 and k["mfma"] == 160, k      # X (boundary), Y (first), X, Y, X (tail): 5 x 32
