@@ -69,7 +69,7 @@ WORKLOADS = {
     "dev16": (32_768, 1_048_576, 1536, 100, "sqeuclidean", "f16", "dev16: 32k x 1M, d=1536, k=100, fp16 (not a headline number)"),
 }
 # (workload, timed steps, timed steps of its pre-screened leg, queries of the one warm-up step (0: all), estimated wall seconds)
-SECONDARY = (("c4gpu", 1, 0, 50_000, 42), ("refcli", 2, 2, 0, 8), ("c2", 10, 2, 0, 4), ("c3shard", 3, 2, 0, 10))
+SECONDARY = (("c4gpu", 1, 0, 50_000, 36), ("refcli", 2, 2, 0, 5), ("c2", 10, 2, 0, 3), ("c3shard", 3, 2, 0, 10))
 SECONDARY_BUDGET_S = 440.0          # wall clock since process start after which no further secondary leg is started (the driver allows 600 s)
 REF_PUBLISHED = {"knn_stage_s": 103.46, "queries_per_s": 96.7, "tflops": 1.19, "hardware": "1x NVIDIA RTX A5500 Laptop GPU 16 GB",
                  "source": "docs/cli.png (BASELINE.md section 1): kNN stage incl. parquet load, 9 x 9 knn() calls"}
@@ -119,17 +119,45 @@ def recorded_traffic(workload):
         return None, None
 
 
-def cpu_baseline(base_dev, queries_dev, k, metric, full_b, flop_budget=0.45e13):
-    """Brute force on the host cores over a bounded sample of the same workload: numpy/BLAS (the oracle's sgemm form) and, beside it,
-    scikit-learn's NearestNeighbors(algorithm='brute').  Each leg is sized to ~flop_budget of sgemm (~10 s on a 64-core host)."""
-    import numpy as np
-    from oracle import cpu_oracle
+def _blas_threads():
     cores = len(os.sched_getaffinity(0))
     try:
         from threadpoolctl import threadpool_info
-        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [cores])
+        return max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [cores])
     except Exception:
-        blas_threads = cores
+        return cores
+
+
+def cpu_baseline(base_dev, queries_dev, k, metric, full_b, flop_budget=0.45e13, defer=False, blas_threads=None):
+    """Brute force on the host cores over a bounded sample of the same workload: numpy/BLAS (the oracle's sgemm form) and, beside it,
+    scikit-learn's NearestNeighbors(algorithm='brute').  Each leg is sized to ~flop_budget of sgemm (~10 s on a 64-core host).
+    defer=True (the default line, which has GPU-only legs still to run): the sample is copied to the host now, the ~25 s of host work run
+    on a background thread, and a concurrent.futures.Future of the result is returned (main() resolves it before it prints)."""
+    if defer:
+        # Everything that imports a module or walks the loaded libraries happens HERE, on the main thread: threadpoolctl's threadpool_info()
+        # runs Python inside dl_iterate_phdr (it holds the loader lock and needs the GIL) while another thread's first `import pyarrow` holds
+        # the GIL and needs the loader lock for its dlopen -- the default line deadlocked on exactly that the first time this was deferred.
+        from concurrent.futures import ThreadPoolExecutor
+        import numpy  # noqa: F401
+        from oracle import cpu_oracle  # noqa: F401
+        try:
+            from sklearn.neighbors import NearestNeighbors  # noqa: F401
+        except Exception:
+            pass
+        blas_threads = _blas_threads()
+        d_ = base_dev.shape[1]
+        qs_ = min(queries_dev.shape[0], 2048)
+        bs_ = min(base_dev.shape[0], max(10_000, int(flop_budget / (2.0 * qs_ * d_))))
+        b_host, q_host = base_dev[:bs_].float().cpu(), queries_dev[:qs_].float().cpu()
+        pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="nw-bench-cpu")
+        fut = pool.submit(cpu_baseline, b_host, q_host, k, metric, full_b, flop_budget, False, blas_threads)
+        pool.shutdown(wait=False)
+        return fut
+    import numpy as np
+    from oracle import cpu_oracle
+    cores = len(os.sched_getaffinity(0))
+    if blas_threads is None:
+        blas_threads = _blas_threads()
     d = base_dev.shape[1]
     qs = min(queries_dev.shape[0], 2048)
     bs = min(base_dev.shape[0], max(10_000, int(flop_budget / (2.0 * qs * d))))
@@ -161,7 +189,7 @@ def cpu_baseline(base_dev, queries_dev, k, metric, full_b, flop_budget=0.45e13):
     return out
 
 
-REF_FILES_EST_S = 75               # the file legs of the reference's published run: write a 24.6 GB parquet file, run compute_knn / compute_knn_ds from it; then a 3 GB file in pyarrow's default encoding
+REF_FILES_EST_S = 30               # the file legs of the reference's published run: write a 24.6 GB parquet file, run compute_knn / compute_knn_ds from it; then a 3 GB file in pyarrow's default encoding
 REF_FILES_BASE_ROWS = 4_000_000
 
 
@@ -185,44 +213,62 @@ REF_FILES_DEFAULTS_ROWS = 500_000  # rows of the default-encoding leg: pyarrow w
                                    # pyarrow 25), so the 4M-row file would take ~170 s to WRITE (not timed, but inside the bench's wall clock)
 
 
-def ref_cli_through_files(eng, base_rows=REF_FILES_BASE_ROWS, q_rows=10_000, d=1536, k=100, encoding="uncompressed", legs=("direct", "prescreened"), via=("compute_knn",)):
-    """The reference's published run as its CLI does it: compute_knn(data_dir, ...) from parquet files with one float32 column per
-    dimension (cu_knn.py:151-180), load included, then merge_indices_and_distances -- what docs/cli.png times at 103.46 s + 2.02 s.
-    The synthetic source files are written first (not timed: the reference's stage 1-2 is not in its figure either), to /dev/shm when it
-    is there (no disk in the picture), 100 000-row row groups, in the named ENCODING (FILE_ENCODINGS: uncompressed, or pyarrow's defaults
-    as the reference's ParquetStreamer writes).  `via` adds compute_knn_ds (the dataset flavour, cu_knn_ds.py:136-146) over the same files."""
-    import shutil
+def synth_column_chunks(eng, seed, rows, d):
+    """[d, n] float32 host arrays, one per 100 000-row group: column j of a group is one contiguous array (what a parquet column chunk
+    is written from).  Generated on the GPU -- 614 MB per group of the reference's shape, ~25 ms of generate + transpose + copy."""
+    return [eng.generate(seed, r0, min(100_000, rows - r0), d).t().contiguous().cpu().numpy() for r0 in range(0, rows, 100_000)]
+
+
+def write_ref_files(eng, base_rows, q_rows=10_000, d=1536, encoding="uncompressed", chunks=None):
+    """The synthetic source files of a file leg (one float32 column per dimension, 100 000-row groups, /dev/shm when it is there).
+    `chunks` = (base groups, query groups) from synth_column_chunks when the values were generated ahead: the writing itself is host work
+    only, and the default line does it on a background thread under the c4gpu leg."""
     import tempfile
-    import numpy as np
     import pyarrow as pa
     import pyarrow.parquet as pq
-    import torch
-    from neighborhoodwatch_amd import cu_knn, cu_knn_ds, merge
     root = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     tmp = tempfile.mkdtemp(prefix="nwk_refcli_", dir=root)
-    out = {"data_dir": tmp, "base_rows": base_rows, "queries": q_rows, "dim": d, "k": k, "encoding": encoding,
-           "encoding_note": ("pyarrow defaults (snappy, dictionary, statistics): what the reference's ParquetStreamer writes, generate_dataset.py:241-242"
-                             if encoding == "pyarrow_defaults" else "compression NONE, no dictionary, no statistics: the cheapest bytes to decode, NOT what the reference writes")}
+    out = {"data_dir": tmp, "base_rows": base_rows, "queries": q_rows, "dim": d, "encoding": encoding}
+    t0 = time.perf_counter()
+    names = [f"embedding_{j}" for j in range(d)]
     try:
-        t0 = time.perf_counter()
-        names = [f"embedding_{j}" for j in range(d)]
-
-        def write(fname, seed, rows):
+        if chunks is None:
+            chunks = (synth_column_chunks(eng, SEED_BASE, base_rows, d), synth_column_chunks(eng, SEED_QUERY, q_rows, d))
+        for fname, groups in (("base.parquet", chunks[0]), ("query.parquet", chunks[1])):
             writer = None
-            for r0 in range(0, rows, 100_000):
-                n = min(100_000, rows - r0)
-                cols = eng.generate(seed, r0, n, d).t().contiguous().cpu().numpy()          # [d, n]: one contiguous array per column
+            for cols in groups:
                 t = pa.Table.from_arrays([pa.array(cols[j]) for j in range(d)], names=names)
                 if writer is None:
                     writer = pq.ParquetWriter(os.path.join(tmp, fname), t.schema, **FILE_ENCODINGS[encoding])
                 writer.write_table(t)
             writer.close()
-        write("base.parquet", SEED_BASE, base_rows)
-        write("query.parquet", SEED_QUERY, q_rows)
-        torch.cuda.synchronize()
         out["write_s_not_timed"] = time.perf_counter() - t0
         out["file_gb"] = os.path.getsize(os.path.join(tmp, "base.parquet")) / 1e9
         out["float_gb"] = base_rows * d * 4 / 1e9
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
+def ref_cli_through_files(eng, base_rows=REF_FILES_BASE_ROWS, q_rows=10_000, d=1536, k=100, encoding="uncompressed", legs=("direct", "prescreened"),
+                          via=("compute_knn",), prepared=None):
+    """The reference's published run as its CLI does it: compute_knn(data_dir, ...) from parquet files with one float32 column per
+    dimension (cu_knn.py:151-180), load included, then merge_indices_and_distances -- what docs/cli.png times at 103.46 s + 2.02 s.
+    The synthetic source files are written first (not timed: the reference's stage 1-2 is not in its figure either; `prepared` = the result
+    of write_ref_files when a background thread already wrote them), in the named ENCODING (FILE_ENCODINGS: uncompressed, or pyarrow's
+    defaults as the reference's ParquetStreamer writes).  `via` adds compute_knn_ds (the dataset flavour, cu_knn_ds.py:136-146)."""
+    import shutil
+    from neighborhoodwatch_amd import cu_knn, cu_knn_ds, merge
+    out = prepared if prepared is not None else write_ref_files(eng, base_rows, q_rows, d, encoding)
+    tmp = out["data_dir"]
+    out["k"] = k
+    out["encoding_note"] = ("pyarrow defaults (snappy, dictionary, statistics): what the reference's ParquetStreamer writes, generate_dataset.py:241-242"
+                            if out["encoding"] == "pyarrow_defaults" else
+                            "compression NONE, no dictionary, no statistics: the cheapest bytes to decode, NOT what the reference writes")
+    try:
+        if "error" in out:
+            return out
+        base_rows, q_rows, d = out["base_rows"], out["queries"], out["dim"]
         for how in via:
             for label in legs:
                 pre = label == "prescreened"
@@ -253,13 +299,52 @@ def ref_cli_through_files(eng, base_rows=REF_FILES_BASE_ROWS, q_rows=10_000, d=1
     return out
 
 
+class RefFiles:
+    """Both file legs of the refcli workload -- the reference's size on uncompressed files (compute_knn and compute_knn_ds) and a smaller
+    file in the encoding the reference's own writer produces.  The VALUES are generated here, on the calling thread, while the GPU is
+    free (27.7 GB of float32 through PCIe: a few seconds); the 29 GB of parquet are then written by a BACKGROUND thread -- host work only --
+    while the caller goes on measuring (the default line: under the c4gpu leg, whose ~30 s of GPU work leave the host idle)."""
+
+    def __init__(self, eng, base_rows, q_rows=10_000, d=1536):
+        import threading
+        import pyarrow  # noqa: F401  (first imports belong on the main thread: see cpu_baseline)
+        import pyarrow.parquet  # noqa: F401
+        from neighborhoodwatch_amd import cu_knn, cu_knn_ds, merge  # noqa: F401
+        self.base_rows = base_rows
+        self.small = min(base_rows, REF_FILES_DEFAULTS_ROWS)
+        self.files = {}
+        t0 = time.perf_counter()
+        base = synth_column_chunks(eng, SEED_BASE, base_rows, d)
+        qry = synth_column_chunks(eng, SEED_QUERY, q_rows, d)
+        n_small = (self.small + 99_999) // 100_000
+        small = [g if (i + 1) * 100_000 <= self.small else g[:, :self.small - i * 100_000] for i, g in enumerate(base[:n_small])]
+        self.generate_s = time.perf_counter() - t0
+
+        def work():
+            self.files["plain"] = write_ref_files(None, base_rows, q_rows, d, chunks=(base, qry))
+            self.files["defaults"] = write_ref_files(None, self.small, q_rows, d, encoding="pyarrow_defaults", chunks=(small, qry))
+        self.thread = threading.Thread(target=work, name="nw-bench-files", daemon=True)
+        self.thread.start()
+
+    def run(self, eng):
+        t0 = time.perf_counter()
+        self.thread.join()
+        waited = time.perf_counter() - t0
+        out = ref_cli_through_files(eng, via=("compute_knn", "compute_knn_ds"), prepared=self.files["plain"])
+        out["reference_encoding"] = ref_cli_through_files(eng, legs=("direct",), prepared=self.files["defaults"])
+        out["files_written"] = (f"values generated on the GPU in {self.generate_s:.1f} s, files written on a background thread while the previous leg "
+                                f"ran; the main thread waited {waited:.1f} s for it")
+        return out
+
+    def discard(self):
+        import shutil
+        self.thread.join()
+        for f in self.files.values():
+            shutil.rmtree(f.get("data_dir", ""), ignore_errors=True)
+
+
 def ref_cli_file_legs(eng, base_rows):
-    """Both file legs of the refcli workload: the reference's size on uncompressed files (both engines' paths, compute_knn and compute_knn_ds)
-    and a smaller file in the encoding the reference's own writer produces."""
-    out = ref_cli_through_files(eng, base_rows, via=("compute_knn", "compute_knn_ds"))
-    small = min(base_rows, REF_FILES_DEFAULTS_ROWS)
-    out["reference_encoding"] = ref_cli_through_files(eng, small, encoding="pyarrow_defaults", legs=("direct",))
-    return out
+    return RefFiles(eng, base_rows).run(eng)
 
 
 class Bench:
@@ -338,7 +423,7 @@ class Bench:
         return gathered
 
     # ---- one workload ----------------------------------------------------------------------------------------------------------------
-    def run(self, name, steps, warmup, pre_steps, metric_override=None, shard="base", verify=False, with_cpu=False, warm_queries=0, pre_shard="auto"):
+    def run(self, name, steps, warmup, pre_steps, metric_override=None, shard="base", verify=False, with_cpu=False, warm_queries=0, pre_shard="auto", defer_cpu=False):
         torch, td, eng, world, rank = self.torch, self.td, self.eng, self.world, self.rank
         from neighborhoodwatch_amd.distributed import query_sharded_search, shard_bounds, sharded_search
         Q, B, d, k, metric, dtype, desc = WORKLOADS[name]
@@ -540,7 +625,7 @@ class Bench:
             if pre is not None:
                 out["exact_prescreen"] = pre
             if with_cpu and not maxsim:
-                out["cpu_baseline"] = cpu_baseline(base_raw, queries, k, metric, B)
+                out["cpu_baseline"] = cpu_baseline(base_raw, queries, k, metric, B, defer=defer_cpu)
         ok = None
         if verify and rank == 0:
             if maxsim:
@@ -667,6 +752,9 @@ def main():
     ap.add_argument("--metric", default=None, choices=["sqeuclidean", "one_minus_dot", "cosine"], help="override the workload's metric (dev)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option (nwknn_set_option), dev use")
     args = ap.parse_args()
+    if os.environ.get("NWKNN_BENCH_WATCHDOG"):                   # dev: every N seconds, every thread's Python stack on stderr (a hang names itself)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["NWKNN_BENCH_WATCHDOG"]), repeat=True, file=sys.stderr)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.collective == "inlib":
@@ -685,7 +773,8 @@ def main():
     td, world, rank = b.td, b.world, b.rank
     devices = b.devices()
     out, ok = b.run(args.workload, args.steps, args.warmup, 0 if args.no_prescreen else min(args.steps, 5), args.metric, args.shard,
-                    args.verify, with_cpu=(world == 1 and not args.no_cpu_baseline), pre_shard=args.shard_prescreen)
+                    args.verify, with_cpu=(world == 1 and not args.no_cpu_baseline), pre_shard=args.shard_prescreen,
+                    defer_cpu=(world == 1 and args.workload == "c3" and not args.no_secondary and not args.opt and not args.metric))
     if rank == 0:
         line = {"metric": "queries/sec + pairwise-dist TFLOP/s, 100k x 10M d=1024 k=100" if args.workload == "c3" else f"queries/sec ({args.workload})",
                 "value": out.pop("value"), "unit": out.pop("unit"), "n_gpus": world, "steps": out.pop("steps"), "warmup": out.pop("warmup"),
@@ -699,6 +788,9 @@ def main():
             line["through_files"] = ref_cli_file_legs(b.eng, args.files_base_rows)
     if world == 1 and args.workload == "c3" and not args.no_secondary and not args.opt and not args.metric:
         sec = {}
+        # the file legs' source files (29 GB of parquet) are written by a background thread from here on, under the c4gpu leg
+        # (it costs the main thread nothing; whether its ~20 s of compute legs still fit is decided when the refcli leg gets there)
+        ref_files = RefFiles(b.eng, args.files_base_rows)
         for name, s_steps, s_pre, s_warm_q, est_s in SECONDARY:
             t0 = time.perf_counter()
             if t0 - T_PROCESS_START + est_s > SECONDARY_BUDGET_S:
@@ -709,15 +801,24 @@ def main():
                 s_out, _ = b.run(name, s_steps, 1, 0 if args.no_prescreen else s_pre, warm_queries=s_warm_q)
                 if name == "refcli":
                     s_out["vs_reference_published"] = ref_published_block(s_out["value"], s_out.get("exact_prescreen"))
-                    if time.perf_counter() - T_PROCESS_START + REF_FILES_EST_S <= SECONDARY_BUDGET_S:
-                        s_out["through_files"] = ref_cli_file_legs(b.eng, args.files_base_rows)
+                    if ref_files is not None and time.perf_counter() - T_PROCESS_START + REF_FILES_EST_S <= SECONDARY_BUDGET_S:
+                        s_out["through_files"] = ref_files.run(b.eng)
+                        ref_files = None
                     else:
                         s_out["through_files"] = {"skipped": f"time box ({REF_FILES_EST_S} s needed); run `python bench.py --workload refcli --files`"}
                 s_out["wall_s"] = time.perf_counter() - t0
                 sec[name] = s_out
             except Exception as e:                                  # a secondary figure must never cost the headline line
                 sec[name] = {"error": f"{type(e).__name__}: {e}"}
+        if ref_files is not None:
+            ref_files.discard()
         line["secondary"] = sec
+        if hasattr(line.get("cpu_baseline"), "result"):               # the host-side baseline ran on a background thread under the GPU-only legs above
+            try:
+                line["cpu_baseline"] = line["cpu_baseline"].result()
+                line["cpu_baseline"]["ran"] = "on a background thread while the secondary legs (GPU work with an idle host) ran"
+            except Exception as e:
+                line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         line["wall_s_since_process_start"] = time.perf_counter() - T_PROCESS_START
     if rank == 0:
         print(json.dumps(line), flush=True)
