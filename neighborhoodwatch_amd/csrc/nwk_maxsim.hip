@@ -360,17 +360,25 @@ __device__ __forceinline__ float ms_rows_max(float v)      // max over the wave'
     return fmaxf(__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1));
 }
 
-__global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_ring16_kernel(const NwkTileParams p)
+// WAVES = 4: the 256 x 128 tile above (4 documents x 4 queries), two workgroups per CU.
+// WAVES = 8 (round 5, the default): a 256 x 256 tile, 4 documents x EIGHT queries, one eight-wave workgroup per CU -- the same eight waves a CU
+// held before (a wave still owns 128 document rows x 64 query-token columns = 2 documents x 2 queries, its 64 registers of query fragments and
+// its 128 accumulators), but they now share ONE document stream and one ring: half the LDS-DMA instructions, L2 -> LDS bytes and ring space per
+// FLOP (256 FLOP/B instead of 128), and a slab's barrier joins the two waves of every SIMD instead of leaving them to two unrelated workgroups.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void nwk_maxsim_pre_ring16_kernel(const NwkTileParams p)
 {
-    constexpr int TM = 256, TQ = 128, NK = 4, SLAB = TM * 64, RING = 4, B_SLAB = TQ * 64;      // 32-half slabs of 64-B rows
+    constexpr int TM = 256, TQ = 32 * WAVES, NK = 4, SLAB = TM * 64, RING = 4, B_SLAB = TQ * 64;      // 32-half slabs of 64-B rows
+    constexpr int IA = 16 / WAVES;                   // LDS-DMA instructions (16 rows x 64 B each) a wave issues per document slab: 256 rows / WAVES / 16
     constexpr int OFF_CD = RING * SLAB;
+    static_assert(NK * B_SLAB <= RING * SLAB, "the query tokens are staged through the ring's space");
     __shared__ __attribute__((aligned(16))) char smem[OFF_CD + MS_RING_MAX_STRIP * MS_DOCS_PER_TILE * 4];
 
-    const TileCoord tc = tile_from_block(p);         // tc.qt: group of 4 queries, tc.bt: STRIP of document tiles
+    const TileCoord tc = tile_from_block(p);         // tc.qt: group of WAVES queries, tc.bt: STRIP of document tiles
     if (!tc.ok) return;
     const int tid = threadIdx.x;
     const int w = tid >> 6, l = tid & 63;
-    const int wr = w >> 1, wc = w & 1;
+    const int wr = WAVES == 8 ? (w >> 2) : (w >> 1), wc = WAVES == 8 ? (w & 3) : (w & 1);
     const int g = l >> 4, c16 = l & 15;
     const int T = p.tiles_per_wg > 1 ? p.tiles_per_wg : 1;         // <= MS_RING_MAX_STRIP (launcher)
     const int bt_first = p.bt0 + (tc.bt - p.bt0) * T;
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_ring16_kernel(const Nwk
     const unsigned voff = (unsigned)((l >> 2) * dp * 2 + (((l & 3) ^ ((0 - (l >> 4)) & 3)) << 4));      // the ring kernel's LDS image
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(qrys + qrow0 * dp), 0, 0x7FFFFFFF, 0x00020000);
     const int wu = __builtin_amdgcn_readfirstlane(w);
-    const int rowsA = wu * 64 * dp * 2, rowsB = wu * 32 * dp * 2, step16 = 16 * dp * 2;
+    const int rowsA = wu * (16 * IA) * dp * 2, rowsB = wu * 32 * dp * 2, step16 = 16 * dp * 2;
     // fragment of a 16-row block: lane l reads row l % 16, k = 8 (l / 16) .. + 7 = the row's 16-B chunk l / 16, stored in slot chunk ^ swizzle(row)
     const int swz = (0 - (c16 >> 2)) & 3;
     const int offA0 = (wr * 128 + c16) * 64 + ((g ^ swz) << 4);      // + 1024 m
@@ -396,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_ring16_kernel(const Nwk
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(smem + kt * B_SLAB + wu * 2048 + i * 1024), 16, voff,
                                                      kt * 64 + rowsB + i * step16, 0, 0);
-    const long long q_first = (long long)tc.qt * MS_QUERIES_PER_TILE + 2 * wc;
+    const long long q_first = (long long)tc.qt * WAVES + 2 * wc;      // WAVES queries per tile (32 token columns each)
     const u64 tauq[2] = {p.tau[q_first], p.tau[q_first + 1]};
     const float rq[2] = {p.ms_rq[q_first], p.ms_rq[q_first + 1]};
     float cd_mine = 0.0f;
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_ring16_kernel(const Nwk
         if (tid < n_here * MS_DOCS_PER_TILE && doc < p.nb_valid) cd_mine = p.ms_cd[doc];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ((float*)(smem + OFF_CD))[tid] = cd_mine;
+    if (tid < MS_RING_MAX_STRIP * MS_DOCS_PER_TILE) ((float*)(smem + OFF_CD))[tid] = cd_mine;
     __builtin_amdgcn_s_barrier();
     f16x8 bq[NK][4];
 #pragma unroll
@@ -431,8 +439,8 @@ __global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_ring16_kernel(const Nwk
     auto issue_next = [&]() {
         const int soff = it * tile_bytes + ik * 64 + rowsA;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(smem + ist * SLAB + wu * 4096 + i * 1024), 16, voff, soff + i * step16, 0, 0);
+        for (int i = 0; i < IA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(smem + ist * SLAB + wu * (IA * 1024) + i * 1024), 16, voff, soff + i * step16, 0, 0);
         ist = (ist + 1) & (RING - 1);
         if (it * nk + ik + 1 < NS) { if (++ik == nk) { ik = 0; ++it; } }
     };
@@ -446,7 +454,9 @@ __global__ __launch_bounds__(256, 2) void nwk_maxsim_pre_ring16_kernel(const Nwk
 #pragma unroll
         for (int kt = 0; kt < NK; ++kt) {
             if (kt >= nk) break;
-            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            // all but the requests of the two slabs behind this one (2 x IA instructions) have landed
+            if (WAVES == 8) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             issue_next();
             const char* sb = smem + st * SLAB;
@@ -797,6 +807,8 @@ hipError_t nwk_launch_maxsim_pre(hipStream_t st, NwkTileParams p)
     if (p.n_qtiles <= 0 || p.n_btiles <= 0) return hipSuccess;
     if (p.sq_shift < 0 || p.sq_shift > 6) return hipErrorInvalidValue;
     const bool ring = p.dp <= 128 && p.tiles_per_wg != 1;       // d <= 128: query fragments fit the registers (tiles_per_wg = 1: the plain kernel)
+    const bool wide = ring && p.f16_shape != 4;                 // 256 x 256 tiles of 8 queries (p.f16_shape = 4: option ms_waves, the four-wave build)
+    if (wide) p.n_qtiles = (p.n_qtiles + 1) / 2;                // the query matrix is padded to 8 queries (nq_pad): the last tile's rows exist
     if (ring) {
         if (p.tiles_per_wg < 1) {                               // auto (option ms_strip = 0): the ring likes long strips (64: +3 % over 8 on C5)
             p.tiles_per_wg = MS_RING_MAX_STRIP;                 // as long as the launch still has a few workgroups for each of the 512 slots
@@ -813,7 +825,8 @@ hipError_t nwk_launch_maxsim_pre(hipStream_t st, NwkTileParams p)
     supers = (supers + 7) / 8 * 8;
     const long long grid = supers * 64;
     if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    if (ring) hipLaunchKernelGGL(nwk_maxsim_pre_ring16_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
+    if (wide) hipLaunchKernelGGL(nwk_maxsim_pre_ring16_kernel<8>, dim3((unsigned)grid), dim3(512), 0, st, p);
+    else if (ring) hipLaunchKernelGGL(nwk_maxsim_pre_ring16_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(nwk_maxsim_pre_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
     return hipGetLastError();
 }

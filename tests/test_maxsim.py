@@ -109,21 +109,25 @@ def test_hip_maxsim_prescreened_overflow_repair_unit_tokens_and_offsets(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("waves", [8, 4])
 @pytest.mark.parametrize("strip", [0, 3, 5, 64, 1])
-def test_hip_maxsim_prescreen_kernel_forms_give_the_same_bits(oracle, strip):
-    """The forms of the d <= 128 pre-screen tile kernel (the ring kernel with auto / odd / longest strips; ms_strip = 1: the any-d
-    kernel) list under the same bound, so each of them must end in the oracle's bits; d = 64 is two k-slabs per tile in the
-    four-stage ring (stage != k-slab), with a document count whose last strip is ragged."""
+def test_hip_maxsim_prescreen_kernel_forms_give_the_same_bits(oracle, strip, waves):
+    """The forms of the d <= 128 pre-screen tile kernel (the ring kernel with auto / odd / longest strips, as the 256 x 256 eight-wave tile of
+    8 queries -- round 5, the default -- or the 256 x 128 four-wave tile of 4; ms_strip = 1: the any-d kernel) list under the same bound, so
+    each of them must end in the oracle's bits; d = 64 is two k-slabs per tile in the four-stage ring (stage != k-slab), with a document
+    count whose last strip is ragged; 21 and 6 queries leave the last query tile of either shape partly empty, 9 fills one 8-query tile
+    and one query of the next."""
     from neighborhoodwatch_amd import KnnEngine
-    for nd, nq, k, d in ((9000, 21, 64, 128), (3333, 6, 100, 64)):
+    for nd, nq, k, d in ((9000, 21, 64, 128), (3333, 6, 100, 64), (2100, 9, 30, 96)):
         docs, qs = _tokens(oracle, 0xD1 + nd, nd, 64, d), _tokens(oracle, 0xD2 + nq, nq, 32, d)
         with KnnEngine(0, profile=True) as eng:
             eng.set_prescreen(True)
             eng.set_option("ms_strip", strip)
+            eng.set_option("ms_waves", waves)
             eng.maxsim_set_docs(docs)
             s, i = eng.maxsim_search(qs, k)
             assert eng.stats()["prescreen"] == 1
-            assert eng.tile_kernel_name() == ("nwk_maxsim_pre_kernel" if strip == 1 else "nwk_maxsim_pre_ring16_kernel")
+            assert eng.tile_kernel_name() == ("nwk_maxsim_pre_kernel" if strip == 1 else f"nwk_maxsim_pre_ring16_kernel<{waves}>")
         rs, ri = oracle.maxsim_canonical(docs, qs, k)
         assert np.array_equal(i, ri), f"doc ids differ at {(i != ri).sum()} of {i.size} positions (strip={strip}, d={d})"
         assert np.array_equal(s.view(np.uint32), rs.view(np.uint32))
