@@ -365,10 +365,16 @@ __device__ __forceinline__ float ms_rows_max(float v)      // max over the wave'
 // held before (a wave still owns 128 document rows x 64 query-token columns = 2 documents x 2 queries, its 64 registers of query fragments and
 // its 128 accumulators), but they now share ONE document stream and one ring: half the LDS-DMA instructions, L2 -> LDS bytes and ring space per
 // FLOP (256 FLOP/B instead of 128), and a slab's barrier joins the two waves of every SIMD instead of leaving them to two unrelated workgroups.
-template <int WAVES>
+// SPB = slabs per barrier (WAVES = 8 only; round 5).  One eight-wave workgroup has the CU's whole LDS to itself, so the ring can hold EIGHT
+// 16 KiB slabs and the barrier joins the waves every second slab (64 MFMAs per wave between barriers instead of 32): a barrier costs the
+// interval 10-12 % whatever it waits for, because the SIMD's arbiter prefers the older wave, which then sits in the barrier while its
+// partner runs alone (tools/f16y_probe.hip) -- hence also the priority ladder inside the interval (s_setprio 3, 2, 1, 0 per 16 MFMAs).
+// SPB = 2 needs an even number of k-slabs per tile (d = 64, 128: ColBERT's); other depths run SPB = 1.
+template <int WAVES, int SPB = 1>
 __global__ __launch_bounds__(64 * WAVES, 2) void nwk_maxsim_pre_ring16_kernel(const NwkTileParams p)
 {
-    constexpr int TM = 256, TQ = 32 * WAVES, NK = 4, SLAB = TM * 64, RING = 4, B_SLAB = TQ * 64;      // 32-half slabs of 64-B rows
+    constexpr int TM = 256, TQ = 32 * WAVES, NK = 4, SLAB = TM * 64, RING = 4 * SPB, B_SLAB = TQ * 64;      // 32-half slabs of 64-B rows
+    static_assert(SPB == 1 || WAVES == 8, "the deep ring is the eight-wave workgroup's");
     constexpr int IA = 16 / WAVES;                   // LDS-DMA instructions (16 rows x 64 B each) a wave issues per document slab: 256 rows / WAVES / 16
     constexpr int OFF_CD = RING * SLAB;
     static_assert(NK * B_SLAB <= RING * SLAB, "the query tokens are staged through the ring's space");
@@ -444,7 +450,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void nwk_maxsim_pre_ring16_kernel(co
         ist = (ist + 1) & (RING - 1);
         if (it * nk + ik + 1 < NS) { if (++ik == nk) { ik = 0; ++it; } }
     };
-    issue_next(); issue_next(); issue_next();
+#pragma unroll
+    for (int i = 0; i < 3 * SPB; ++i) issue_next();                 // three barrier intervals ahead
 
     const int cap = p.cap;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -454,18 +461,28 @@ __global__ __launch_bounds__(64 * WAVES, 2) void nwk_maxsim_pre_ring16_kernel(co
 #pragma unroll
         for (int kt = 0; kt < NK; ++kt) {
             if (kt >= nk) break;
-            // all but the requests of the two slabs behind this one (2 x IA instructions) have landed
-            if (WAVES == 8) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            issue_next();
+            if (kt % SPB == 0) {
+                // all but the requests of the two intervals behind this one (2 x SPB x IA instructions) have landed
+                if (2 * SPB * IA == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int i = 0; i < SPB; ++i) issue_next();
+            }
             const char* sb = smem + st * SLAB;
             st = (st + 1) & (RING - 1);
             f16x8 a[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) a[m] = *(const f16x8*)(sb + offA0 + m * 1024);
+            if (SPB == 2) { __builtin_amdgcn_sched_barrier(0); if (kt % 2 == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-            for (int m = 0; m < 8; ++m)
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], bq[kt][n], kt == 0 ? zero4 : acc[m][n], 0, 0, 0);
+            if (SPB == 2) { __builtin_amdgcn_sched_barrier(0); if (kt % 2 == 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int m = 4; m < 8; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], bq[kt][n], kt == 0 ? zero4 : acc[m][n], 0, 0, 0);
@@ -825,8 +842,9 @@ hipError_t nwk_launch_maxsim_pre(hipStream_t st, NwkTileParams p)
     supers = (supers + 7) / 8 * 8;
     const long long grid = supers * 64;
     if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    if (wide) hipLaunchKernelGGL(nwk_maxsim_pre_ring16_kernel<8>, dim3((unsigned)grid), dim3(512), 0, st, p);
-    else if (ring) hipLaunchKernelGGL(nwk_maxsim_pre_ring16_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, p);
+    if (wide && p.agg != 1 && (p.dp / 32) % 2 == 0) hipLaunchKernelGGL((nwk_maxsim_pre_ring16_kernel<8, 2>), dim3((unsigned)grid), dim3(512), 0, st, p);      // p.agg = 1: option ms_spb = 1
+    else if (wide) hipLaunchKernelGGL((nwk_maxsim_pre_ring16_kernel<8, 1>), dim3((unsigned)grid), dim3(512), 0, st, p);
+    else if (ring) hipLaunchKernelGGL((nwk_maxsim_pre_ring16_kernel<4, 1>), dim3((unsigned)grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(nwk_maxsim_pre_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
     return hipGetLastError();
 }

@@ -127,7 +127,8 @@ def test_hip_maxsim_prescreen_kernel_forms_give_the_same_bits(oracle, strip, wav
             eng.maxsim_set_docs(docs)
             s, i = eng.maxsim_search(qs, k)
             assert eng.stats()["prescreen"] == 1
-            assert eng.tile_kernel_name() == ("nwk_maxsim_pre_kernel" if strip == 1 else f"nwk_maxsim_pre_ring16_kernel<{waves}>")
+            spb = 2 if (waves == 8 and (d // 32) % 2 == 0) else 1       # one barrier per two k-slabs where a tile has an even number of them
+            assert eng.tile_kernel_name() == ("nwk_maxsim_pre_kernel" if strip == 1 else f"nwk_maxsim_pre_ring16_kernel<{waves},{spb}>")
         rs, ri = oracle.maxsim_canonical(docs, qs, k)
         assert np.array_equal(i, ri), f"doc ids differ at {(i != ri).sum()} of {i.size} positions (strip={strip}, d={d})"
         assert np.array_equal(s.view(np.uint32), rs.view(np.uint32))
