@@ -539,6 +539,207 @@ __global__ __launch_bounds__(64 * WAVES, 2) void nwk_maxsim_pre_ring16_kernel(co
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the workgroup leaves
 }
 
+// ------------------------------------------------------------------------------------------------
+// The pre-screen for d <= 128, "pipelined" form (round 5; the default: option ms_form = 3).  Halving the document stream per FLOP
+// (<8,1>) and halving the barriers (<8,2>) bought 1.4 % together: the ring kernels are bound by neither.  A tile is 4 096 MFMA cycles
+// per SIMD and lives ~6 500: the rest is the EPILOGUE -- per wave and tile ~120 v_max, 16 lane swaps, 32 DPP adds, run by both waves of a
+// SIMD at the same time with the matrix pipe idle.  So the epilogue moves UNDER the MFMAs:
+//   * the ring's granule is a whole TILE (4 documents x all of d = 64 KiB; two stages), one barrier per tile: B(t) certifies that tile t
+//     has landed and that tile t-1 has been read, tile t+1 is requested right behind it and has a whole tile time to arrive;
+//   * a wave's work on a tile is split by DOCUMENT, not by k-slab: first all k-steps of its document 0 (row blocks 0-3: 16 nk MFMAs into
+//     acc[0..3]), then all k-steps of document 1 (acc[4..7]) -- the same ascending-k chain per accumulator, hence the same estimates;
+//   * software pipeline: while document 0 of tile t is being multiplied, the vector pipes reduce document 1 of tile t-1 (its accumulators
+//     are not written again before the second half), and while document 1 of tile t is multiplied they reduce document 0 of tile t.  The
+//     reductions are independent of the MFMAs in flight and the instruction stream is pinned as {1 MFMA, 2 VALU} (sched_group_barrier);
+//     only the threshold test and the rare append sit behind each half.
+// Same estimates, same keys, same lists as the ring kernels.
+// ------------------------------------------------------------------------------------------------
+// NKT = k-slabs per tile (dp / 32 = 2 or 4: a template parameter so that a document's MFMAs are ONE basic block -- a run-time bound puts a branch
+// behind every k-step, and sched_group_barrier interleaves inside a block only).
+template <int NKT>
+__global__ __launch_bounds__(512, 2) void nwk_maxsim_pre_tile8_kernel(const NwkTileParams p)
+{
+    constexpr int TM = 256, TQ = 256, NK = NKT, SLAB = TM * 64, STAGE = 4 * SLAB, B_SLAB = TQ * 64;      // 32-half slabs of 64-B rows; a stage = one tile
+    constexpr int OFF_CD = 2 * STAGE;
+    __shared__ __attribute__((aligned(16))) char smem[OFF_CD + MS_RING_MAX_STRIP * MS_DOCS_PER_TILE * 4];
+
+    const TileCoord tc = tile_from_block(p);         // tc.qt: group of 8 queries, tc.bt: STRIP of document tiles
+    if (!tc.ok) return;
+    const int tid = threadIdx.x;
+    const int l = tid & 63;
+    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wu >> 2, wc = wu & 3;
+    const int g = l >> 4, c16 = l & 15;
+    const int T = p.tiles_per_wg > 1 ? p.tiles_per_wg : 1;         // <= MS_RING_MAX_STRIP (launcher)
+    const int bt_first = p.bt0 + (tc.bt - p.bt0) * T;
+    int n_here = p.bt0 + p.n_btiles_real - bt_first;
+    if (n_here > T) n_here = T;
+    const long long qrow0 = (long long)tc.qt * TQ;
+    const int dp = p.dp;                             // halves per row = 32 NKT (the launcher picks the instance)
+    constexpr int nk = NKT;
+    const _Float16* docs = (const _Float16*)p.bp;
+    const _Float16* qrys = (const _Float16*)p.qp;
+
+    const unsigned voff = (unsigned)((l >> 2) * dp * 2 + (((l & 3) ^ ((0 - (l >> 4)) & 3)) << 4));      // the ring kernels' LDS image
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(qrys + qrow0 * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const int rowsA = wu * 32 * dp * 2, rowsB = wu * 32 * dp * 2, step16 = 16 * dp * 2;
+    const int swz = (0 - (c16 >> 2)) & 3;
+    const int offA0 = (wr * 128 + c16) * 64 + ((g ^ swz) << 4);      // + 1024 m + SLAB kt
+    const int offB0 = (wc * 64 + c16) * 64 + ((g ^ swz) << 4);       // + 1024 n
+
+    for (int kt = 0; kt < nk; ++kt)                                  // the 8 queries' tokens, through stage 0, once
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (LDS_AS void*)(smem + kt * B_SLAB + wu * 2048 + i * 1024), 16, voff,
+                                                     kt * 64 + rowsB + i * step16, 0, 0);
+    const long long q_first = (long long)tc.qt * 8 + 2 * wc;
+    const u64 tauq[2] = {p.tau[q_first], p.tau[q_first + 1]};
+    const float rq[2] = {p.ms_rq[q_first], p.ms_rq[q_first + 1]};
+    float cd_mine = 0.0f;
+    {
+        const long long doc = (long long)bt_first * MS_DOCS_PER_TILE + tid;
+        if (tid < n_here * MS_DOCS_PER_TILE && doc < p.nb_valid) cd_mine = p.ms_cd[doc];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid < MS_RING_MAX_STRIP * MS_DOCS_PER_TILE) ((float*)(smem + OFF_CD))[tid] = cd_mine;
+    __builtin_amdgcn_s_barrier();
+    f16x8 bq[NK][4];
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            bq[kt][n] = (kt < nk) ? *(const f16x8*)(smem + kt * B_SLAB + offB0 + n * 1024) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    float ntd[2], atd[2];
+    bool open_[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        open_[n] = tauq[n] == ~0ull;
+        const float td = unsortable_f32((u32)(tauq[n] >> 32));
+        ntd[n] = -td; atd[n] = fabsf(td);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                   // the query fragments are in registers: stage 0 is free
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(docs + (long long)bt_first * TM * dp), 0, 0x7FFFFFFF, 0x00020000);
+    const int tile_bytes = TM * dp * 2;
+    // tile t of the strip -> stage t & 1: k-slab kt at + kt SLAB, this wave's 32 rows of each (2 instructions per slab, 2 nk per tile)
+    auto issue_tile = [&](int t) __attribute__((always_inline)) {
+        const int tt = t < n_here ? t : n_here - 1;                  // past the end: the last tile once more, into the stage nobody reads again (no branch)
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (LDS_AS void*)(smem + (t & 1) * STAGE + kt * SLAB + wu * 2048 + i * 1024), 16, voff,
+                                                         tt * tile_bytes + kt * 64 + rowsA + i * step16, 0, 0);
+        }
+    };
+    issue_tile(0);
+
+    const int cap = p.cap;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[8][4];
+    // the MFMAs of one document (half dd of the wave's rows) of the tile in stage st
+    auto mfma_doc = [&](int dd, int st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+            f16x8 a[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] = *(const f16x8*)(smem + st * STAGE + kt * SLAB + offA0 + (4 * dd + m) * 1024);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[4 * dd + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], bq[kt][n], kt == 0 ? zero4 : acc[4 * dd + m][n], 0, 0, 0);
+        }
+    };
+    // reductions of one document: max over its 64 token rows per query-token column, sum over each query's 32 tokens -> two score estimates
+    auto reduce_doc = [&](int dd, float (&score)[2]) __attribute__((always_inline)) {
+        float vmx[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            float v = fmaxf(acc[4 * dd][n][0], acc[4 * dd][n][1]);
+            v = fmaxf(fmaxf(v, acc[4 * dd][n][2]), acc[4 * dd][n][3]);
+#pragma unroll
+            for (int m = 1; m < 4; ++m) {
+                v = fmaxf(fmaxf(v, acc[4 * dd + m][n][0]), acc[4 * dd + m][n][1]);
+                v = fmaxf(fmaxf(v, acc[4 * dd + m][n][2]), acc[4 * dd + m][n][3]);
+            }
+            vmx[n] = ms_rows_max(v);
+        }
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn) {
+            float s = __fadd_rn(vmx[2 * qn], vmx[2 * qn + 1]);      // tokens c and c + 16
+            s = __fadd_rn(s, ms_dpp<0xB1>(s));
+            s = __fadd_rn(s, ms_dpp<0x4E>(s));
+            s = __fadd_rn(s, ms_dpp<0x141>(s));
+            s = __fadd_rn(s, ms_dpp<0x140>(s));
+            score[qn] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 0)) * p.pre_inv_scale;
+        }
+    };
+    // threshold test and append of one document's two estimates (tile t of the strip)
+    auto list_doc = [&](int t, int dd, const float (&score)[2]) __attribute__((always_inline)) {
+        const long long doc = (long long)(bt_first + t) * MS_DOCS_PER_TILE + 2 * wr + dd;
+        const bool doc_ok = doc < p.nb_valid;
+        const float cd = ((const float*)(smem + OFF_CD))[t * MS_DOCS_PER_TILE + 2 * wr + dd];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const long long q = q_first + n;
+            const float err = rq[n] + cd;
+            const bool pass = open_[n] || !(score[n] < ntd[n] - err - 2.0e-6f * (atd[n] + err));
+            if (pass && doc_ok && q < p.nq_valid && l == 0) {
+                const u32 pos = atomicAdd(p.cnt + q, 1u);
+                if (pos < (u32)cap) p.buf[q * cap + pos] = ((u64)__float_as_uint(-score[n]) << 32) | (u32)doc;
+            }
+        }
+    };
+    auto interleave = [&]() __attribute__((always_inline)) {          // {1 MFMA, 2 VALU} per MFMA of a document: the reductions ride in the MFMAs' shadow
+#pragma unroll
+        for (int i = 0; i < 16 * NKT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+    };
+#define MS_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+    // tile 0, document 0: nothing to reduce yet
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                     // B(0): tile 0 complete
+    MS_FENCE();
+    issue_tile(1);
+    mfma_doc(0, 0);
+    MS_FENCE();
+    for (int t = 0; t < n_here; ++t) {
+        float s0[2], s1[2];
+        // document 1 of tile t  ||  reductions of document 0 of tile t
+        mfma_doc(1, t & 1);
+        reduce_doc(0, s0);
+        interleave();
+        MS_FENCE();
+        list_doc(t, 0, s0);
+        MS_FENCE();
+        if (t + 1 < n_here) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's part of tile t + 1 has landed (requested a tile time ago)
+            __builtin_amdgcn_s_barrier();                             // B(t + 1): tile t + 1 complete, tile t read by everybody
+            MS_FENCE();
+            issue_tile(t + 2);
+            // document 0 of tile t + 1  ||  reductions of document 1 of tile t
+            mfma_doc(0, (t + 1) & 1);
+            reduce_doc(1, s1);
+            interleave();
+            MS_FENCE();
+            list_doc(t, 1, s1);
+            MS_FENCE();
+        }
+    }
+    {
+        float s1[2];                                                  // the strip's last document 1: nothing left to hide it under
+        reduce_doc(1, s1);
+        list_doc(n_here - 1, 1, s1);
+    }
+#undef MS_FENCE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the workgroup leaves
+}
+
 // Rescoring in two launches.  (1) nwk_maxsim_prune_kernel, one wave per query: bounds est +- (R(q) + C(doc)) of the listed pairs,
 // k-th smallest upper bound by bisection, pairs that cannot reach the top k become ~0, the slots of the others go to surv[q][.].
 // (2) nwk_maxsim_rescore_kernel, grid (queries, slices): a wave takes every slices-th survivor of its query, two at a time (each
@@ -842,7 +1043,9 @@ hipError_t nwk_launch_maxsim_pre(hipStream_t st, NwkTileParams p)
     supers = (supers + 7) / 8 * 8;
     const long long grid = supers * 64;
     if (grid > 0x7FFFFFFFll) return hipErrorInvalidValue;
-    if (wide && p.agg != 1 && (p.dp / 32) % 2 == 0) hipLaunchKernelGGL((nwk_maxsim_pre_ring16_kernel<8, 2>), dim3((unsigned)grid), dim3(512), 0, st, p);      // p.agg = 1: option ms_spb = 1
+    if (wide && p.agg == 3 && p.dp == 128) hipLaunchKernelGGL(nwk_maxsim_pre_tile8_kernel<4>, dim3((unsigned)grid), dim3(512), 0, st, p);      // p.agg: option ms_form
+    else if (wide && p.agg == 3 && p.dp == 64) hipLaunchKernelGGL(nwk_maxsim_pre_tile8_kernel<2>, dim3((unsigned)grid), dim3(512), 0, st, p);
+    else if (wide && p.agg == 2 && (p.dp / 32) % 2 == 0) hipLaunchKernelGGL((nwk_maxsim_pre_ring16_kernel<8, 2>), dim3((unsigned)grid), dim3(512), 0, st, p);
     else if (wide) hipLaunchKernelGGL((nwk_maxsim_pre_ring16_kernel<8, 1>), dim3((unsigned)grid), dim3(512), 0, st, p);
     else if (ring) hipLaunchKernelGGL((nwk_maxsim_pre_ring16_kernel<4, 1>), dim3((unsigned)grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(nwk_maxsim_pre_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);

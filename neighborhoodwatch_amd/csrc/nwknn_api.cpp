@@ -133,7 +133,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i, ctab, chk, calib;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 0, opt_f16_agg = -1, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_waves = 8, opt_ms_spb = 2, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128, opt_pre_check_ppm = 1000000;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 0, opt_f16_agg = -1, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_waves = 8, opt_ms_form = 3, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128, opt_pre_check_ppm = 1000000;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -323,9 +323,11 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
     } else if (!strcmp(name, "ms_waves")) {
         if (value != 4 && value != 8) return fail(NWKNN_EINVAL, "ms_waves must be 8 (256 x 256 tiles of 8 queries, the default) or 4 (256 x 128 tiles of 4 queries)");
         h->opt_ms_waves = value;
-    } else if (!strcmp(name, "ms_spb")) {
-        if (value != 1 && value != 2) return fail(NWKNN_EINVAL, "ms_spb must be 2 (one barrier per two k-slabs, an eight-slab ring: the default where d / 32 is even) or 1");
-        h->opt_ms_spb = value;
+    } else if (!strcmp(name, "ms_form")) {
+        if (value < 1 || value > 3)
+            return fail(NWKNN_EINVAL, "ms_form (eight-wave MaxSim pre-screen tile) must be 3 (tile-granular ring, epilogue pipelined under the MFMAs: the default), "
+                                      "2 (eight-slab ring, one barrier per two k-slabs) or 1 (four-slab ring, one barrier per k-slab)");
+        h->opt_ms_form = value;
     } else if (!strcmp(name, "ms_strip")) {
         if (value < 0 || value > 64) return fail(NWKNN_EINVAL, "ms_strip must be 0..64");
         h->opt_ms_strip = value;            // MaxSim pre-screen, d <= 128: document tiles a workgroup of the ring kernel walks per query group (0: auto, 1: the any-d kernel)
@@ -1371,7 +1373,7 @@ static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq
     const bool prescreen = pre && !dense;                // the dense first chunk runs the fp32 kernel (exact keys)
     tp.tiles_per_wg = (int)h->opt_ms_strip;
     tp.f16_shape = h->opt_ms_waves == 4 ? 4 : 8;          // MaxSim ring kernel: waves per workgroup (the field is the kNN kernels' otherwise)
-    tp.agg = h->opt_ms_spb == 1 ? 1 : 0;                  // ... and 1 = one barrier per k-slab
+    tp.agg = (int)h->opt_ms_form;                         // ... and which build of the eight-wave tile (option ms_form)
     EvPair* e = ev_begin(h, 0);
     if (prescreen) {
         // the ring kernel streams documents only (the query fragments live in registers): the more query groups of an XCD walk the same
@@ -1386,7 +1388,7 @@ static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq
         tp.nq_valid = nq; tp.ms_rq = h->ms_rq.as<float>(); tp.ms_cd = h->ms_cd.as<float>();
         tp.pre_scale = h->ms_scale; tp.pre_inv_scale = 1.0f / h->ms_scale;
         HIPCHK(nwk_launch_maxsim_pre(h->stream, tp));
-        snprintf(h->tile_kernel, sizeof h->tile_kernel, "%s", (h->dp16 <= 128 && h->opt_ms_strip != 1) ? (h->opt_ms_waves == 4 ? "nwk_maxsim_pre_ring16_kernel<4,1>" : ((h->opt_ms_spb != 1 && (h->dp16 / 32) % 2 == 0) ? "nwk_maxsim_pre_ring16_kernel<8,2>" : "nwk_maxsim_pre_ring16_kernel<8,1>")) : "nwk_maxsim_pre_kernel");
+        snprintf(h->tile_kernel, sizeof h->tile_kernel, "%s", (h->dp16 <= 128 && h->opt_ms_strip != 1) ? (h->opt_ms_waves == 4 ? "nwk_maxsim_pre_ring16_kernel<4,1>" : (h->opt_ms_form == 3 ? (h->dp16 == 128 ? "nwk_maxsim_pre_tile8_kernel<4>" : "nwk_maxsim_pre_tile8_kernel<2>") : (h->opt_ms_form == 2 ? "nwk_maxsim_pre_ring16_kernel<8,2>" : "nwk_maxsim_pre_ring16_kernel<8,1>"))) : "nwk_maxsim_pre_kernel");
     } else {
         HIPCHK(nwk_launch_maxsim(h->stream, tp, dense));
         if (!dense) snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_maxsim_kernel<false>");

@@ -109,11 +109,11 @@ def test_hip_maxsim_prescreened_overflow_repair_unit_tokens_and_offsets(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("waves", [8, 4])
+@pytest.mark.parametrize("waves,form", [(8, 3), (8, 2), (8, 1), (4, 1)])
 @pytest.mark.parametrize("strip", [0, 3, 5, 64, 1])
-def test_hip_maxsim_prescreen_kernel_forms_give_the_same_bits(oracle, strip, waves):
+def test_hip_maxsim_prescreen_kernel_forms_give_the_same_bits(oracle, strip, waves, form):
     """The forms of the d <= 128 pre-screen tile kernel (the ring kernel with auto / odd / longest strips, as the 256 x 256 eight-wave tile of
-    8 queries -- round 5, the default -- or the 256 x 128 four-wave tile of 4; ms_strip = 1: the any-d kernel) list under the same bound, so
+    8 queries -- round 5: pipelined (the default), deep ring, plain ring -- or the 256 x 128 four-wave tile of 4; ms_strip = 1: the any-d kernel) list under the same bound, so
     each of them must end in the oracle's bits; d = 64 is two k-slabs per tile in the four-stage ring (stage != k-slab), with a document
     count whose last strip is ragged; 21 and 6 queries leave the last query tile of either shape partly empty, 9 fills one 8-query tile
     and one query of the next."""
@@ -124,11 +124,13 @@ def test_hip_maxsim_prescreen_kernel_forms_give_the_same_bits(oracle, strip, wav
             eng.set_prescreen(True)
             eng.set_option("ms_strip", strip)
             eng.set_option("ms_waves", waves)
+            eng.set_option("ms_form", form)
             eng.maxsim_set_docs(docs)
             s, i = eng.maxsim_search(qs, k)
             assert eng.stats()["prescreen"] == 1
-            spb = 2 if (waves == 8 and (d // 32) % 2 == 0) else 1       # one barrier per two k-slabs where a tile has an even number of them
-            assert eng.tile_kernel_name() == ("nwk_maxsim_pre_kernel" if strip == 1 else f"nwk_maxsim_pre_ring16_kernel<{waves},{spb}>")
+            ring = {(8, 3): "nwk_maxsim_pre_tile8_kernel<4>" if d > 64 else "nwk_maxsim_pre_tile8_kernel<2>", (8, 2): "nwk_maxsim_pre_ring16_kernel<8,2>", (8, 1): "nwk_maxsim_pre_ring16_kernel<8,1>",
+                    (4, 1): "nwk_maxsim_pre_ring16_kernel<4,1>"}[(waves, form)]
+            assert eng.tile_kernel_name() == ("nwk_maxsim_pre_kernel" if strip == 1 else ring)
         rs, ri = oracle.maxsim_canonical(docs, qs, k)
         assert np.array_equal(i, ri), f"doc ids differ at {(i != ri).sum()} of {i.size} positions (strip={strip}, d={d})"
         assert np.array_equal(s.view(np.uint32), rs.view(np.uint32))

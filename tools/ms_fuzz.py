@@ -25,7 +25,7 @@ for c in range(cases):
     for pre in (0, 1):
         with KnnEngine(0, profile=True) as eng:
             eng.set_prescreen(bool(pre))
-            eng.set_option("ms_strip", strip); eng.set_option("ms_rescore_valu", valu); eng.set_option("ms_waves", int(rng.choice([8, 8, 4]))); eng.set_option("ms_spb", int(rng.choice([2, 2, 1])))
+            eng.set_option("ms_strip", strip); eng.set_option("ms_rescore_valu", valu); eng.set_option("ms_waves", int(rng.choice([8, 8, 4]))); eng.set_option("ms_form", int(rng.choice([3, 3, 2, 1])))
             if rng.integers(0, 4) == 0:
                 eng.set_option("capacity", 4096 if k > 256 else 1024); eng.set_option("first_chunk", 256)
             eng.maxsim_set_docs(docs)
