@@ -552,7 +552,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void nwk_maxsim_pre_ring16_kernel(co
 //     are not written again before the second half), and while document 1 of tile t is multiplied they reduce document 0 of tile t.  The
 //     reductions are independent of the MFMAs in flight and the instruction stream is pinned as {1 MFMA, 2 VALU} (sched_group_barrier);
 //     only the threshold test and the rare append sit behind each half.
-// Same estimates, same keys, same lists as the ring kernels.
+// Same estimates, same keys, same lists as the ring kernels.  C5, same-box A/B (bench.py --workload c5): four-wave ring 0.482-0.485 of 2.5 PF
+// (2 007-2 022 q/s pre-screened), <8,1> 0.487, <8,2> 0.493, this form 0.520-0.524 (2 149-2 162 q/s).  Tried on it and dropped, each +-0.3 %:
+// s_setprio 1 / 0 for the two halves of a barrier interval; the next tile's LDS-DMA instructions spread through the MFMAs of document 0
+// instead of issued right behind the barrier; strips of 32 instead of 64 tiles (16: -2 %, 8: -6 %).
 // ------------------------------------------------------------------------------------------------
 // NKT = k-slabs per tile (dp / 32 = 2 or 4: a template parameter so that a document's MFMAs are ONE basic block -- a run-time bound puts a branch
 // behind every k-step, and sched_group_barrier interleaves inside a block only).
