@@ -656,7 +656,10 @@ __global__ __launch_bounds__(512, 2) void nwk_maxsim_pre_tile8_kernel(const NwkT
         }
     };
     // reductions of one document: max over its 64 token rows per query-token column, sum over each query's 32 tokens -> two score estimates
-    auto reduce_doc = [&](int dd, float (&score)[2]) __attribute__((always_inline)) {
+    // (the document's bound term is read from LDS HERE, at the head of the pinned stream, so that the threshold test behind the phase finds it
+    // in a register instead of starting an LDS round trip with both waves of the SIMD waiting)
+    auto reduce_doc = [&](int t, int dd, float (&score)[2], float& cd) __attribute__((always_inline)) {
+        cd = ((const float*)(smem + OFF_CD))[t * MS_DOCS_PER_TILE + 2 * wr + dd];
         float vmx[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -680,10 +683,9 @@ __global__ __launch_bounds__(512, 2) void nwk_maxsim_pre_tile8_kernel(const NwkT
         }
     };
     // threshold test and append of one document's two estimates (tile t of the strip)
-    auto list_doc = [&](int t, int dd, const float (&score)[2]) __attribute__((always_inline)) {
+    auto list_doc = [&](int t, int dd, const float (&score)[2], float cd) __attribute__((always_inline)) {
         const long long doc = (long long)(bt_first + t) * MS_DOCS_PER_TILE + 2 * wr + dd;
         const bool doc_ok = doc < p.nb_valid;
-        const float cd = ((const float*)(smem + OFF_CD))[t * MS_DOCS_PER_TILE + 2 * wr + dd];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const long long q = q_first + n;
@@ -712,13 +714,13 @@ __global__ __launch_bounds__(512, 2) void nwk_maxsim_pre_tile8_kernel(const NwkT
     mfma_doc(0, 0);
     MS_FENCE();
     for (int t = 0; t < n_here; ++t) {
-        float s0[2], s1[2];
+        float s0[2], s1[2], cd0, cd1;
         // document 1 of tile t  ||  reductions of document 0 of tile t
         mfma_doc(1, t & 1);
-        reduce_doc(0, s0);
+        reduce_doc(t, 0, s0, cd0);
         interleave();
         MS_FENCE();
-        list_doc(t, 0, s0);
+        list_doc(t, 0, s0, cd0);
         MS_FENCE();
         if (t + 1 < n_here) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's part of tile t + 1 has landed (requested a tile time ago)
@@ -727,17 +729,17 @@ __global__ __launch_bounds__(512, 2) void nwk_maxsim_pre_tile8_kernel(const NwkT
             issue_tile(t + 2);
             // document 0 of tile t + 1  ||  reductions of document 1 of tile t
             mfma_doc(0, (t + 1) & 1);
-            reduce_doc(1, s1);
+            reduce_doc(t, 1, s1, cd1);
             interleave();
             MS_FENCE();
-            list_doc(t, 1, s1);
+            list_doc(t, 1, s1, cd1);
             MS_FENCE();
         }
     }
     {
-        float s1[2];                                                  // the strip's last document 1: nothing left to hide it under
-        reduce_doc(1, s1);
-        list_doc(n_here - 1, 1, s1);
+        float s1[2], cd1;                                             // the strip's last document 1: nothing left to hide it under
+        reduce_doc(n_here - 1, 1, s1, cd1);
+        list_doc(n_here - 1, 1, s1, cd1);
     }
 #undef MS_FENCE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the workgroup leaves
