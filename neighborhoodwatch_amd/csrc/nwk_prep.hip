@@ -298,7 +298,16 @@ __global__ __launch_bounds__(256) void nwk_maxabs_kernel(const float* __restrict
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const u32 o = (u32)__shfl_xor((int)m, off); m = o > m ? o : m; }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out_bits, m);
+    // ONE atomic per workgroup: the first version had every wave of up to 4 096 workgroups hit the same word -- 16k device-scope atomics on
+    // one address, 0.19 ms for a 30 MB query matrix whose bytes take 10 us (profiles/r05m_c2_prescreen_chunk_trace.log)
+    __shared__ u32 s_m[4];
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 a = s_m[0] > s_m[1] ? s_m[0] : s_m[1], b = s_m[2] > s_m[3] ? s_m[2] : s_m[3];
+        const u32 mm = a > b ? a : b;
+        if (mm) atomicMax(out_bits, mm);
+    }
 }
 
 // max |bits| over an fp16 matrix (n8 groups of 8 halves): >= 0x7C00 means Inf/NaN somewhere
@@ -441,7 +450,7 @@ hipError_t nwk_launch_maxabs(hipStream_t st, const float* x, long long n, unsign
 {
     if (n <= 0) return hipSuccess;                              // n is a multiple of 4 (dp is a multiple of 32)
     long long blocks = (n / 4 + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(nwk_maxabs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n / 4, out_bits);
     return hipGetLastError();
 }

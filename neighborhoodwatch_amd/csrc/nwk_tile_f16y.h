@@ -41,6 +41,9 @@
 #include "nwk_f16_common.h"
 
 #define Y_BN_BUFS 4                   // column-norm buffers (tile & 3)
+#ifndef Y_DIAG
+#define Y_DIAG 0                      // build-time timing ablations (tools/mk_variant_lib.sh; WRONG results): 8 = no epilogue, 128 = first pass only
+#endif
 
 template <int METRIC, int PRE>
 __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16y(const NwkTileParams p)
@@ -159,6 +162,13 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16y(const NwkTilePara
     // ---- epilogue of tile t (this wave's 128 x 64 part) ------------------------------------------------------------------------
     u32 wcnt = 0;                                                   // PRE: length of this wave's survivor list (a scalar)
     auto epilogue = [&](int t) __attribute__((always_inline)) {
+        if (Y_DIAG & 8) {                                           // keep the accumulators (and so the MFMAs) alive
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) asm volatile("" :: "v"(acc[m][n]));
+            return;
+        }
         int l_here = l;                                             // opaque per tile: nothing derived from it is hoisted out of the strip loop
         asm volatile("" : "+v"(l_here));
         const int g = l_here >> 4, c16 = l_here & 15;
@@ -189,6 +199,7 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16y(const NwkTilePara
             }
             blocks = prescreen_block_mask(acc, pmin, fminf(fminf(cpre[0], cpre[1]), fminf(cpre[2], cpre[3])));
         }
+        if (Y_DIAG & 128) { asm volatile("" :: "s"(blocks)); blocks = 0; }   // first pass only: no block ever takes the exact test
         if (blocks) {
             if (PRE)
                 tile_epilogue16_flagged<METRIC>(p, acc, (const float*)epi, bnv, colv, colok, cpre, q0, wr * 128, g_here, c_here, s_key + wu * H_SCW,
