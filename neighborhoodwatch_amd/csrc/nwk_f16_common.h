@@ -72,6 +72,39 @@ __device__ __forceinline__ void flush_survivors(const NwkTileParams& p, LDS_AS c
 // cmin = min of the lane's four column terms,  fl(pmin + cmin) <= fl(row + col)  for every element of the block (rounded addition
 // is monotone), so "max of the block's 16 accumulators >= pmin + cmin" holds whenever any of them passes: 8 v_max3, one add and
 // one compare per block, no LDS, no branch.  The blocks it flags (a few percent) go through the exact test as before.
+// H_FIRSTPASS (build-time variant, tools/mk_variant_lib.sh): 0 = the form above (shipped); 1 = the lane's own column term per column block
+// (prescreen_block_mask_cols: 16 VALU per block instead of 10, ~10x fewer flagged blocks).  Round 5 re-measured round 3's finding with
+// today's kernels, on the C3 shape (100k x 10M, d = 1024, same-box A/B, profiles/r05ad_firstpass_cols.log): ping-pong form 1 347 -> 1 317 TF
+// (-2.2 %), two-issuing-waves form 1 335 -> 1 325 (-0.8 %), d = 128: -1.2 % -- although the ablations of the same day price everything
+// behind the first pass at 5.4-7 % of the tile kernel (first pass only: 1 385 / 1 421 TF; no epilogue at all: 1 409 / 1 460;
+// profiles/r05ac_epilogue_share_c3.log).  So that cost is not the exact tests of flagged-but-empty blocks: it is the APPENDS of real
+// survivors (~420 per query and chunk whatever the kernel does: ~650 wave-cycles each), which no first pass can thin out.
+#ifndef H_FIRSTPASS
+#define H_FIRSTPASS 0
+#endif
+__device__ __forceinline__ u32 prescreen_block_mask_cols(const f32x4 (&acc)[8][4], const float (&pmin)[8], const float (&cpre)[4])
+{
+    u32 fired = 0;
+    // An element passes the exact test when acc >= fl(row + col).  Then, in real arithmetic, acc - col >= row - u |row + col| >= pmin - u T, and the
+    // rounded d = fl(acc - col) >= (acc - col) - u |acc - col|; with T <= max(|pmin|, |d|) + |col| and |acc - col| <= max(|pmin|, |d|) (+ lower order)
+    // the test below -- the block's largest d against pmin lowered by 8 u (|pmin| + |d| + max |col|) -- fires whenever any element passes.
+    const float cslack = 4.8e-7f * fmaxf(fmaxf(fabsf(cpre[0]), fabsf(cpre[1])), fmaxf(fabsf(cpre[2]), fabsf(cpre[3])));
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        float d[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const float mx = fmaxf(fmaxf(acc[m][n][0], acc[m][n][1]), fmaxf(acc[m][n][2], acc[m][n][3]));
+            d[n] = mx - cpre[n];                                     // rounded subtraction is monotone: d[n] >= fl(acc - cpre[n]) for the block's elements
+        }
+        const float dm = fmaxf(fmaxf(d[0], d[1]), fmaxf(d[2], d[3]));
+        const float thr = pmin[m] - (4.8e-7f * (fabsf(pmin[m]) + fabsf(dm)) + cslack);
+        const bool f = !(dm < thr);                                  // NaN (inf - inf: an infinite column term of a padding column meets ...) flags the block
+        if (__ballot(f)) fired |= 1u << m;
+    }
+    return fired;
+}
+
 __device__ __forceinline__ u32 prescreen_block_mask(const f32x4 (&acc)[8][4], const float (&pmin)[8], float cmin)
 {
     u32 fired = 0;

@@ -253,7 +253,8 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
             // instructions instead of prescreen_col's ~15 (timing experiment, what a per-row table brought by DMA would save): +1 %; a second
             // look at the flagged blocks only -- the same test per column block, ~17 VALU, before the exact test's LDS round trip: 0.9 % SLOWER
             // on 32k x 4M, 1.8 % on 100k x 1M.)
-            blocks = prescreen_block_mask(acc, pmin, fminf(fminf(cpre[0], cpre[1]), fminf(cpre[2], cpre[3])));
+            if (H_FIRSTPASS == 1) blocks = prescreen_block_mask_cols(acc, pmin, cpre);
+            else blocks = prescreen_block_mask(acc, pmin, fminf(fminf(cpre[0], cpre[1]), fminf(cpre[2], cpre[3])));
 #ifdef NWKNN_DEV
             if (NWK_DBG(p) && (p.diag & 64)) {                      // dev census: how selective are the epilogue's tests?  (tools/f16x_census.py)
                 float rmin = pmin[0], mx = -__builtin_inff();

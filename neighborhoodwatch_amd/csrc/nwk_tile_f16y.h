@@ -197,7 +197,8 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16y(const NwkTilePara
                 rowterm[m] = *(const f32x4*)(s_pre + wr * 128 + m * 16 + 4 * g_here);
                 pmin[m] = fminf(fminf(rowterm[m][0], rowterm[m][1]), fminf(rowterm[m][2], rowterm[m][3]));
             }
-            blocks = prescreen_block_mask(acc, pmin, fminf(fminf(cpre[0], cpre[1]), fminf(cpre[2], cpre[3])));
+            if (H_FIRSTPASS == 1) blocks = prescreen_block_mask_cols(acc, pmin, cpre);
+            else blocks = prescreen_block_mask(acc, pmin, fminf(fminf(cpre[0], cpre[1]), fminf(cpre[2], cpre[3])));
         }
         if (Y_DIAG & 128) { asm volatile("" :: "s"(blocks)); blocks = 0; }   // first pass only: no block ever takes the exact test
         if (blocks) {
