@@ -68,7 +68,11 @@ def build_dev_comm(verbose: bool = False) -> Path:
     """ab/libnwknn_devcomm.so = the product's objects with ONE file, nwknn_comm.cpp, recompiled under -DNWKNN_DEV: the only build in which a
     collective transport that announces itself as a test stand-in (tests/fake_rccl) may place several shards on one GPU.  The virtual-device
     tests and the bench rehearsal load it through NWKNN_LIB_PATH; the shipped library refuses a device listed twice whatever is loaded."""
-    build(force=False, verbose=verbose)
+    # The product's objects are linked as they are.  They are only (re)built here when some are MISSING: a staleness check by modification
+    # time would fire on a box whose copy of the tree scrambled the times, and relinking libnwknn.so in place under a process that has it
+    # mapped (the test runner) is not something a helper should do.
+    if not OUT.exists() or not all(_obj(s).exists() for s in SOURCES):
+        build(force=False, verbose=verbose)
     hipcc = hipcc_path()
     out_dir = PKG.parent / "ab"
     out_dir.mkdir(exist_ok=True)
