@@ -184,6 +184,9 @@ __device__ __forceinline__ void tile_epilogue16_flagged(const NwkTileParams& p, 
         }
         const int rb = wrow0 + m * 16 + 4 * g;                       // this lane's four query rows: rb .. rb+3
         const f32x4 qn4 = *(const f32x4*)(s_qn + rb);
+        // (Tried, round 5: the block's sixteen pass masks first -- packed adds, sixteen compares into scalar registers, no branch in between --
+        // then one scalar test per mask, instead of the column-block test below: -4 % at d = 128, -2 % on C2, -1.8 % on the C3 shape,
+        // profiles/r05ae_append_variant.log.)
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             {   // the block's test once more per column block: a block with a survivor usually has it in one of the four
