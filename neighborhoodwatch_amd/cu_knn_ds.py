@@ -76,7 +76,9 @@ def tune_memory(dataset, batch_size, max_memory_threshold, rmm, column_names, de
     num_rows = dataset_count(dataset)
     total = get_gpu_memory(device)
     print("-- total memory per GPU:", total)
-    fields = [dataset.schema.field(c) for c in column_names if c in dataset.schema.names]
+    schema = dataset.schema
+    have = set(schema.names)
+    fields = [schema.field(c) for c in column_names if c in have]
     row_bytes = float_row_bytes(fields)
     used = min(batch_size, num_rows) * row_bytes
     factor = math.ceil((total * max_memory_threshold) / used)
