@@ -197,6 +197,26 @@ int nwknn_base_append_column_chunks(nwknn_handle h, const void* const* chunks, c
                                     int dtype);
 int nwknn_base_end(nwknn_handle h);
 
+/* ---- the tile loop's search, started before the tile has arrived: cu_knn.py:201-245 with the read, the upload and knn() overlapped ------
+ * The reference's loop is read -> upload -> knn() per base tile, one after the other.  A search ATTACHED to a base that is being handed
+ * over in pieces walks it as it lands: every chunk of the ordinary walk is launched as soon as the pieces that cover it have been appended
+ * (same chunk boundaries, hence the same launches in the same order: the result is bit for bit nwknn_search's), on a stream of its own
+ * beside the copies and layout kernels of the pieces that follow.
+ *   nwknn_base_begin(...)
+ *   nwknn_search_attach*(h, queries..., k, metric, index_offset, &attached)     between begin and the first piece.  *attached = 0 (and
+ *                                         NWKNN_OK) when the configured path needs the whole base before its first launch -- the fp16
+ *                                         pre-screen (its scale is the base's max |x|), the fp16 compute path (its finiteness check): search
+ *                                         after nwknn_base_end as before;
+ *   nwknn_base_append*(...) ...           each also launches the chunks it completes;
+ *   nwknn_base_end(h)                     launches the rest;
+ *   nwknn_search_collect(h, out_dist, out_idx, out_location)                    overflow repair, order, copy-out: what nwknn_search returns.
+ * While a search is attached, nwknn_search* on the handle returns NWKNN_ESTATE (the running lists are in use); a new base abandons it. */
+int nwknn_search_attach(nwknn_handle h, const void* queries, int64_t nq, int dtype, int location, int32_t k, int metric,
+                        int64_t index_offset, int* attached);
+int nwknn_search_attach_column_chunks(nwknn_handle h, const void* const* chunks, const int64_t* chunk_rows, int32_t n_chunks, int64_t nq,
+                                      int dtype, int32_t k, int metric, int64_t index_offset, int* attached);
+int nwknn_search_collect(nwknn_handle h, float* out_dist, int64_t* out_idx, int out_location);
+
 /* ---- merge of partial top-k lists: merge_indices_and_distances(), merge.py:56-101 ----------------------- */
 /* dists/idx: [n_lists][nq][k_in] (partial list l of query q at ((l*nq)+q)*k_in); idx < 0 marks an empty
  * slot.  Writes the k_out smallest by (distance, index) into out_dist/out_idx [nq][k_out].

@@ -29,6 +29,7 @@ EXPORTS = [
     "nwknn_merge", "nwknn_generate", "nwknn_set_base_columns", "nwknn_search_columns",
     "nwknn_set_base_column_chunks", "nwknn_search_column_chunks",
     "nwknn_base_begin", "nwknn_base_append", "nwknn_base_append_column_chunks", "nwknn_base_end",
+    "nwknn_search_attach", "nwknn_search_attach_column_chunks", "nwknn_search_collect",
     "nwknn_maxsim_set_docs", "nwknn_maxsim_search", "nwknn_tile_kernel_name",
     "nwknn_comm_create", "nwknn_comm_destroy", "nwknn_comm_device_count", "nwknn_comm_engine", "nwknn_comm_set_option",
     "nwknn_comm_set_base", "nwknn_comm_generate_base", "nwknn_search_sharded", "nwknn_comm_get_stats", "nwknn_comm_merge_lists", "nwknn_mfma_ceiling", "nwknn_fabric_probe", "nwknn_pair_distances", "nwknn_pair_dots",
@@ -155,6 +156,10 @@ def load() -> ctypes.CDLL:
     L.nwknn_base_append.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int]
     L.nwknn_base_append_column_chunks.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_int64), c_int32, c_int64, c_int]
     L.nwknn_base_end.argtypes = [c_void_p]
+    L.nwknn_search_attach.argtypes = [c_void_p, c_void_p, c_int64, c_int, c_int, c_int32, c_int, c_int64, POINTER(c_int)]
+    L.nwknn_search_attach_column_chunks.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_int64), c_int32, c_int64, c_int, c_int32, c_int, c_int64,
+                                                    POINTER(c_int)]
+    L.nwknn_search_collect.argtypes = [c_void_p, c_void_p, c_void_p, c_int]
     L.nwknn_maxsim_set_docs.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int, c_int]
     L.nwknn_maxsim_search.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int, c_int, c_int32, c_int64, c_void_p, c_void_p, c_int]
     L.nwknn_generate.argtypes = [c_void_p, c_uint64, c_int64, c_int64, c_int32, c_int, c_void_p]

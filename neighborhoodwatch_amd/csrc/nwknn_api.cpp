@@ -97,6 +97,23 @@ struct DevBuf {
 
 struct EvPair { hipEvent_t a, b; int kind; };   // kind: 0 tile, 1 compact, 2 prep, 3 rescore
 
+struct SearchPlan {
+    int cap; long long first, max_chunk, safe; int tile_rows; int granule;
+    bool pre;                                   // filtered chunks run the fp16 pre-screen + fp32 rescoring
+    bool native16;                              // exact fp16 mode: the fp16 rows ARE the data; rescoring walks them, the dense chunk is rescored too
+    bool copies16;                              // the tile kernel reads the fp16 COPIES (fp32 data; cosine's unit rows), not the native fp16 rows
+    float pre_scale, pre_eps_half, pre_aq, pre_ab, pre_cst;
+    float chk_scale = 1.0f;                     // fraction of the bound the rescoring kernel holds the invariant against (option pre_check_ppm on attempt 0)
+};
+
+// A search that rides a base which is still arriving (nwknn_search_attach / nwknn_search_collect): the plan of the walk and how far it got.
+struct FollowState {
+    int active = 0;
+    SearchPlan pl;
+    int k = 0, metric = 0;
+    long long nq = 0, nq_pad = 0, index_offset = 0, seen = 0, growth = 1, rows = 0;
+};
+
 struct nwknn_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -107,6 +124,9 @@ struct nwknn_ctx {
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_prepped[2] = {nullptr, nullptr};
     hipEvent_t ev_cal[3] = {nullptr, nullptr, nullptr};      // walk calibration of the direct fp32 kernel (search_attempt)
     int walk_auto_q = 0, walk_auto_sq = 3;                   // what "auto" means for the fp32 kernel's super-tile walk in the current search
+    FollowState fw;
+    hipStream_t fw_stream = nullptr;                         // the attached search's chunks run here, beside the layout kernels of later pieces
+    hipEvent_t ev_fw_ready = nullptr, ev_fw_done = nullptr;
     long long up_seq = 0;           // slabs the column upload pipeline has sent so far (never reset: the two pinned / device slabs alternate across calls)
     // base shard
     DevBuf bp, bn, braw;
@@ -270,6 +290,9 @@ extern "C" int nwknn_destroy(nwknn_handle h)
     }
     for (int i = 0; i < 3; ++i) if (h->ev_cal[i]) (void)hipEventDestroy(h->ev_cal[i]);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->ev_fw_ready) (void)hipEventDestroy(h->ev_fw_ready);
+    if (h->ev_fw_done) (void)hipEventDestroy(h->ev_fw_done);
+    if (h->fw_stream) (void)hipStreamDestroy(h->fw_stream);
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -627,6 +650,10 @@ static int base_plan(nwknn_ctx* h, int64_t rows, int32_t d, int dtype, bool cols
     bp->rows_pad = round_up(rows, (bp->f16 || bp->pre) ? NWK_F16_TILE_ROWS : NWK_TILE_ROWS);
     bp->dp = (int)round_up(d, bp->f16 ? NWK_K_ALIGN_F16 : NWK_K_ALIGN);
     h->sb_rows = 0;                                                 // a half-streamed base is abandoned by any new base
+    if (h->fw.active) {                                             // ... and so is a search that was riding it (its chunks may still read bp)
+        h->fw.active = 0;
+        if (h->fw_stream) HIPCHK(hipStreamSynchronize(h->fw_stream));
+    }
     h->nb = 0;                                                      // ... and the previous base is gone as soon as its buffers may move
     RCCHK(h->bp.ensure((size_t)bp->rows_pad * bp->dp * (bp->f16 ? 2 : 4)));
     RCCHK(h->bn.ensure((size_t)bp->rows_pad * 4));
@@ -699,6 +726,8 @@ static int base_begin_common(nwknn_ctx* h, int64_t rows, int32_t d, int dtype)
     return NWKNN_OK;
 }
 
+static int follow_advance(nwknn_ctx* h, bool final);
+
 static int base_append_check(nwknn_ctx* h, const char* what, int64_t n)
 {
     if (!h) return fail(NWKNN_EINVAL, "%s: null handle", what);
@@ -717,7 +746,7 @@ static int base_append_columns_common(nwknn_ctx* h, const ColumnSource& src, int
                                           h->bn.as<float>() + h->sb_done, false);
     if (rc != NWKNN_OK) { h->sb_rows = 0; return rc; }              // a failed piece abandons the base (streams may hold half of it)
     h->sb_done += n;
-    return NWKNN_OK;
+    return follow_advance(h, false);
 }
 
 static int base_append_rows_common(nwknn_ctx* h, const void* rows_ptr, int64_t n, int dtype, int location)
@@ -730,7 +759,7 @@ static int base_append_rows_common(nwknn_ctx* h, const void* rows_ptr, int64_t n
                                   (char*)h->bp.p + (size_t)h->sb_done * h->sb_dp * out_es, h->bn.as<float>() + h->sb_done);
     if (rc != NWKNN_OK) { h->sb_rows = 0; return rc; }
     h->sb_done += n;
-    return NWKNN_OK;
+    return follow_advance(h, false);
 }
 
 static int base_end_common(nwknn_ctx* h)
@@ -751,6 +780,10 @@ static int base_end_common(nwknn_ctx* h)
         HIPCHK(nwk_launch_prep_strided(h->stream, h->bp.p, NWKNN_DTYPE_F32, 1, 1, 0, b.d, b.rows_pad - b.rows, b.dp, b.f16,
                                        (char*)h->bp.p + (size_t)b.rows * b.dp * out_es, h->bn.as<float>() + b.rows));
         ev_end(h, e);
+    }
+    if (h->fw.active) {                                               // the attached search walks what is left; the compute stream then waits for it
+        const int rc = follow_advance(h, true);
+        if (rc != NWKNN_OK) return rc;
     }
     return base_finish(h, b);                                         // its first reduction synchronises the compute stream: every piece has landed
 }
@@ -801,15 +834,6 @@ extern "C" int nwknn_base_end(nwknn_handle h)
 }
 
 // ---- search -----------------------------------------------------------------------------------------
-struct SearchPlan {
-    int cap; long long first, max_chunk, safe; int tile_rows; int granule;
-    bool pre;                                   // filtered chunks run the fp16 pre-screen + fp32 rescoring
-    bool native16;                              // exact fp16 mode: the fp16 rows ARE the data; rescoring walks them, the dense chunk is rescored too
-    bool copies16;                              // the tile kernel reads the fp16 COPIES (fp32 data; cosine's unit rows), not the native fp16 rows
-    float pre_scale, pre_eps_half, pre_aq, pre_ab, pre_cst;
-    float chk_scale = 1.0f;                     // fraction of the bound the rescoring kernel holds the invariant against (option pre_check_ppm on attempt 0)
-};
-
 static int make_plan(nwknn_ctx* h, int k, long long nq, bool pre, SearchPlan* pl)
 {
     long long cap = h->opt_capacity;
@@ -1039,6 +1063,51 @@ static int repair(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long lo
     return NWKNN_OK;
 }
 
+// The end of a walk: overflow repair, the pre-screen's invariant, the k nearest of every list in order, the copy to the caller.
+static int search_finish(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long long nq, long long nq_pad, int64_t index_offset,
+                         float* out_dist, int64_t* out_idx, int out_location, long long* violations)
+{
+    u32 any = 0;
+    HIPCHK(hipMemcpyAsync(&any, h->ovf_any.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (any) RCCHK(repair(h, pl, metric, k, nq_pad));
+    if (pl.pre) {                                                  // the invariant of the pre-screen, counted by every rescoring launch
+        u64 chk[3] = {0, 0, 0};
+        HIPCHK(hipMemcpyAsync(chk, h->chk.p, sizeof chk, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->stats.prescreen_checked = (int64_t)chk[0];
+        float w;
+        const u32 wb = (u32)chk[2];
+        memcpy(&w, &wb, 4);
+        h->stats.prescreen_worst = (double)w;
+        if (chk[1] != 0) { *violations = (long long)chk[1]; return NWKNN_OK; }      // this attempt is discarded by the caller
+    }
+
+    float* od = out_dist;
+    long long* oi = (long long*)out_idx;
+    if (out_location == NWKNN_HOST) {
+        RCCHK(h->out_d.ensure((size_t)nq * k * 4));
+        RCCHK(h->out_i.ensure((size_t)nq * k * 8));
+        od = h->out_d.as<float>(); oi = h->out_i.as<long long>();
+    }
+    HIPCHK(nwk_launch_finalize(h->stream, h->buf.as<u64>(), h->cnt.as<u32>(), pl.cap, k, nq, index_offset, od, oi, 0));
+    if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_end, h->stream));
+    if (out_location == NWKNN_HOST) {
+        HIPCHK(hipMemcpyAsync(out_dist, od, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(out_idx, oi, (size_t)nq * k * 8, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->opt_profile) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev_begin, h->ev_end));
+        h->stats.total_ms = ms;
+        ev_collect(h, &h->stats.tile_ms, &h->stats.compact_ms, &h->stats.prep_ms, &h->stats.rescore_ms);
+        h->stats.prep_ms += h->base_prep_ms;      // the base layout/norm pass that preceded this search
+        h->base_prep_ms = 0.0;
+    }
+    return NWKNN_OK;
+}
+
 // One attempt of a search.  attempt 0 is the search as configured.  A later attempt follows a pre-screened one whose invariant failed
 // (*violations > 0 on return: nothing was written to the outputs): fp32 data then runs the direct kernel; exact fp16 mode, whose
 // rows have no fp32 form, widens its bound 16x per attempt and is checked again.
@@ -1049,6 +1118,7 @@ static int search_attempt(nwknn_ctx* h, const void* queries, const ColumnSource*
     if (!h || (!queries && !qcolumns) || !out_dist || !out_idx) return fail(NWKNN_EINVAL, "nwknn_search: null argument");
     if (!h->bp.p || h->nb <= 0) return fail(NWKNN_ESTATE, "nwknn_search: call nwknn_set_base first");
     if (h->ms_docs > 0) return fail(NWKNN_ESTATE, "nwknn_search: the handle holds MaxSim documents; call nwknn_set_base for kNN");
+    if (h->fw.active) return fail(NWKNN_ESTATE, "nwknn_search: an attached search holds the lists; call nwknn_search_collect first");
     if (nq <= 0) return fail(NWKNN_EINVAL, "nwknn_search: nq=%lld must be positive", (long long)nq);
     if (k <= 0 || k > h->nb) return fail(NWKNN_EINVAL, "nwknn_search: k=%d must satisfy 0 < k <= %lld base rows", k, h->nb);   // cu_knn.py:237
     if (k > NWK_MAX_K) return fail(NWKNN_EINVAL, "nwknn_search: k=%d exceeds the supported maximum %d", k, NWK_MAX_K);
@@ -1216,45 +1286,7 @@ static int search_attempt(nwknn_ctx* h, const void* queries, const ColumnSource*
     }
     h->walk_auto_q = 0; h->walk_auto_sq = 3;                       // repairs and later searches start from the default again
 
-    u32 any = 0;
-    HIPCHK(hipMemcpyAsync(&any, h->ovf_any.p, 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (any) RCCHK(repair(h, pl, metric, k, nq_pad));
-    if (pl.pre) {                                                  // the invariant of the pre-screen, counted by every rescoring launch
-        u64 chk[3] = {0, 0, 0};
-        HIPCHK(hipMemcpyAsync(chk, h->chk.p, sizeof chk, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        h->stats.prescreen_checked = (int64_t)chk[0];
-        float w;
-        const u32 wb = (u32)chk[2];
-        memcpy(&w, &wb, 4);
-        h->stats.prescreen_worst = (double)w;
-        if (chk[1] != 0) { *violations = (long long)chk[1]; return NWKNN_OK; }      // this attempt is discarded by the caller
-    }
-
-    float* od = out_dist;
-    long long* oi = (long long*)out_idx;
-    if (out_location == NWKNN_HOST) {
-        RCCHK(h->out_d.ensure((size_t)nq * k * 4));
-        RCCHK(h->out_i.ensure((size_t)nq * k * 8));
-        od = h->out_d.as<float>(); oi = h->out_i.as<long long>();
-    }
-    HIPCHK(nwk_launch_finalize(h->stream, h->buf.as<u64>(), h->cnt.as<u32>(), pl.cap, k, nq, index_offset, od, oi, 0));
-    if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_end, h->stream));
-    if (out_location == NWKNN_HOST) {
-        HIPCHK(hipMemcpyAsync(out_dist, od, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(out_idx, oi, (size_t)nq * k * 8, hipMemcpyDeviceToHost, h->stream));
-    }
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->opt_profile) {
-        float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, h->ev_begin, h->ev_end));
-        h->stats.total_ms = ms;
-        ev_collect(h, &h->stats.tile_ms, &h->stats.compact_ms, &h->stats.prep_ms, &h->stats.rescore_ms);
-        h->stats.prep_ms += h->base_prep_ms;      // the base layout/norm pass that preceded this search
-        h->base_prep_ms = 0.0;
-    }
-    return NWKNN_OK;
+    return search_finish(h, pl, metric, k, nq, nq_pad, index_offset, out_dist, out_idx, out_location, violations);
 }
 
 static int search_common(nwknn_ctx* h, const void* queries, const ColumnSource* qcolumns, int64_t nq, int dtype, int location, int32_t k, int metric,
@@ -1275,6 +1307,134 @@ static int search_common(nwknn_ctx* h, const void* queries, const ColumnSource* 
                 attempt, h->f16 ? "under a 16x wider bound" : "on the direct fp32 kernel");                                  // never silent
         if (attempt >= 3) return fail(NWKNN_EHIP, "pre-screen invariant still violated after widening the bound %d times (%lld pairs)", attempt, bad);
     }
+}
+
+// ---- a search that rides a base handed over in pieces -----------------------------------------------------------------------------------
+// Through files the base arrives at the speed of the parquet decoder (10-18 GB/s on the GPU box's host), the direct kernel walks it at the
+// equivalent of ~27 GB/s for 10 000 queries -- and until round 5 it started only after the last piece had landed: 1.4 s of a 4 s stage with
+// the decoder idle.  The walk needs nothing from rows it has not reached (a chunk reads its own rows and the running lists), so an attached
+// search launches every chunk of the ordinary walk -- same boundaries, hence the same launches in the same order -- as soon as the pieces
+// that cover it have been appended: on a stream of its own, ordered behind the layout kernels by an event, beside the copies and layout
+// kernels of the pieces that follow.  nwknn_base_end launches what is left, nwknn_search_collect repairs / sorts / copies out as
+// nwknn_search does.  Direct fp32 path only: the pre-screen's scale and exact fp16 mode's finiteness check need the whole base
+// (*attached = 0: search after nwknn_base_end as before; the pre-screened search of that shape takes 0.17 s, there is nothing to hide).
+static int search_attach_common(nwknn_ctx* h, const void* queries, const ColumnSource* qcolumns, int64_t nq, int dtype, int location, int32_t k,
+                                int metric, int64_t index_offset, int* attached)
+{
+    if (!h || (!queries && !qcolumns) || !attached) return fail(NWKNN_EINVAL, "nwknn_search_attach: null argument");
+    *attached = 0;
+    if (h->sb_rows <= 0 || h->sb_done != 0) return fail(NWKNN_ESTATE, "nwknn_search_attach: call it between nwknn_base_begin and the first piece");
+    if (h->fw.active) return fail(NWKNN_ESTATE, "nwknn_search_attach: a search is attached to this base already");
+    if (nq <= 0) return fail(NWKNN_EINVAL, "nwknn_search_attach: nq=%lld must be positive", (long long)nq);
+    if (k <= 0 || k > h->sb_rows) return fail(NWKNN_EINVAL, "nwknn_search_attach: k=%d must satisfy 0 < k <= %lld base rows", k, h->sb_rows);
+    if (k > NWK_MAX_K) return fail(NWKNN_EINVAL, "nwknn_search_attach: k=%d exceeds the supported maximum %d", k, NWK_MAX_K);
+    if (metric < 0 || metric > 2) return fail(NWKNN_EINVAL, "nwknn_search_attach: unknown metric %d", metric);
+    if (dtype != NWKNN_DTYPE_F32 && !(qcolumns && dtype == NWKNN_DTYPE_F64)) {
+        if (dtype == NWKNN_DTYPE_F16) return NWKNN_OK;                        // fp16 queries belong to the fp16 compute path
+        return fail(NWKNN_EINVAL, "nwknn_search_attach: unsupported query dtype %d", dtype);
+    }
+    if (location != NWKNN_HOST && location != NWKNN_DEVICE) return fail(NWKNN_EINVAL, "nwknn_search_attach: bad location");
+    if (h->sb_f16 || h->sb_pre) return NWKNN_OK;
+    RCCHK(use_device(h));
+    if (!h->fw_stream) HIPCHK(hipStreamCreateWithFlags(&h->fw_stream, hipStreamNonBlocking));
+    if (!h->ev_fw_ready) HIPCHK(hipEventCreateWithFlags(&h->ev_fw_ready, hipEventDisableTiming));
+    if (!h->ev_fw_done) HIPCHK(hipEventCreateWithFlags(&h->ev_fw_done, hipEventDisableTiming));
+    // the geometry the walk reads; nb stays 0 (no ordinary search on half a base) and is lent to the chunk launches by follow_advance
+    h->nb_pad = h->sb_rows_pad; h->d = h->sb_d; h->dp = h->sb_dp; h->f16 = 0; h->ms_docs = 0; h->pre_ok = 0; h->f16_finite = 0;
+    FollowState f;
+    RCCHK(make_plan(h, k, nq, false, &f.pl));
+    f.k = k; f.metric = metric; f.nq = nq; f.nq_pad = round_up(nq, NWK_QPAD_ROWS); f.index_offset = index_offset; f.seen = 0; f.rows = h->sb_rows;
+    f.growth = h->opt_chunk_growth;
+    if (f.growth <= 0) f.growth = std::max<long long>(1, std::min<long long>(3, (long long)((0.8 * f.pl.cap / k - 1.0) / 1.5)));
+    const long long nq_pad = f.nq_pad;
+    RCCHK(h->qp.ensure((size_t)nq_pad * h->dp * 4));
+    RCCHK(h->qn.ensure((size_t)nq_pad * 4));
+    RCCHK(h->tau.ensure((size_t)nq_pad * 8));
+    RCCHK(h->cnt.ensure((size_t)nq_pad * 4));
+    RCCHK(h->ovf.ensure((size_t)nq_pad * 4));
+    RCCHK(h->ovf_any.ensure(16));
+    RCCHK(h->buf.ensure((size_t)nq_pad * f.pl.cap * 8));
+    memset(&h->stats, 0, sizeof h->stats);
+    h->stats.nq = nq; h->stats.nb = h->sb_rows; h->stats.d = h->d; h->stats.k = k;
+    if (h->opt_profile) HIPCHK(hipEventRecord(h->ev_begin, h->stream));
+    if (qcolumns) RCCHK(stage_and_prep_columns(h, *qcolumns, dtype, 0, nq, h->d, nq_pad, h->dp, h->qraw, h->qp.p, h->qn.as<float>()));
+    else RCCHK(stage_and_prep(h, queries, location, false, 0, nq, h->d, nq_pad, h->dp, h->qraw, h->qp.p, h->qn.as<float>()));
+    HIPCHK(hipMemsetAsync(h->tau.p, 0xFF, (size_t)nq_pad * 8, h->stream));
+    HIPCHK(hipMemsetAsync(h->cnt.p, 0, (size_t)nq_pad * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->ovf.p, 0, (size_t)nq_pad * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->ovf_any.p, 0, 4, h->stream));
+    h->walk_auto_q = 0; h->walk_auto_sq = 3;
+    f.active = 1;
+    h->fw = f;
+    *attached = 1;
+    return NWKNN_OK;
+}
+
+// Launch every chunk of the attached search's walk whose rows have been appended (final: the base is complete, padding included).
+static int follow_advance(nwknn_ctx* h, bool final)
+{
+    FollowState& f = h->fw;
+    if (!f.active) return NWKNN_OK;
+    struct Lend {                                                   // the walk's helpers read h->stream / h->nb: lent for the launches, always handed back
+        nwknn_ctx* h; hipStream_t stream; long long nb; bool on = false;
+        ~Lend() { if (on) { h->stream = stream; h->nb = nb; } }
+    } lend{h, h->stream, h->nb};
+    const long long avail = final ? h->nb_pad : h->sb_done;
+    int rc = NWKNN_OK;
+    while (f.seen < h->nb_pad) {
+        const long long m = f.seen == 0 ? std::min(h->nb_pad, f.pl.first) : std::min(std::min(f.pl.max_chunk, f.seen * f.growth), h->nb_pad - f.seen);
+        if (f.seen + m > avail) break;
+        if (!lend.on) {                                             // everything appended so far has been enqueued on the compute stream
+            HIPCHK(hipEventRecord(h->ev_fw_ready, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->fw_stream, h->ev_fw_ready, 0));
+            lend.on = true;
+            h->stream = h->fw_stream;
+            h->nb = f.rows;
+        }
+        rc = run_chunk(h, f.pl, f.metric, f.k, f.nq_pad, f.seen, m, f.seen == 0, nullptr, 0, false, false);
+        if (rc != NWKNN_OK) break;
+        f.seen += m;
+    }
+    if (rc != NWKNN_OK) { f.active = 0; return rc; }
+    if (final) {
+        HIPCHK(hipEventRecord(h->ev_fw_done, h->fw_stream));
+        HIPCHK(hipStreamWaitEvent(lend.stream, h->ev_fw_done, 0));
+    }
+    return NWKNN_OK;
+}
+
+static int search_collect_common(nwknn_ctx* h, float* out_dist, int64_t* out_idx, int out_location)
+{
+    if (!h || !out_dist || !out_idx) return fail(NWKNN_EINVAL, "nwknn_search_collect: null argument");
+    if (out_location != NWKNN_HOST && out_location != NWKNN_DEVICE) return fail(NWKNN_EINVAL, "nwknn_search_collect: bad location");
+    FollowState& f = h->fw;
+    if (!f.active) return fail(NWKNN_ESTATE, "nwknn_search_collect: no search is attached (nwknn_search_attach reported 0, or the base was abandoned)");
+    if (h->sb_rows > 0 || h->nb <= 0 || f.seen < h->nb_pad) return fail(NWKNN_ESTATE, "nwknn_search_collect: call nwknn_base_end first");
+    RCCHK(use_device(h));
+    f.active = 0;
+    h->base_prep_ms = 0.0;                                          // the layout passes lie inside this search's span
+    long long violations = 0;
+    return search_finish(h, f.pl, f.metric, f.k, f.nq, f.nq_pad, f.index_offset, out_dist, out_idx, out_location, &violations);
+}
+
+extern "C" int nwknn_search_attach(nwknn_handle h, const void* queries, int64_t nq, int dtype, int location, int32_t k, int metric, int64_t index_offset,
+                                   int* attached)
+{
+    if (!queries) return fail(NWKNN_EINVAL, "nwknn_search_attach: null argument");
+    return guarded([&] { return search_attach_common(h, queries, nullptr, nq, dtype, location, k, metric, index_offset, attached); });
+}
+
+extern "C" int nwknn_search_attach_column_chunks(nwknn_handle h, const void* const* chunks, const int64_t* chunk_rows, int32_t n_chunks, int64_t nq,
+                                                 int dtype, int32_t k, int metric, int64_t index_offset, int* attached)
+{
+    if (!chunks || !chunk_rows || n_chunks <= 0) return fail(NWKNN_EINVAL, "nwknn_search_attach_column_chunks: null or empty chunk table");
+    const ColumnSource src{chunks, chunk_rows, n_chunks};
+    return guarded([&] { return search_attach_common(h, nullptr, &src, nq, dtype, NWKNN_HOST, k, metric, index_offset, attached); });
+}
+
+extern "C" int nwknn_search_collect(nwknn_handle h, float* out_dist, int64_t* out_idx, int out_location)
+{
+    return guarded([&] { return search_collect_common(h, out_dist, out_idx, out_location); });
 }
 
 extern "C" int nwknn_search(nwknn_handle h, const void* queries, int64_t nq, int dtype, int location, int32_t k, int metric, int64_t index_offset,

@@ -187,13 +187,16 @@ def base_geometry(schema):
     return len(fields), ("f16" if fields and all(pa.types.is_float16(f.type) for f in fields) else "f32")
 
 
-def stream_tiles(eng, rows: ParquetRows, tiles, readers=None):
+def stream_tiles(eng, rows: ParquetRows, tiles, readers=None, follow=None):
     """Load base tiles ``[(first row, rows), ...]`` of a lazy parquet window into ``eng`` one after the other, each PIECE BY PIECE: the
     row groups of ALL the listed tiles are decoded in row order by a pool of reader threads (``PieceReader``: own memory-mapped handles, a
     bounded number of pieces ahead), and every decoded piece goes straight to the GPU (``base_append*``: gather into pinned memory, H2D copy
     and layout kernel asynchronous) while the next ones are decoded.  Yields the tile's position in ``tiles`` once the tile is resident
     (``base_end`` done); while the consumer searches it, the readers are already decoding the first pieces of the next tile.
-    The reference reads the whole file, then uploads tile after tile (cu_knn.py:112-114,201-211)."""
+    The reference reads the whole file, then uploads tile after tile (cu_knn.py:112-114,201-211).
+    ``follow(i) -> (queries, k, metric, index_offset)``: the search the consumer will run on tile i, attached to the tile before its first
+    piece (``KnnEngine.search_attach``) so that it walks the tile while it arrives; when ``eng.search_attached`` is true at the yield, the
+    consumer takes the result with ``eng.search_collect()`` instead of searching."""
     dims, dtype = base_geometry(rows.schema)
     counts, pieces = [], []
     for off, length in tiles:
@@ -210,6 +213,9 @@ def stream_tiles(eng, rows: ParquetRows, tiles, readers=None):
     with PieceReader(pieces, readers=readers, transform=ready) as reader, ThreadPoolExecutor(max_workers=1, thread_name_prefix="nw-drop") as dropper:
         for i, ((off, length), n_pieces) in enumerate(zip(tiles, counts)):
             eng.base_begin(length, dims, dtype)
+            if follow is not None:
+                queries, k, metric, index_offset = follow(i)
+                eng.search_attach(queries, k, metric, index_offset=index_offset)
             for _ in range(n_pieces):
                 item = next(reader)
                 if item[1] == "matrix":
@@ -408,7 +414,8 @@ def process_batches(data_dir,
             todo = plan()
             if isinstance(base_table, ParquetRows):
                 dims = base_geometry(base_table.schema)[0]
-                for i in stream_tiles(eng, base_table, [(off, length) for _, off, length, _ in todo]):
+                for i in stream_tiles(eng, base_table, [(off, length) for _, off, length, _ in todo],
+                                      follow=lambda i: (queries, k, metric, todo[i][1])):
                     start, batch_offset, batch_length, tag = todo[i]
                     yield start, batch_offset, batch_length, tag, dims
                 return
@@ -435,7 +442,10 @@ def process_batches(data_dir,
                 for start, batch_offset, batch_length, tag, dims in resident_tiles():
                     assert (k <= batch_length)                              # cu_knn.py:237
                     print(f"Dataset shape: ({batch_length}, {dims}), Query shape: ({len(query_table)}, {dims})")
-                    distances, indices = engine_search(eng, queries, k, metric, index_offset=batch_offset)   # + batch_offset, cu_knn.py:273
+                    if eng.search_attached:                                 # the search walked the tile while it arrived
+                        distances, indices = eng.search_collect()
+                    else:
+                        distances, indices = engine_search(eng, queries, k, metric, index_offset=batch_offset)   # + batch_offset, cu_knn.py:273
                     assert (len(distances) == len(query_table))             # cu_knn.py:281-282
                     assert (len(indices) == len(query_table))
                     writes.extend(write_pair(start, distances, indices, tag))

@@ -241,7 +241,7 @@ def process_dataset_batches(data_dir,
         groups of all remaining batches are decoded in order by reader threads and handed to the GPU as they arrive (cu_knn.stream_tiles),
         so decode, upload and -- across batches -- search overlap; in-memory rows are sliced and uploaded one batch ahead."""
         if isinstance(base_rows, ParquetRows):
-            for i in stream_tiles(eng, base_rows, todo):
+            for i in stream_tiles(eng, base_rows, todo, follow=lambda i: (queries, k, metric, todo[i][0])):
                 yield todo[i]
             return
 
@@ -260,7 +260,10 @@ def process_dataset_batches(data_dir,
         with ThreadPoolExecutor(max_workers=1) as writer:
             for batch_offset, rows in resident_batches():
                 assert (k <= rows)                                                # cu_knn_ds.py:203
-                d, i = engine_search(eng, queries, k, metric, index_offset=batch_offset, out_device=True)   # + batch_offset, cu_knn_ds.py:216
+                if eng.search_attached:                                           # the search walked the batch while it arrived
+                    d, i = eng.search_collect(out_device=True)
+                else:
+                    d, i = engine_search(eng, queries, k, metric, index_offset=batch_offset, out_device=True)   # + batch_offset, cu_knn_ds.py:216
                 if run_d is None:
                     run_d, run_i = d, i
                 else:                                                             # fold on the device: [2,Q,k] -> [Q,k]

@@ -237,6 +237,7 @@ class KnnEngine:
             raise ValueError("dataset is empty")
         dt = {"f32": DTYPE_F32, "fp32": DTYPE_F32, "f16": DTYPE_F16, "fp16": DTYPE_F16}[dtype]
         self.rows = 0
+        self._attached = None
         check(self._L.nwknn_base_begin(self._h, int(rows), int(dim), dt), "nwknn_base_begin")
         self._pending = (int(rows), int(dim))
 
@@ -274,6 +275,65 @@ class KnnEngine:
     def base_end(self) -> None:
         check(self._L.nwknn_base_end(self._h), "nwknn_base_end")
         self.rows, self.dim = self._pending
+
+    # -- a search that walks the base while it arrives (nwknn_search_attach / nwknn_search_collect) --------------------------------------
+    def search_attach(self, queries, k: int, metric: str = "sqeuclidean", index_offset: int = 0) -> bool:
+        """Between ``base_begin`` and the first piece: start a search that launches every chunk of its walk as soon as the pieces covering
+        it have been appended.  ``queries``: a row-major matrix, or ``("columns", per-dimension arrays)`` / ``("matrix", array)`` as
+        ``cu_knn.table_input`` yields.  -> True when the search is attached (``search_collect`` after ``base_end`` returns its result,
+        the bits ``search`` would give); False when the configured path needs the whole base first (fp16 compute path, pre-screen):
+        call ``search`` after ``base_end`` as usual."""
+        metric = resolve_metric(metric)
+        if not getattr(self, "_pending", None):
+            raise _lib.NwknnError("search_attach before base_begin")
+        rows, dim = self._pending
+        kind, data = queries if isinstance(queries, tuple) and len(queries) == 2 and isinstance(queries[0], str) else ("matrix", queries)
+        attached = ctypes.c_int(0)
+        if kind == "columns":
+            table, rows_arr, n_chunks, nq, qdim, dt, keep = self._columns(data, "queries")
+        else:
+            ptr, nq, qdim, dt, loc, keep = self._matrix(data, "queries")
+        if qdim != dim:
+            raise ValueError(f"queries have dimension {qdim}, dataset has {dim}")
+        if not (0 < int(k) <= rows):
+            raise ValueError(f"k={k} must satisfy 0 < k <= {rows} dataset rows")           # cu_knn.py:237
+        if nq == 0:
+            raise ValueError("queries are empty")
+        if kind == "columns":
+            check(self._L.nwknn_search_attach_column_chunks(self._h, table, rows_arr, n_chunks, nq, dt, int(k), METRIC_IDS[metric], int(index_offset),
+                                                            ctypes.byref(attached)), "nwknn_search_attach_column_chunks")
+        else:
+            if loc == DEVICE:
+                self._order_after_torch(keep, "queries")
+            check(self._L.nwknn_search_attach(self._h, ctypes.c_void_p(ptr), nq, dt, loc, int(k), METRIC_IDS[metric], int(index_offset),
+                                              ctypes.byref(attached)), "nwknn_search_attach")
+        del keep
+        self._attached = (nq, int(k)) if attached.value else None
+        return bool(attached.value)
+
+    @property
+    def search_attached(self) -> bool:
+        return bool(getattr(self, "_attached", None))
+
+    def search_collect(self, out_device: bool = False):
+        """After ``base_end``: the attached search's (distances [q,k] f32, indices [q,k] i64)."""
+        if not getattr(self, "_attached", None):
+            raise _lib.NwknnError("search_collect without an attached search")
+        nq, k = self._attached
+        self._attached = None
+        if out_device:
+            import torch
+            dev = torch.device("cuda", self.device)
+            od = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            oi = torch.empty((nq, k), dtype=torch.int64, device=dev)
+            torch.cuda.current_stream(dev).synchronize()
+            pd_, pi_, oloc = od.data_ptr(), oi.data_ptr(), DEVICE
+        else:
+            od = np.empty((nq, k), dtype=np.float32)
+            oi = np.empty((nq, k), dtype=np.int64)
+            pd_, pi_, oloc = od.ctypes.data, oi.ctypes.data, HOST
+        check(self._L.nwknn_search_collect(self._h, ctypes.c_void_p(pd_), ctypes.c_void_p(pi_), oloc), "nwknn_search_collect")
+        return od, oi
 
     def search_columns(self, columns, k: int, metric: str = "sqeuclidean", index_offset: int = 0, out_device: bool = False):
         """Queries as per-dimension host arrays (or chunk lists).  -> (distances [q,k] f32, indices [q,k] i64): numpy arrays, or torch

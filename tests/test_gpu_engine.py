@@ -392,6 +392,90 @@ def test_a_base_handed_over_in_pieces_gives_the_bits_of_the_whole(oracle, mode):
         assert np.array_equal(idx, ri) and _same_bits(dist, rd)
 
 
+@pytest.mark.parametrize("metric", ["sqeuclidean", "one_minus_dot", "cosine"])
+@pytest.mark.parametrize("queries_as", ["matrix", "columns"])
+def test_a_search_attached_to_an_arriving_base_gives_the_bits_of_the_search_after_it(oracle, metric, queries_as):
+    """nwknn_search_attach / nwknn_search_collect (how the file API now overlaps knn() with the decoding of the tile): the walk's chunks are
+    launched as the pieces that cover them are appended.  max_chunk = 2 048 rows and pieces of 1 / 2 559 / 1 / 7 000 / rest rows: chunks are
+    launched from inside appends (some appends complete none, some several) and from base_end; the result must be the oracle's bits, the
+    launches those of the ordinary search, and the base left behind must serve ordinary searches."""
+    from neighborhoodwatch_amd import KnnEngine
+    from neighborhoodwatch_amd._lib import NwknnError
+    B, Q, d, k = 30_001, 333, 80, 25
+    base, queries = oracle.gen(0xA71, 0, B, d), oracle.gen(0xA72, 0, Q, d)
+    rd, ri = oracle.knn_canonical(base, queries, k, metric)
+    cuts = [0, 1, 2_560, 2_561, 9_561, B]
+    q_in = ("columns", [np.ascontiguousarray(queries[:, j]) for j in range(d)]) if queries_as == "columns" else queries
+    with KnnEngine(0) as eng:
+        eng.set_option("upload_slab_mib", 1)
+        eng.set_option("max_chunk", 2048)
+        eng.set_base(base)
+        eng.search(queries, k, metric)
+        plain = eng.stats()
+        eng.base_begin(B, d)
+        assert eng.search_attach(q_in, k, metric, index_offset=1000) is True
+        launched = []
+        for n, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+            piece = base[a:b]
+            if n % 2:
+                eng.base_append(piece)
+            else:
+                eng.base_append_columns([np.ascontiguousarray(piece[:, j]) for j in range(d)])
+            launched.append(eng.stats()["tile_launches"])
+            with pytest.raises(NwknnError):
+                eng.search(queries, k, metric)                         # half a base, and the lists are in use
+        assert launched[0] == 0 and launched[-1] > launched[1] > 0 and launched[-1] < plain["tile_launches"]     # chunks went out under the appends
+        eng.base_end()
+        with pytest.raises(NwknnError, match="nwknn_search_collect first"):
+            eng.search(queries, k, metric)
+        dist, idx = eng.search_collect()
+        st = eng.stats()
+        assert np.array_equal(idx, ri + 1000) and _same_bits(dist, rd)
+        assert st["tile_launches"] == plain["tile_launches"] and st["compact_launches"] == plain["compact_launches"]
+        assert not eng.search_attached
+        dist, idx = eng.search(queries, k, metric)                     # the base it leaves behind is an ordinary base
+        assert np.array_equal(idx, ri) and _same_bits(dist, rd)
+
+
+def test_an_attached_search_declines_what_needs_the_whole_base_and_dies_with_its_base(oracle):
+    from neighborhoodwatch_amd import KnnEngine
+    from neighborhoodwatch_amd._lib import NwknnError
+    B, Q, d, k = 5_000, 40, 48, 10
+    base, queries = oracle.gen(0xA73, 0, B, d), oracle.gen(0xA74, 0, Q, d)
+    rd, ri = oracle.knn_canonical(base, queries, k)
+    with KnnEngine(0) as eng:
+        with pytest.raises(NwknnError):
+            eng.search_attach(queries, k)                              # no base announced
+        eng.set_prescreen(True)                                        # the pre-screen's scale is the base's max |x|: not attached
+        eng.base_begin(B, d)
+        assert eng.search_attach(queries, k) is False
+        eng.base_append(base); eng.base_end()
+        with pytest.raises(NwknnError):
+            eng.search_collect()
+        dist, idx = eng.search(queries, k)
+        assert np.array_equal(idx, ri) and _same_bits(dist, rd) and eng.stats()["prescreen"] == 1
+        eng.set_prescreen(False)
+        eng.base_begin(B, d, "f16")                                    # fp16 compute path: finiteness is checked on the whole base
+        assert eng.search_attach(queries, k) is False
+        eng.base_begin(B, d)
+        assert eng.search_attach(queries, k) is True
+        eng.base_append(base[:3000])
+        with pytest.raises(NwknnError, match="between nwknn_base_begin and the first piece"):
+            eng.search_attach(queries, k)
+        eng.base_begin(B, d)                                           # a new base abandons the search with the half-built one
+        assert not eng.search_attached
+        eng.base_append(base); eng.base_end()
+        with pytest.raises(NwknnError):
+            eng.search_collect()
+        dist, idx = eng.search(queries, k)
+        assert np.array_equal(idx, ri) and _same_bits(dist, rd)
+        eng.base_begin(B, d)                                           # collect before the end
+        assert eng.search_attach(queries, k) is True
+        eng.base_append(base[:100])
+        with pytest.raises(NwknnError, match="nwknn_base_end first"):
+            eng.search_collect()
+
+
 def test_walk_calibration_times_both_super_tile_walks_and_keeps_the_bits(oracle):
     """The direct fp32 kernel times two consecutive full-size chunks, one under each walk of an XCD's super-tile (8 x 8 base-tile-fastest,
     2 x 32 query-tile-fastest), and runs the rest under the faster one (nwknn_stats.walk_*): the walks differ in what they share through L2,
