@@ -92,7 +92,7 @@ int nwknn_device_count(void);
  * get_gpu_memory(), cu_knn_ds.py:30-36. */
 int nwknn_mem_info(int device, size_t* free_bytes, size_t* total_bytes);
 /* Read rate, GB/s, of a plain streaming kernel over a working set of `bytes` read again and again for `seconds` (a multiple of 1 MiB, at most
- * 16 GiB): 128 MiB sits beyond the 8 x 4 MiB of L2 and inside the 256 MiB Infinity Cache -- the path the tile kernels' L2 misses take, and the
+ * 16 GiB; launches of ~16 GiB of reads each, the fastest launch's rate is reported): 128 MiB sits beyond the 8 x 4 MiB of L2 and inside the 256 MiB Infinity Cache -- the path the tile kernels' L2 misses take, and the
  * part of a device that differs between boxes when their MFMA pipes do not; 4 GiB measures HBM.  bench.py prints both next to the bare MFMA
  * loop (roofline.fabric_probe_gbs / hbm_probe_gbs) so that a slow line can be told apart from a slow box.  No reference counterpart. */
 int nwknn_fabric_probe(nwknn_handle h, int64_t bytes, double seconds, double* out_gbs);
@@ -199,9 +199,10 @@ int nwknn_base_end(nwknn_handle h);
 
 /* ---- the tile loop's search, started before the tile has arrived: cu_knn.py:201-245 with the read, the upload and knn() overlapped ------
  * The reference's loop is read -> upload -> knn() per base tile, one after the other.  A search ATTACHED to a base that is being handed
- * over in pieces walks it as it lands: every chunk of the ordinary walk is launched as soon as the pieces that cover it have been appended
- * (same chunk boundaries, hence the same launches in the same order: the result is bit for bit nwknn_search's), on a stream of its own
- * beside the copies and layout kernels of the pieces that follow.
+ * over in pieces walks it as it lands: every chunk of the walk is launched as soon as the pieces that cover it have been appended (the
+ * ordinary walk with chunks of at most 2^18 rows, so that little is left to do after the last piece; the lists are exact top-k lists under
+ * the canonical arithmetic whatever the chunking: the result is bit for bit nwknn_search's), on a stream of its own beside the copies and
+ * layout kernels of the pieces that follow.
  *   nwknn_base_begin(...)
  *   nwknn_search_attach*(h, queries..., k, metric, index_offset, &attached)     between begin and the first piece.  *attached = 0 (and
  *                                         NWKNN_OK) when the configured path needs the whole base before its first launch -- the fp16

@@ -1313,8 +1313,8 @@ static int search_common(nwknn_ctx* h, const void* queries, const ColumnSource* 
 // Through files the base arrives at the speed of the parquet decoder (10-18 GB/s on the GPU box's host), the direct kernel walks it at the
 // equivalent of ~27 GB/s for 10 000 queries -- and until round 5 it started only after the last piece had landed: 1.4 s of a 4 s stage with
 // the decoder idle.  The walk needs nothing from rows it has not reached (a chunk reads its own rows and the running lists), so an attached
-// search launches every chunk of the ordinary walk -- same boundaries, hence the same launches in the same order -- as soon as the pieces
-// that cover it have been appended: on a stream of its own, ordered behind the layout kernels by an event, beside the copies and layout
+// search launches every chunk of its walk -- the ordinary walk with chunks of at most 2^18 rows -- as soon as the pieces that cover it
+// have been appended: on a stream of its own, ordered behind the layout kernels by an event, beside the copies and layout
 // kernels of the pieces that follow.  nwknn_base_end launches what is left, nwknn_search_collect repairs / sorts / copies out as
 // nwknn_search does.  Direct fp32 path only: the pre-screen's scale and exact fp16 mode's finiteness check need the whole base
 // (*attached = 0: search after nwknn_base_end as before; the pre-screened search of that shape takes 0.17 s, there is nothing to hide).
@@ -1343,6 +1343,9 @@ static int search_attach_common(nwknn_ctx* h, const void* queries, const ColumnS
     h->nb_pad = h->sb_rows_pad; h->d = h->sb_d; h->dp = h->sb_dp; h->f16 = 0; h->ms_docs = 0; h->pre_ok = 0; h->f16_finite = 0;
     FollowState f;
     RCCHK(make_plan(h, k, nq, false, &f.pl));
+    // What cannot start before the last piece has landed is the walk's last chunk: 2^20 rows are 0.21 s of the direct kernel for 10 000
+    // queries of d = 1536, a quarter of that bound costs a few more launches (each with its compaction, ~50 us) and leaves 0.05 s.
+    f.pl.max_chunk = std::max<long long>(f.pl.granule, std::min<long long>(f.pl.max_chunk, (1ll << 18) / f.pl.granule * f.pl.granule));
     f.k = k; f.metric = metric; f.nq = nq; f.nq_pad = round_up(nq, NWK_QPAD_ROWS); f.index_offset = index_offset; f.seen = 0; f.rows = h->sb_rows;
     f.growth = h->opt_chunk_growth;
     if (f.growth <= 0) f.growth = std::max<long long>(1, std::min<long long>(3, (long long)((0.8 * f.pl.cap / k - 1.0) / 1.5)));
@@ -1861,24 +1864,24 @@ extern "C" int nwknn_fabric_probe(nwknn_handle h, int64_t bytes, double seconds,
     float* sink = (float*)((char*)buf + bytes);
     // passes per launch: ~4 ms of work at 4 TB/s, so that a launch is long against its own start-up; launches until `seconds` have passed
     const int passes = (int)std::max<long long>(1, (16ll << 30) / bytes / 1);
-    double total_bytes = 0.0;
-    // warm: one launch (brings the working set to where it will live), then timed launches
+    // warm: one launch (brings the working set to where it will live), then launches timed one by one until `seconds` have passed.  The
+    // rate reported is the FASTEST launch's: the question is what the fabric can deliver, and a launch that shared the device with
+    // something else for a moment (seen once in round 5: one 3 ms launch took 33) must not answer it.
     if (nwk_launch_stream_read(h->stream, buf, bytes, 1, grid, sink) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
         return done(fail(NWKNN_EHIP, "nwknn_fabric_probe: launch failed: %s", hipGetErrorString(hipGetLastError())));
     const auto t_begin = std::chrono::steady_clock::now();
-    if (hipEventRecord(e0, h->stream) != hipSuccess) return done(fail(NWKNN_EHIP, "hipEventRecord failed"));
+    double best = 0.0;
     do {
-        if (nwk_launch_stream_read(h->stream, buf, bytes, passes, grid, sink) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+        float ms = 0.f;
+        if (hipEventRecord(e0, h->stream) != hipSuccess || nwk_launch_stream_read(h->stream, buf, bytes, passes, grid, sink) != hipSuccess ||
+            hipEventRecord(e1, h->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
             rc = fail(NWKNN_EHIP, "nwknn_fabric_probe: launch failed: %s", hipGetErrorString(hipGetLastError()));
             break;
         }
-        total_bytes += (double)bytes * passes;
+        if (ms > 0.f) best = std::max(best, (double)bytes * passes / 1e9 / (ms * 1e-3));
     } while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() < seconds);
     if (rc != NWKNN_OK) return done(rc);
-    float ms = 0.f;
-    if (hipEventRecord(e1, h->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
-        return done(fail(NWKNN_EHIP, "nwknn_fabric_probe: timing failed"));
-    *out_gbs = ms > 0.f ? total_bytes / 1e9 / (ms * 1e-3) : 0.0;
+    *out_gbs = best;
     return done(NWKNN_OK);
 }
 

@@ -99,16 +99,25 @@ def test_dataset_api_streams_batches_and_resumes_from_its_checkpoint(dataset, or
     from neighborhoodwatch_amd import engine as eng_mod
     from neighborhoodwatch_amd import parquet_stream
     data_dir, qf, bf = dataset
-    real_search = eng_mod.KnnEngine.search_columns
+    # every batch's search is attached to the batch before its first piece (search_attach: the global offset goes in there) and collected
+    # once the batch is resident (search_collect: results asked for on the device)
+    real_attach, real_collect = eng_mod.KnnEngine.search_attach, eng_mod.KnnEngine.search_collect
     calls = []
 
-    def flaky(self, columns, k, metric="sqeuclidean", index_offset=0, out_device=False):
-        calls.append((index_offset, out_device))
+    def attach(self, queries, k, metric="sqeuclidean", index_offset=0):
+        calls.append([index_offset, None])
+        ok = real_attach(self, queries, k, metric, index_offset)
+        assert ok
+        return ok
+
+    def flaky(self, out_device=False):
+        calls[-1][1] = out_device
         if len(calls) == 4:
             raise RuntimeError("simulated crash in batch 4")
-        return real_search(self, columns, k, metric, index_offset, out_device)
+        return real_collect(self, out_device)
 
-    monkeypatch.setattr(eng_mod.KnnEngine, "search_columns", flaky)
+    monkeypatch.setattr(eng_mod.KnnEngine, "search_attach", attach)
+    monkeypatch.setattr(eng_mod.KnnEngine, "search_collect", flaky)
     with pytest.raises(RuntimeError, match="simulated crash"):
         cu_knn_ds.compute_knn_ds(data_dir, 384, qf, 300, bf, 2600, False, 10, 400, resume=True)
     assert [c[0] for c in calls] == [0, 400, 800, 1200] and all(c[1] for c in calls)     # global offsets; results asked for on the device
@@ -122,7 +131,7 @@ def test_dataset_api_streams_batches_and_resumes_from_its_checkpoint(dataset, or
     assert cu_knn_ds._load_checkpoint(data_dir, "sqeuclidean", 10, 300, 2600) is None     # nor one whose input files are not these
     assert cu_knn_ds._load_checkpoint(data_dir, "sqeuclidean", 10, 300, 2600, cu_knn_ds.checkpoint_inputs(rows_of(qf, 300), rows_of(bf, 2599))) is None
 
-    monkeypatch.setattr(eng_mod.KnnEngine, "search_columns", real_search)
+    monkeypatch.setattr(eng_mod.KnnEngine, "search_collect", real_collect)
     seen = []
     real_reader = parquet_stream.PieceReader
 
@@ -133,9 +142,9 @@ def test_dataset_api_streams_batches_and_resumes_from_its_checkpoint(dataset, or
 
     monkeypatch.setattr(cu_knn, "PieceReader", Watched)                                         # cu_knn.stream_tiles feeds both drivers
     calls2 = []
-    monkeypatch.setattr(eng_mod.KnnEngine, "search_columns",
-                        lambda self, columns, k, metric="sqeuclidean", index_offset=0, out_device=False:
-                        (calls2.append(index_offset), real_search(self, columns, k, metric, index_offset, out_device))[1])
+    monkeypatch.setattr(eng_mod.KnnEngine, "search_attach",
+                        lambda self, queries, k, metric="sqeuclidean", index_offset=0:
+                        (calls2.append(index_offset), real_attach(self, queries, k, metric, index_offset))[1])
     cu_knn_ds.compute_knn_ds(data_dir, 384, qf, 300, bf, 2600, False, 10, 400, resume=True)
     assert calls2 == [1200, 1600, 2000, 2400]                                             # the first three batches were not searched again
     # ONE reader pool for the whole job: the row-group pieces of the remaining batches in row order (rows 1200..2599 over 700-row groups:
@@ -173,7 +182,17 @@ def test_compute_knn_reads_tiles_lazily_and_overlaps(dataset, oracle, monkeypatc
     monkeypatch.setattr(eng_mod.KnnEngine, "base_begin", lambda self, rows, dim, dtype="f32": (begun.append(rows), real_begin(self, rows, dim, dtype))[1])
     # (the pieces arrive prepared -- KnnEngine.prepare_columns on the reader thread: slot 4 of the tuple is the piece's row count)
     monkeypatch.setattr(eng_mod.KnnEngine, "base_append_columns", lambda self, cols: (appended.append(cols[4]), real_append(self, cols))[1])
+    attached = []
+    real_attach = eng_mod.KnnEngine.search_attach
+
+    def attach(self, queries, k, metric="sqeuclidean", index_offset=0):
+        attached.append((index_offset, len(appended), real_attach(self, queries, k, metric, index_offset)))
+        return attached[-1][2]
+
+    monkeypatch.setattr(eng_mod.KnnEngine, "search_attach", attach)
     cu_knn.compute_knn(data_dir, "intfloat/e5-small-v2", 384, qf, 300, bf, 2600, False, 10, 900)
+    # every tile's search was attached before the tile's first piece (global offset, pieces appended so far): knn() walks the tile as it arrives
+    assert attached == [(0, 0, True), (900, 2, True), (1800, 4, True)]
     # tiles of 900 / 900 / 800 rows over 700-row groups: (first row, rows) of every piece, each decoded exactly once, in row order
     assert sorted(read_calls) == [(0, 700), (700, 200), (900, 500), (1400, 400), (1800, 300), (2100, 500)]
     assert begun == [900, 900, 800] and appended == [700, 200, 500, 400, 300, 500]
