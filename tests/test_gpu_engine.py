@@ -437,6 +437,49 @@ def test_a_search_attached_to_an_arriving_base_gives_the_bits_of_the_search_afte
         assert np.array_equal(idx, ri) and _same_bits(dist, rd)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_attached_search_random_shapes_and_cuts(oracle, seed):
+    """Random shapes, k, metric, chunk options and piece boundaries (row-major and column pieces mixed, float64 columns now and then; ties
+    from small-integer data every third case): the attached search returns the oracle's bits and the base serves a plain search after it."""
+    from neighborhoodwatch_amd import KnnEngine
+    rng = np.random.default_rng(9100 + seed)
+    d = int(rng.choice([1, 7, 32, 100, 129, 384]))
+    B = int(rng.integers(300, 40_000))
+    Q = int(rng.integers(1, 600))
+    k = int(min(B, rng.choice([1, 5, 64, 100, 257])))
+    metric = ["sqeuclidean", "one_minus_dot", "cosine"][seed % 3]
+    if seed % 3 == 0:
+        base = rng.integers(-3, 4, size=(B, d)).astype(np.float32); queries = rng.integers(-3, 4, size=(Q, d)).astype(np.float32)
+        base[np.all(base == 0, axis=1), 0] = 1.0; queries[np.all(queries == 0, axis=1), 0] = 1.0
+    else:
+        base = rng.standard_normal((B, d)).astype(np.float32); queries = rng.standard_normal((Q, d)).astype(np.float32)
+    n_cuts = int(rng.integers(0, 12))
+    cuts = [0] + sorted(set(int(x) for x in rng.integers(1, B, size=n_cuts))) + [B]
+    rd, ri = oracle.knn_canonical(base, queries, k, metric)
+    with KnnEngine(0) as eng:
+        eng.set_option("upload_slab_mib", int(rng.choice([1, 4, 128])))
+        if seed % 2:
+            eng.set_option("max_chunk", int(rng.choice([1024, 4096, 1 << 16])))
+        if seed % 5 == 0:
+            eng.set_option("first_chunk", 256)
+        eng.base_begin(B, d)
+        assert eng.search_attach(queries, k, metric, index_offset=seed) is True
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            how = int(rng.integers(0, 3))
+            if how == 0:
+                eng.base_append(base[a:b])
+            elif how == 1:
+                eng.base_append_columns([np.ascontiguousarray(base[a:b, j]) for j in range(d)])
+            else:
+                eng.base_append_columns([base[a:b, j].astype(np.float64) for j in range(d)])
+        eng.base_end()
+        dist, idx = eng.search_collect()
+        assert np.array_equal(idx, ri + seed), f"seed {seed}: {(idx != ri + seed).sum()} index mismatches (B={B} Q={Q} d={d} k={k} {metric} cuts={cuts})"
+        assert _same_bits(dist, rd), f"seed {seed}"
+        dist, idx = eng.search(queries, k, metric)
+        assert np.array_equal(idx, ri) and _same_bits(dist, rd)
+
+
 def test_an_attached_search_declines_what_needs_the_whole_base_and_dies_with_its_base(oracle):
     from neighborhoodwatch_amd import KnnEngine
     from neighborhoodwatch_amd._lib import NwknnError
