@@ -37,6 +37,9 @@
 //   nwk_maxsim.hip     MaxSim late interaction (extension)
 // each with its host-side launchers (declared in nwknn_internal.h, called from nwknn_api.cpp).
 #pragma once
+#ifndef NWK_MFMA_SNAKE
+#define NWK_MFMA_SNAKE 1      // issue order of a k-step's MFMAs (nwk_tile_f16y.h); 0 = n ascending under every m, for A/B builds
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

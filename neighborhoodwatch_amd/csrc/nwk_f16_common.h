@@ -1,6 +1,7 @@
 // nwk_f16_common.h -- shared by the fp16 tile kernels (nwk_tile_f16.hip, nwk_tile_f16p.hip): tile geometry, the filter epilogue of
 // the 16x16x32 accumulator layout and the LDS staging of survivors.
 #pragma once
+
 #include "nwk_device.h"
 
 #define H_TM 256

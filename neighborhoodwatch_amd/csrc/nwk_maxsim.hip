@@ -478,14 +478,18 @@ __global__ __launch_bounds__(64 * WAVES, 2) void nwk_maxsim_pre_ring16_kernel(co
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
+                for (int j = 0; j < 4; ++j) {
+                    const int n = NWK_MFMA_SNAKE && (m & 1) ? 3 - j : j;          // snaked issue order (nwk_tile_f16y.h)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], bq[kt][n], kt == 0 ? zero4 : acc[m][n], 0, 0, 0);
+                }
             if (SPB == 2) { __builtin_amdgcn_sched_barrier(0); if (kt % 2 == 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
             for (int m = 4; m < 8; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
+                for (int j = 0; j < 4; ++j) {
+                    const int n = NWK_MFMA_SNAKE && (m & 1) ? 3 - j : j;
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], bq[kt][n], kt == 0 ? zero4 : acc[m][n], 0, 0, 0);
+                }
         }
         // ---- epilogue of tile t: 2 docs (row blocks 4 dd .. 4 dd + 3) x 2 queries (column blocks 2 qn, 2 qn + 1) per wave
         const float* cd_s = (const float*)(smem + OFF_CD) + t * MS_DOCS_PER_TILE + 2 * wr;
@@ -651,8 +655,10 @@ __global__ __launch_bounds__(512, 2) void nwk_maxsim_pre_tile8_kernel(const NwkT
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
+                for (int j = 0; j < 4; ++j) {
+                    const int n = NWK_MFMA_SNAKE && (m & 1) ? 3 - j : j;          // snaked issue order (nwk_tile_f16y.h)
                     acc[4 * dd + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], bq[kt][n], kt == 0 ? zero4 : acc[4 * dd + m][n], 0, 0, 0);
+                }
         }
     };
     // reductions of one document: max over its 64 token rows per query-token column, sum over each query's 32 tokens -> two score estimates

@@ -116,8 +116,10 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16p(const NwkTilePara
     };
     auto mma = [&](int buf, int j, int ks, int mb) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int i = 0; i < 4; ++i) {
+            const int n = NWK_MFMA_SNAKE && (mb & 1) ? 3 - i : i;             // snaked issue order (nwk_tile_f16y.h)
             acc[2 * j + mb][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[buf][2 * ks + mb], fb[ks][n], acc[2 * j + mb][n], 0, 0, 0);
+        }
     };
     auto zero_acc = [&]() {
 #pragma unroll

@@ -199,8 +199,10 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16x(const NwkTilePara
 #pragma unroll
             for (int m = 0; m < 8; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
+                for (int j = 0; j < 4; ++j) {
+                    const int n = NWK_MFMA_SNAKE && (m & 1) ? 3 - j : j;      // snaked issue order: see nwk_tile_f16y.h
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ks][m], fb[ks][n], (FIRST && ks == 0) ? zero : acc[m][n], 0, 0, 0);
+                }
         if (X_PRIO) __builtin_amdgcn_s_setprio(0);
     };
 

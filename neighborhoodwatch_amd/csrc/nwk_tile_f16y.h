@@ -141,11 +141,16 @@ __global__ __launch_bounds__(512, 2) void nwk_tile_kernel_f16y(const NwkTilePara
     auto mfma_rows = [&](int ks, int m0, int m1, auto first_tag) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;        // the tile's first k-step starts from a zero C
         const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+        // Issue order: A fragment m held over four MFMAs, the B fragments walked 0..3 and back 3..0 -- every two consecutive MFMAs share one
+        // operand register.  The order is worth clock: bare loop on random operands (tools/f16y_probe.hip, profiles/r05an_mfma_order.log)
+        // 2 012 TF with n always ascending, 2 049 TF snaked, 1 948 TF when both operands change every time.
 #pragma unroll
         for (int m = m0; m < m1; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
+            for (int j = 0; j < 4; ++j) {
+                const int n = NWK_MFMA_SNAKE && (m & 1) ? 3 - j : j;
                 acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ks][m], fb[ks][n], FIRST ? zero : acc[m][n], 0, 0, 0);
+            }
     };
     // the instruction stream of one chunk of 16 MFMAs: four groups of {4 MFMAs, at most one LDS-DMA instruction, two fragment reads}
     auto pattern = [&](bool with_dma) __attribute__((always_inline)) {

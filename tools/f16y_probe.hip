@@ -46,7 +46,7 @@ struct Out { unsigned long long cycles, realtime; float sink; unsigned wait[8]; 
 #define LDS_AS __attribute__((address_space(3)))
 
 // ---- reference points (as in lds_mfma_probe.hip) ------------------------------------------------------------------------------------
-template <int MODE>   // 0 free-running reads + MFMAs, 2 bare
+template <int MODE>   // 0 free-running reads + MFMAs, 2 bare (A fragment held over 4 MFMAs); bare in other issue orders: 3 snake, 4 B held over 8, 5 both operands change every time
 __global__ __launch_bounds__(512, 2) void probe_free(const _Float16* __restrict__ rnd, int slabs, Out* out)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(512, 2) void probe_free(const _Float16* __restrict_
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = zero;
     f16x8 fa[8], fb[4];
-    if (MODE == 2) {
+    if (MODE >= 2) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) fa[m] = *(const f16x8*)(smem + offA0 + m * 2048);
 #pragma unroll
@@ -74,16 +74,20 @@ __global__ __launch_bounds__(512, 2) void probe_free(const _Float16* __restrict_
     for (int s = 0; s < slabs; ++s) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            if (MODE != 2) {
+            if (MODE < 2) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) fa[m] = *(const f16x8*)(smem + (offA0 ^ (ks << 6)) + m * 2048);
 #pragma unroll
                 for (int n = 0; n < 4; ++n) fb[n] = *(const f16x8*)(smem + (offB0 ^ (ks << 6)) + n * 2048);
             }
 #pragma unroll
-            for (int m = 0; m < 8; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+            for (int i = 0; i < 32; ++i) {
+                // issue order of the 32 MFMAs of a k-step: which operand registers two consecutive instructions share
+                const int m = MODE == 4 ? ((i >> 3) & 1 ? 7 - (i & 7) : (i & 7)) : MODE == 5 ? (i & 7) : (i >> 2);
+                const int n = MODE == 4 ? (i >> 3) : MODE == 5 ? ((i + (i >> 3)) & 3) : MODE == 3 ? ((i >> 2) & 1 ? 3 - (i & 3) : (i & 3)) : (i & 3);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+                if (MODE >= 3) __builtin_amdgcn_sched_barrier(0);       // keep the order as written
+            }
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -578,6 +582,9 @@ int main(int argc, char** argv)
 #define RUN_LAD(D, L, WHAT) if (timeit([&] { hipLaunchKernelGGL((probe_ladder<D, L>), dim3(grid), dim3(512), lds2, 0, rnd, stream, slabs, out); }, out, grid, cus, slabs, WHAT, true)) return 1
     for (int r = 0; r < 1; ++r) {
         RUN_FREE(2, "bare: fragments kept in registers");
+        RUN_FREE(3, "bare, snake order (one operand shared by every consecutive pair)");
+        RUN_FREE(4, "bare, B held over 8 MFMAs, A snakes");
+        RUN_FREE(5, "bare, both operands change with every MFMA");
         if (only) {
             RUN_PP(1, "pp: ping-pong phases + LDS-DMA in the other phase (round 4's model of the shipped kernel)");
             RUN_LAD(1, 0, "lad1/0: mid-slab barrier + DMA (4 + 4), no priorities");
