@@ -689,7 +689,7 @@ static int base_finish(nwknn_ctx* h, const BasePlan& b)
             else RCCHK(rc);
         }
     }
-    if (h->opt_profile) {
+    if (h->opt_profile && !h->fw.active) {                          // (an attached search keeps the events: its own collection counts them all)
         HIPCHK(hipStreamSynchronize(h->stream));
         double t, c, p;
         ev_collect(h, &t, &c, &p);

@@ -480,6 +480,31 @@ def test_attached_search_random_shapes_and_cuts(oracle, seed):
         assert np.array_equal(idx, ri) and _same_bits(dist, rd)
 
 
+def test_attached_search_with_per_kernel_timing_and_a_caller_stream(oracle):
+    """Option profile (per-kernel HIP events, recorded on whichever stream carried the launch) and nwknn_set_stream (the handle's work on
+    torch's current stream) under an attached search: same bits, and the stats account for every launch."""
+    import torch
+    from neighborhoodwatch_amd import KnnEngine
+    B, Q, d, k = 20_000, 200, 64, 10
+    base, queries = oracle.gen(0xA75, 0, B, d), oracle.gen(0xA76, 0, Q, d)
+    rd, ri = oracle.knn_canonical(base, queries, k)
+    with KnnEngine(0, profile=True) as eng:
+        eng.set_option("max_chunk", 2048)
+        side = torch.cuda.Stream(device=0)
+        with torch.cuda.stream(side):
+            eng.set_stream(side.cuda_stream)
+            eng.base_begin(B, d)
+            assert eng.search_attach(queries, k) is True
+            for a in range(0, B, 3000):
+                eng.base_append(base[a:a + 3000])
+            eng.base_end()
+            dist, idx = eng.search_collect()
+            st = eng.stats()
+            eng.set_stream(0)
+        assert np.array_equal(idx, ri) and _same_bits(dist, rd)
+        assert st["tile_launches"] >= 10 and st["tile_ms"] > 0.0 and st["prep_ms"] > 0.0 and st["total_ms"] >= st["tile_ms"]
+
+
 def test_an_attached_search_declines_what_needs_the_whole_base_and_dies_with_its_base(oracle):
     from neighborhoodwatch_amd import KnnEngine
     from neighborhoodwatch_amd._lib import NwknnError
