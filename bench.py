@@ -120,12 +120,18 @@ def recorded_traffic(workload):
 
 
 def _blas_threads():
-    cores = len(os.sched_getaffinity(0))
+    """(BLAS threads the CPU baseline will use, a threadpoolctl controller or None).  The GPU box shows 256 CPUs and allows 16 CPUs' worth of time
+    (cgroup quota): a BLAS pool sized by the former spends the quota on contention, so the pool is limited to what the container may run --
+    `cores` in the line is that number.  The controller is made HERE, on the main thread (it walks the loaded libraries under the loader lock)."""
+    from neighborhoodwatch_amd.hostinfo import effective_cpus
+    cores = effective_cpus()
     try:
-        from threadpoolctl import threadpool_info
-        return max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [cores])
+        from threadpoolctl import ThreadpoolController
+        ctl = ThreadpoolController()
+        have = max([p.get("num_threads", 1) for p in ctl.info() if p.get("user_api") == "blas"] or [cores])
+        return min(have, cores), ctl
     except Exception:
-        return cores
+        return cores, None
 
 
 def cpu_baseline(base_dev, queries_dev, k, metric, full_b, flop_budget=0.45e13, defer=False, blas_threads=None):
@@ -153,11 +159,20 @@ def cpu_baseline(base_dev, queries_dev, k, metric, full_b, flop_budget=0.45e13, 
         fut = pool.submit(cpu_baseline, b_host, q_host, k, metric, full_b, flop_budget, False, blas_threads)
         pool.shutdown(wait=False)
         return fut
+    import contextlib
     import numpy as np
     from oracle import cpu_oracle
-    cores = len(os.sched_getaffinity(0))
     if blas_threads is None:
         blas_threads = _blas_threads()
+    cores, ctl = blas_threads
+    limited = ctl.limit(limits=cores, user_api="blas") if ctl is not None else contextlib.nullcontext()
+    with limited:
+        return _cpu_baseline_legs(base_dev, queries_dev, k, metric, full_b, flop_budget, cores)
+
+
+def _cpu_baseline_legs(base_dev, queries_dev, k, metric, full_b, flop_budget, cores):
+    import numpy as np
+    from oracle import cpu_oracle
     d = base_dev.shape[1]
     qs = min(queries_dev.shape[0], 2048)
     bs = min(base_dev.shape[0], max(10_000, int(flop_budget / (2.0 * qs * d))))
@@ -169,20 +184,21 @@ def cpu_baseline(base_dev, queries_dev, k, metric, full_b, flop_budget=0.45e13, 
     dt = time.perf_counter() - t0
     scale = bs / float(full_b)                                                   # brute force is linear in B
     out = {
-        "value": qs / dt * scale, "unit": "queries/s", "cores": int(blas_threads), "kind": "port",
+        "value": qs / dt * scale, "unit": "queries/s", "cores": int(cores), "kind": "port",
+        "cores_note": f"BLAS threads = the CPUs this container may use (cgroup quota / affinity); the host shows {os.cpu_count()}",
         "sample": f"{qs} queries x first {bs} of {full_b} base rows in {dt:.2f}s (numpy sgemm + argpartition, "
                   f"oracle.cpu_oracle.knn_blas_fp32); rate scaled by {bs}/{full_b} to the full base",
     }
     if metric in ("sqeuclidean", "cosine"):
         try:
             from sklearn.neighbors import NearestNeighbors
-            nn = NearestNeighbors(n_neighbors=min(k, bs), algorithm="brute", metric=metric, n_jobs=-1)
+            nn = NearestNeighbors(n_neighbors=min(k, bs), algorithm="brute", metric=metric, n_jobs=cores)
             nn.fit(base[: min(bs, 20000)]).kneighbors(qry[:64], return_distance=True)     # warm-up
             t0 = time.perf_counter()
             nn.fit(base).kneighbors(qry, return_distance=True)
             dts = time.perf_counter() - t0
             out["sklearn"] = {"value": qs / dts * scale, "unit": "queries/s", "cores": cores, "kind": "library",
-                              "sample": f"sklearn.neighbors.NearestNeighbors(algorithm='brute', metric='{metric}', n_jobs=-1).kneighbors on the same "
+                              "sample": f"sklearn.neighbors.NearestNeighbors(algorithm='brute', metric='{metric}', n_jobs={cores}).kneighbors on the same "
                                         f"{qs} x {bs} sample in {dts:.2f}s; same scaling"}
         except Exception as e:                                                    # the baseline is a report, never a reason to lose the line
             out["sklearn"] = {"error": f"{type(e).__name__}: {e}"}

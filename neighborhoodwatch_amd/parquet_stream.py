@@ -29,6 +29,8 @@ from typing import Callable, Iterable, Iterator, List, Optional, Sequence, Tuple
 import pyarrow as pa
 import pyarrow.parquet as pq
 
+from .hostinfo import size_arrow_pool
+
 
 class ParquetRows:
     """Rows [0, count) of the concatenation of ``paths``, columns ``columns`` (all when None).  Only metadata is read here."""
@@ -242,6 +244,7 @@ class PieceReader:
         self._pieces = list(pieces)
         self._transform = transform              # applied to every decoded table ON ITS READER THREAD (the consumer gets the result)
         self._readers = readers or default_readers()
+        size_arrow_pool()                        # pyarrow's column threads: as many as the container may run, not as the machine shows
         if ahead is None:
             # bounded by host memory, not by count: a piece of the reference's published run is 100 000 rows x 1536 floats = 614 MB
             biggest = 1
