@@ -19,6 +19,7 @@ Three layers, each citing what it restates (paths relative to /root/reference):
 from __future__ import annotations
 
 import ctypes
+import math
 import os
 import subprocess
 from pathlib import Path
@@ -38,6 +39,27 @@ def build(force: bool = False) -> Path:
     if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < src.stat().st_mtime:
         subprocess.run(["make", "-C", str(_HERE), "-B"], check=True, capture_output=True)
     return _LIB_PATH
+
+
+def _usable_cpus() -> int:
+    """CPUs this process may really use: the affinity mask capped by the cgroup quota (the GPU boxes show 256 CPUs and grant 16 -- OpenMP's
+    default of one thread per CPU shown made the oracle 25x slower there)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, math.ceil(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, math.ceil(q / p)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
 
 
 def lib() -> ctypes.CDLL:
@@ -71,6 +93,9 @@ def lib() -> ctypes.CDLL:
         L.nwo_sortable_u32.argtypes = [ctypes.c_float]
         L.nwo_sortable_u32.restype = ctypes.c_uint32
         L.nwo_has_avx2_fma.restype = ctypes.c_int
+        L.nwo_set_threads.argtypes = [ctypes.c_int]
+        L.nwo_get_threads.restype = ctypes.c_int
+        L.nwo_set_threads(_usable_cpus())
         _lib = L
     return _lib
 

@@ -41,6 +41,21 @@
 #include <omp.h>
 #endif
 
+/* Threads of every parallel region.  The GPU boxes show 256 CPUs and grant the container a quota of 16: with OpenMP's default (one thread per
+ * CPU shown) the suite's oracle calls spent their time in contention -- tests/test_gpu_f16_exact.py 68 s against 2.6 s with 16 threads.
+ * cpu_oracle.py sets this from the cgroup quota when it loads the library; 0 = OpenMP's default. */
+static int g_nwo_threads = 0;
+void nwo_set_threads(int n) { g_nwo_threads = n > 0 ? n : 0; }
+static int nwo_threads(void)
+{
+#ifdef _OPENMP
+    return g_nwo_threads > 0 ? g_nwo_threads : omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+int nwo_get_threads(void) { return nwo_threads(); }
+
 #define NWO_VERSION 1
 #define NWO_METRIC_SQEUCLIDEAN 0
 #define NWO_METRIC_ONE_MINUS_DOT 1
@@ -67,7 +82,7 @@ static inline float nwo_gen_value(uint64_t seed, uint64_t row, uint64_t col)
 
 void nwo_gen(uint64_t seed, int64_t row0, int64_t rows, int32_t d, float* out)
 {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nwo_threads())
     for (int64_t r = 0; r < rows; ++r)
         for (int32_t c = 0; c < d; ++c)
             out[r * d + c] = nwo_gen_value(seed, (uint64_t)(row0 + r), (uint64_t)c);
@@ -98,7 +113,7 @@ static inline float nwo_dot_chain(const float* a, const float* b, int32_t d)
 
 void nwo_row_norms(const float* x, int64_t rows, int32_t d, float* out)
 {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nwo_threads())
     for (int64_t r = 0; r < rows; ++r) out[r] = nwo_dot_chain(x + r * d, x + r * d, d);
 }
 
@@ -160,7 +175,7 @@ int nwo_knn_scalar(const float* base, int64_t nb, const float* queries, int64_t 
     if (!base || !queries || !out_dist || !out_idx || d <= 0 || k <= 0 || k > nb || nb >= (1ll << 32)) return -1;
     float* bn = (float*)malloc((size_t)nb * sizeof(float));
     nwo_row_norms(base, nb, d, bn);
-#pragma omp parallel
+#pragma omp parallel num_threads(nwo_threads())
     {
         uint64_t* keys = (uint64_t*)malloc((size_t)k * sizeof(uint64_t));
 #pragma omp for schedule(dynamic, 1)
@@ -232,7 +247,7 @@ int nwo_knn(const float* base, int64_t nb, const float* queries, int64_t nq, int
     if (!base || !queries || !out_dist || !out_idx || d <= 0 || k <= 0 || k > nb || nb >= (1ll << 32)) return -1;
     if (metric < 0 || metric > 2) return -2;
 #ifdef _OPENMP
-    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    if (nthreads <= 0) nthreads = nwo_threads();
 #else
     nthreads = 1;
 #endif
@@ -301,7 +316,7 @@ int nwo_merge(const float* dists, const int64_t* idx, int32_t n_lists, int64_t n
 {
     if (!dists || !idx || !out_d || !out_i || n_lists <= 0 || k_in <= 0 || k_out <= 0) return -1;
     const int64_t w = (int64_t)n_lists * k_in;
-#pragma omp parallel
+#pragma omp parallel num_threads(nwo_threads())
     {
         nwo_pair* p = (nwo_pair*)malloc((size_t)w * sizeof(nwo_pair));
 #pragma omp for schedule(static)
@@ -370,7 +385,7 @@ int nwo_maxsim(const float* docs, int64_t nd, int32_t td, const float* queries, 
     const int nblk = (td + NWO_RB - 1) / NWO_RB;
     int nthreads = 1;
 #ifdef _OPENMP
-    nthreads = omp_get_max_threads();
+    nthreads = nwo_threads();
 #endif
     /* Work is dealt out in chunks of documents, every thread keeping its own k-heap per query (few queries against many documents:
      * the sampled checks of the full-size tests), merged at the end; the k best by key do not depend on the visiting order.  When
