@@ -123,6 +123,9 @@ int nwknn_set_stream(nwknn_handle h, void* hip_stream);
  * (shape and walk order of an XCD's super-tile), "upload_threads" (host threads of the column upload pipeline, default 8),
  * "upload_slab_mib" (slab size of that pipeline, default 128),
  * "pre_eps_pct" (>= 100: percent of the proven pre-screen error bound to apply; larger = more pairs rescored, same result),
+ * "pre_direct_rows" (-1 auto | rows: in a pre-screened search of fp32 data the filtered chunks that start below this many base rows run the
+ * direct fp32 kernel -- right behind the dense chunk a quarter of all pairs pass the loose threshold, and rescoring them one by one costs more
+ * than computing the exact keys on the MFMA; auto = only the chunk that follows the dense one; same bits whatever the value),
  * "pre_check_ppm" (1..1000000, default 1000000: the invariant |estimate - exact| <= bound of nwknn_stats is checked against this many
  * millionths of the bound ON THE FIRST ATTEMPT of a search; a violation discards the attempt and sends the search down its fallback --
  * fp32 data: the direct fp32 kernel; fp16 data (exact fp16 mode): the same search under a 16x wider bound, held against the whole of that

@@ -153,7 +153,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i, ctab, chk, calib;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 0, opt_f16_agg = -1, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_waves = 8, opt_ms_form = 3, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128, opt_pre_check_ppm = 1000000;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 0, opt_f16_agg = -1, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_waves = 8, opt_ms_form = 3, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128, opt_pre_check_ppm = 1000000, opt_pre_direct_rows = -1;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -335,6 +335,9 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
     } else if (!strcmp(name, "f16_agg")) {
         if (value < -1 || value > 1) return fail(NWKNN_EINVAL, "f16_agg must be -1 (auto), 0 (never) or 1 (every filtered fp16 chunk)");
         h->opt_f16_agg = value;             // which chunks run the row-aggregating build of the streaming fp16 kernel (auto: the loose-threshold ones)
+    } else if (!strcmp(name, "pre_direct_rows")) {
+        if (value < -1) return fail(NWKNN_EINVAL, "pre_direct_rows must be -1 (auto) or a row count >= 0");
+        h->opt_pre_direct_rows = value;     // pre-screened search of fp32 data: filtered chunks that START below this many rows run the direct fp32 kernel (run_chunk)
     } else if (!strcmp(name, "f16_strip")) {
         if (value < 0 || value > 64) return fail(NWKNN_EINVAL, "f16_strip must be 0 (auto) or 1..64");
         h->opt_f16_strip = value;           // base tiles a workgroup of the fp16 kernels walks in a row (auto: 2 for the ping-pong form, 4 for the others)
@@ -897,7 +900,12 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
                      const int* qtile_list, int n_list_tiles, bool dedupe, bool rescan)
 {
     NwkTileParams tp = tile_params(h, pl, nq_pad);
-    const bool prescreen = pl.pre && (!dense || pl.native16);   // fp32 data: the dense first chunk runs the fp32 kernel
+    // fp32 data: the dense first chunk runs the fp32 kernel -- and so do the filtered chunks that start below pre_direct_rows.  Right behind the
+    // dense chunk the threshold is the k-th best of a few hundred rows: a quarter of all pairs pass, the pre-screen lists them and the
+    // rescoring kernel then walks the fp32 chain for each, lane by lane (C3 shard, 1 536-row chunk: 1.5 ms of fp16 tiles + 5.2 ms of
+    // rescoring, against 2.1 ms of fp32 MFMA tiles that produce the exact keys at once).  Auto: only the chunk that follows the dense one.
+    const long long direct_until = h->opt_pre_direct_rows >= 0 ? h->opt_pre_direct_rows : pl.first + 1;
+    const bool prescreen = pl.pre && (pl.native16 || (!dense && (rescan || lo >= direct_until)));
     // fp16 kernel build.  Auto (round 3, same-box A/B on 32k x 4M, tools/f16_forms.py, strips of 2 / 4 tiles): the ping-pong form from
     // 768 halves per row on (d = 768: 1 129 vs 1 084 TF for the streaming form, +4.2 %; 1024: +5.5 % over round 2's default; 1536 fp16
     // input: +4.2 % with the first version of the form; 2048: +6.3 % / +1.0 % over streaming / burst; 4096: +8.3 % / +3.4 %), the

@@ -95,7 +95,7 @@ def test_prescreened_search_equals_direct_search_long_rows(seed):
         for m in METRICS:
             dist, idx = eng.search(tq, k, m)
             assert eng.stats()["prescreen"] == 1, (family, m)
-            if B > 1024:                                          # (a base of one dense chunk never reaches a filtered launch)
+            if B > 4096:                                          # (the dense chunk and the chunk behind it run the fp32 kernel: a base that ends there never reaches a pre-screened launch)
                 name = eng.tile_kernel_name()                     # (…,1,1>: the last chunk's thresholds were still loose -- few rows per k)
                 if not os.environ.get("NWKNN_DEFAULT_OPTS"):      # (a soak that forces a kernel form changes which one ran, not the bits)
                     assert name.startswith("nwk_tile_kernel_f16x") or name.startswith("nwk_tile_kernel_f16y") or name.endswith(",1,1>"), name
