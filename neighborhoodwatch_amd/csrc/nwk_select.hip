@@ -10,6 +10,7 @@
 //      fp32 MFMA accumulator performs), canonical epilogue, 64-bit key written back in place; dropped entries become ~0
 //      (the sentinel compaction already sorts last).
 #define RS_QC 1024                    // query elements staged in LDS at a time (4 KiB per wave)
+#define RS_SEG_BYTES 64               // cooperative row fetch: bytes of every row per step (two stages of 64 rows x this per wave)
 
 // |estimate - canonical distance| of a listed pair is at most this: the bound E(q,b) the tile kernel pruned under (DESIGN.md "Bound"),
 // taken to the distance domain, plus the roundings of the estimate and of these lines themselves.
@@ -23,11 +24,11 @@ __device__ __forceinline__ float rescore_err(const NwkRescoreParams& p, float ro
     return err;
 }
 
-template <int METRIC, bool ROWS16>
+template <int METRIC, bool ROWS16, bool COOP>
 __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams p)
 {
     extern __shared__ __attribute__((aligned(16))) u32 rs_dyn[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = blockDim.x >> 6;
     const long long q = (long long)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + wv));
     u32* s_ub = rs_dyn + (size_t)wv * 2 * p.cap;          // later: the packed survivor slots
     u32* s_lb = s_ub + p.cap;
@@ -118,6 +119,82 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
         const u32 col = valid ? (u32)old : 0u;
         const char* __restrict__ brow = (const char*)p.bp + (long long)col * p.dp * ES;
         float acc = 0.0f;
+        if constexpr (COOP) {
+            // Round 5.  The lane-per-row loads below ask the CU's address unit for 64 different cache lines per instruction, 16 bytes of
+            // each: on chunks whose rows sit in L2 / the Infinity Cache -- the six growth chunks right behind the dense one, where two
+            // thirds of all pairs are rescored -- that unit, not memory, was the bound (~6.8 us per round of 64 pairs, one unit per CU:
+            // 5.2-5.9 ms per chunk of a C3 shard whatever the chunk's size).  Here the WAVE fetches the 64 rows of a round together:
+            // four consecutive lanes take the four 16-byte pieces of one row's 64-byte segment, an instruction covers 16 rows (16 lines,
+            // each used whole over two steps), straight into this wave's own LDS stage (global_load_lds, no register round trip); lane i
+            // then reads ITS row's segment back from LDS and runs the same ascending-k chain.  Same bits; two stages, the next
+            // segment in flight while this one is consumed; no barrier (the stage is private to the wave).
+            constexpr int SEG = RS_SEG_BYTES, LPR = SEG / 16, RPI = 64 / LPR, NI = 64 / RPI;
+            char* const stage = (char*)(rs_dyn + (size_t)wpb * 2 * p.cap) + (size_t)wpb * RS_QC * 4 + (size_t)wv * 2 * 64 * SEG;
+            __builtin_amdgcn_wave_barrier();
+            s_lb[lane] = col;                                           // (the lower bounds are not needed after the packing)
+            __builtin_amdgcn_wave_barrier();
+            const char* src[NI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int r = j * RPI + lane / LPR;
+                src[j] = (const char*)p.bp + (long long)s_lb[r] * p.dp * ES + (lane % LPR) * 16;
+            }
+            auto issue = [&](int buf, int kbyte) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + kbyte),
+                                                     (__attribute__((address_space(3))) void*)(stage + buf * 64 * SEG + j * 1024), 16, 0, 0);
+            };
+            for (int kc = 0; kc < p.dp; kc += RS_QC) {                  // wave-uniform; one pass for d <= 1024
+                const int n = (p.dp - kc < RS_QC) ? p.dp - kc : RS_QC;
+                const int steps = n * ES / SEG;                         // n is a multiple of 32 floats / 64 halves
+                issue(0, kc * ES);
+                f32x4 qt[RS_QC * 4 / 1024];
+#pragma unroll
+                for (int j = 0; j < RS_QC * 4 / 1024; ++j)
+                    if (lane * 16 + j * 1024 < n * ES) qt[j] = *(const f32x4*)(qbytes + (size_t)kc * ES + lane * 16 + j * 1024);
+                __builtin_amdgcn_wave_barrier();                        // the previous chunk has been read by every lane
+#pragma unroll
+                for (int j = 0; j < RS_QC * 4 / 1024; ++j)
+                    if (lane * 16 + j * 1024 < n * ES) *(f32x4*)(s_q + lane * 16 + j * 1024) = qt[j];
+                __builtin_amdgcn_wave_barrier();
+                for (int st = 0; st < steps; ++st) {
+                    // stage (st + 1) & 1 was read during step st - 1; those reads fed FMAs that have been issued: it may be overwritten
+                    if (st + 1 < steps) {
+                        issue((st + 1) & 1, kc * ES + (st + 1) * SEG);
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    const char* mine = stage + (st & 1) * 64 * SEG + lane * SEG;
+                    f32x4 ln[LPR];
+#pragma unroll
+                    for (int c = 0; c < LPR; ++c) ln[c] = *(const f32x4*)(mine + c * 16);
+                    const int kq = st * (SEG / ES);                     // element offset inside the staged query chunk
+                    if (ROWS16) {
+#pragma unroll
+                        for (int c = 0; c < LPR; ++c) {
+                            const f16x8 bv = __builtin_bit_cast(f16x8, ln[c]);
+                            const f16x8 qv = *(const f16x8*)(s_q + (size_t)kq * 2 + c * 16);
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) acc = __fmaf_rn((float)qv[t], (float)bv[t], acc);
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < LPR / 2; ++c) {             // prepared layout: [k k+2 k+4 k+6 | k+1 k+3 k+5 k+7]
+                            const f32x4 be = ln[2 * c], bo = ln[2 * c + 1];
+                            const f32x4 qe = *(const f32x4*)(s_q + (size_t)kq * 4 + c * 32), qo = *(const f32x4*)(s_q + (size_t)kq * 4 + c * 32 + 16);
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                acc = __fmaf_rn(qe[t], be[t], acc);
+                                acc = __fmaf_rn(qo[t], bo[t], acc);
+                            }
+                        }
+                    }
+                    asm volatile("" ::: "memory");                      // the reads of this stage stay above the next iteration's issue
+                }
+            }
+        }
         f32x4 la[8], lb[8];                                             // two lines of this lane's row
         auto load_line = [&](f32x4 (&dst)[8], int k) {
 #pragma unroll
@@ -145,7 +222,7 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
                 }
             }
         };
-        for (int kc = 0; kc < p.dp; kc += RS_QC) {                      // wave-uniform; one pass for d <= 1024
+        for (int kc = 0; !COOP && kc < p.dp; kc += RS_QC) {             // wave-uniform; one pass for d <= 1024
             const int n = (p.dp - kc < RS_QC) ? p.dp - kc : RS_QC;
             const int nl = n / line_elems;                              // n is a multiple of line_elems
             load_line(la, kc);
@@ -418,11 +495,16 @@ hipError_t nwk_launch_rescore(hipStream_t st, const NwkRescoreParams& p, int met
     if (nq_pad <= 0) return hipSuccess;
     const int waves = p.cap <= 1024 ? 4 : (p.cap <= 2048 ? 2 : 1);         // nq_pad is a multiple of 256
     const unsigned grid = (unsigned)(nq_pad / waves);
-    const size_t lds = (size_t)waves * p.cap * 8 + (size_t)waves * RS_QC * 4 + 512;   // lists + staged query chunks (+ slack: predicated-off lanes may still address past `end`)
+    const bool coop = p.coop != 0;
+    // lists + staged query chunks + (cooperative fetch) two stages of 64 row segments per wave; the legacy form keeps 512 B of slack
+    // behind the lists (predicated-off lanes may still address past `end`), the cooperative form has its stages there
+    const size_t lds = (size_t)waves * p.cap * 8 + (size_t)waves * RS_QC * 4 + (coop ? (size_t)waves * 2 * 64 * RS_SEG_BYTES : 512);
 #define NWK_RS(M)                                                                                                        \
     do {                                                                                                                  \
-        if (p.rows16) hipLaunchKernelGGL((nwk_rescore_kernel<M, true>), dim3(grid), dim3(64 * waves), lds, st, p);        \
-        else hipLaunchKernelGGL((nwk_rescore_kernel<M, false>), dim3(grid), dim3(64 * waves), lds, st, p);                \
+        if (p.rows16 && coop) hipLaunchKernelGGL((nwk_rescore_kernel<M, true, true>), dim3(grid), dim3(64 * waves), lds, st, p);        \
+        else if (p.rows16) hipLaunchKernelGGL((nwk_rescore_kernel<M, true, false>), dim3(grid), dim3(64 * waves), lds, st, p);          \
+        else if (coop) hipLaunchKernelGGL((nwk_rescore_kernel<M, false, true>), dim3(grid), dim3(64 * waves), lds, st, p);              \
+        else hipLaunchKernelGGL((nwk_rescore_kernel<M, false, false>), dim3(grid), dim3(64 * waves), lds, st, p);                       \
     } while (0)
     if (metric == NWKNN_METRIC_SQEUCLIDEAN) NWK_RS(NWKNN_METRIC_SQEUCLIDEAN);
     else if (metric == NWKNN_METRIC_ONE_MINUS_DOT) NWK_RS(NWKNN_METRIC_ONE_MINUS_DOT);

@@ -153,7 +153,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i, ctab, chk, calib;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 0, opt_f16_agg = -1, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_waves = 8, opt_ms_form = 3, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128, opt_pre_check_ppm = 1000000, opt_pre_direct_rows = -1;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 0, opt_f16_agg = -1, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_waves = 8, opt_ms_form = 3, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128, opt_pre_check_ppm = 1000000, opt_pre_direct_rows = -1, opt_rescore_coop = 1;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -335,6 +335,8 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
     } else if (!strcmp(name, "f16_agg")) {
         if (value < -1 || value > 1) return fail(NWKNN_EINVAL, "f16_agg must be -1 (auto), 0 (never) or 1 (every filtered fp16 chunk)");
         h->opt_f16_agg = value;             // which chunks run the row-aggregating build of the streaming fp16 kernel (auto: the loose-threshold ones)
+    } else if (!strcmp(name, "rescore_coop")) {
+        h->opt_rescore_coop = value ? 1 : 0; // rescoring kernel: 1 (default) a wave fetches the rows of its 64 pairs together through LDS, 0 every lane its own row
     } else if (!strcmp(name, "pre_direct_rows")) {
         if (value < -1) return fail(NWKNN_EINVAL, "pre_direct_rows must be -1 (auto) or a row count >= 0");
         h->opt_pre_direct_rows = value;     // pre-screened search of fp32 data: filtered chunks that START below this many rows run the direct fp32 kernel (run_chunk)
@@ -993,6 +995,7 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         // the k nearest: 512 -> ~110 rescored pairs per query, a third of a C4 search's rescoring.)
         rp.prune = (h->opt_pre_prune && !dedupe) ? 1 : 0;
         rp.rows16 = pl.native16 ? 1 : 0;
+        rp.coop = h->opt_rescore_coop ? 1 : 0;
         rp.eps_half = pl.pre_eps_half; rp.aq = pl.pre_aq; rp.ab = pl.pre_ab; rp.cst = pl.pre_cst;
         rp.chk_scale = pl.chk_scale;
         rp.chk = h->chk.as<u64>();
@@ -1828,7 +1831,7 @@ static int pair_distances_impl(nwknn_ctx* h, const void* queries, int64_t nq, in
     memset(&rp, 0, sizeof rp);
     rp.qp = h->qp.as<float>(); rp.bp = h->bp.as<float>(); rp.qn = h->qn.as<float>(); rp.bn = h->bn.as<float>();
     rp.buf = h->buf.as<u64>(); rp.cnt = h->cnt.as<u32>(); rp.cnt0 = h->cnt0.as<u32>();
-    rp.dp = h->dp; rp.cap = (int)cap; rp.k = k; rp.prune = 0; rp.rows16 = h->f16 ? 1 : 0;
+    rp.dp = h->dp; rp.cap = (int)cap; rp.k = k; rp.prune = 0; rp.rows16 = h->f16 ? 1 : 0; rp.coop = h->opt_rescore_coop ? 1 : 0;
     rp.chk_scale = 1.0f; rp.chk = nullptr;                          // nothing to hold these keys against: they carry no estimate
     HIPCHK(nwk_launch_rescore(h->stream, rp, metric, nq_pad));      // the canonical chain over the prepared rows, one lane per pair
     float* od = out_dist;
