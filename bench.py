@@ -814,6 +814,20 @@ def main():
                                         f"{SECONDARY_BUDGET_S:.0f} s; run `python bench.py --workload {name}` for it"}
                 continue
             try:
+                if name != "c4gpu":
+                    # Only the c4gpu leg (a handful of 0.1-0.8 s launches per search: the host idles) shares the machine with the background
+                    # threads.  The other legs submit a launch every few milliseconds, and this container's CPU quota (16 CPUs' worth; the
+                    # BLAS baseline alone takes all of it) freezes EVERY thread of the process, the submitting one included, once it is spent:
+                    # a refcli leg that overlapped the baseline read 5 033 q/s instead of 11 600 (profiles/r05bf_*).  So: wait for them here.
+                    if hasattr(line.get("cpu_baseline"), "result"):
+                        try:
+                            line["cpu_baseline"] = line["cpu_baseline"].result()
+                            line["cpu_baseline"]["ran"] = "on a background thread under the c4gpu leg (GPU work with an idle host); the later legs waited for it"
+                        except Exception as e:
+                            line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+                    if ref_files is not None:
+                        ref_files.thread.join()
+                    t0 = time.perf_counter()
                 s_out, _ = b.run(name, s_steps, 1, 0 if args.no_prescreen else s_pre, warm_queries=s_warm_q)
                 if name == "refcli":
                     s_out["vs_reference_published"] = ref_published_block(s_out["value"], s_out.get("exact_prescreen"))
@@ -832,7 +846,7 @@ def main():
         if hasattr(line.get("cpu_baseline"), "result"):               # the host-side baseline ran on a background thread under the GPU-only legs above
             try:
                 line["cpu_baseline"] = line["cpu_baseline"].result()
-                line["cpu_baseline"]["ran"] = "on a background thread while the secondary legs (GPU work with an idle host) ran"
+                line["cpu_baseline"]["ran"] = "on a background thread while the secondary legs ran"
             except Exception as e:
                 line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         line["wall_s_since_process_start"] = time.perf_counter() - T_PROCESS_START
