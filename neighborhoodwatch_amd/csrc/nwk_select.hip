@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
     u32* s_lb = s_ub + p.cap;
     const u32 start = p.cnt0[q];
     u32 end = p.cnt[q];
-    if (end > (u32)p.cap) end = (u32)p.cap;
+    const bool over = end > (u32)p.cap;                    // the list overflowed: its length is left alone (the compaction flags the query for repair)
+    if (over) end = (u32)p.cap;
     if (start >= end) return;
     const float* __restrict__ qrow = ROWS16 ? nullptr : p.qp + q * p.dp;
     const _Float16* __restrict__ qrow16 = ROWS16 ? (const _Float16*)p.qp + q * p.dp : nullptr;      // exact fp16 mode: the rows ARE the data
@@ -246,7 +247,12 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
         }
         const float bnc = p.bn[col];
         const float dist = distance_epilogue<METRIC>(acc, qn, bnc);
-        if (valid) list[e] = ((u64)sortable_u32(dist) << 32) | col;
+        // Survivors go back PACKED behind the compacted prefix (slot start + i; i <= e - start, and the slots a round writes lie below every
+        // slot a later round still has to read), and the list's length becomes start + nsurv below: the compaction that follows sorts
+        // ~2 k entries instead of every slot the tile kernel filled (a C3 shard: ~520 listed, ~90 rescored per query and chunk).
+        const u64 fresh = valid ? (((u64)sortable_u32(dist) << 32) | col) : ~0ull;
+        if (packed && !over) { if (live) list[start + i] = fresh; }
+        else if (valid) list[e] = fresh;
         {
             const float est = __uint_as_float((u32)(old >> 32));
             const float err = rescore_err<METRIC>(p, row_err, qn, bnc, est);
@@ -261,6 +267,7 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
             if (judged) worst = fmaxf(worst, ratio == ratio ? ratio : __builtin_inff());
         }
     }
+    if (packed && !over && lane == 0) p.cnt[q] = start + nsurv;
     if (p.chk) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) worst = fmaxf(worst, __shfl_xor(worst, o));

@@ -1010,7 +1010,7 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
     }
 
     NwkCompactParams cp = compact_params(h, pl, k);
-    cp.dense_count = dense ? (int)rows : 0;
+    cp.dense_count = (dense && !prescreen) ? (int)rows : 0;      // (a rescored dense chunk -- exact fp16 mode -- has its length in cnt: rows, or what the rescoring kernel kept)
     cp.dedupe = dedupe ? 1 : 0;
     cp.qtile_list = qtile_list;
     const long long nqc = qtile_list ? (long long)n_list_tiles * pl.tile_rows : nq_pad;

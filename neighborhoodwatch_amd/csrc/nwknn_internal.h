@@ -60,7 +60,7 @@ struct NwkRescoreParams {
     const float* qn;
     const float* bn;
     unsigned long long* buf;
-    const unsigned int* cnt;       // entries now
+    unsigned int* cnt;             // entries now; the rescoring kernel shortens a pruned list to cnt0 + survivors
     const unsigned int* cnt0;      // entries after the last compaction: [cnt0, min(cnt, cap)) are pre-screen candidates
     int dp;
     int cap;
