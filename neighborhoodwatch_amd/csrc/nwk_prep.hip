@@ -17,6 +17,17 @@ __global__ __launch_bounds__(256) void nwk_gen_kernel(u64 seed, long long row0, 
     }
 }
 
+// max |x| of everything a prep kernel lays out, folded into the layout pass (round 5; the pre-screen's scale needs it, and the separate
+// reduction re-read the whole prepared base): per lane the largest |x| as float bits (non-negative floats order like their bit patterns;
+// NaN / Inf show up as >= 0x7F800000, as in nwk_maxabs_kernel), one atomicMax per wave.
+__device__ __forceinline__ void prep_fold_maxabs(u32 mbits, u32* __restrict__ out_bits)
+{
+    if (!out_bits) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const u32 other = (u32)__shfl_xor((int)mbits, o); mbits = other > mbits ? other : mbits; }
+    if ((threadIdx.x & 63) == 0 && mbits) atomicMax(out_bits, mbits);
+}
+
 // ------------------------------------------------------------------------------------------------
 // prep: raw row-major f32 [rows][d]  ->  MFMA-ready layout [rows_pad][dp] + squared norms
 //   * dp = d rounded up to 32 (zero padded: fma(0,0,acc) leaves every chain unchanged)
@@ -26,16 +37,16 @@ __global__ __launch_bounds__(256) void nwk_gen_kernel(u64 seed, long long row0, 
 //   * norm = the same ascending fmaf chain the MFMA performs for q.q (one lane owns one row)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nwk_prep_kernel(const float* __restrict__ raw, long long rows, int d, long long rows_pad,
-                                                        int dp, float* __restrict__ prepared, float* __restrict__ norms)
+                                                        int dp, float* __restrict__ prepared, float* __restrict__ norms, u32* __restrict__ maxabs_bits)
 {
     const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows_pad) return;
-    float* dst = prepared + r * dp;
-    if (r >= rows) {
+    u32 mbits = 0u;
+    if (r < rows_pad && r >= rows) {
+        float* dst = prepared + r * dp;
         for (int k = 0; k < dp; k += 4) *(f32x4*)(dst + k) = (f32x4){0.f, 0.f, 0.f, 0.f};
         norms[r] = 0.0f;
-        return;
-    }
+    } else if (r < rows) {
+    float* dst = prepared + r * dp;
     const float* src = raw + r * (long long)d;
     float acc = 0.0f;
     const bool vec = ((d & 3) == 0) && ((((uintptr_t)raw) & 15) == 0);
@@ -49,11 +60,13 @@ __global__ __launch_bounds__(256) void nwk_prep_kernel(const float* __restrict__
             for (int j = 0; j < 8; ++j) x[j] = (k0 + j < d) ? src[k0 + j] : 0.0f;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc = __fmaf_rn(x[j], x[j], acc);
+        for (int j = 0; j < 8; ++j) { acc = __fmaf_rn(x[j], x[j], acc); const u32 b = __float_as_uint(x[j]) & 0x7FFFFFFFu; mbits = b > mbits ? b : mbits; }
         *(f32x4*)(dst + k0) = (f32x4){x[0], x[2], x[4], x[6]};
         *(f32x4*)(dst + k0 + 4) = (f32x4){x[1], x[3], x[5], x[7]};
     }
     norms[r] = acc;
+    }
+    prep_fold_maxabs(mbits, maxabs_bits);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -68,7 +81,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <typename TIN, bool OUT16>
 __global__ __launch_bounds__(256) void nwk_prep_tiled_kernel(const TIN* __restrict__ raw, long long rows, int d, long long rows_pad, int dp,
-                                                              void* __restrict__ prepared, float* __restrict__ norms)
+                                                              void* __restrict__ prepared, float* __restrict__ norms, u32* __restrict__ maxabs_bits)
 {
     // round 2: a step moves 128 B of input per row (was 64): every global access is now a whole 128-B line (eight lanes per row), and
     // the next step's lines are requested one step ahead (registers) so that they fly under the LDS passes and the stores of this one
@@ -101,6 +114,7 @@ __global__ __launch_bounds__(256) void nwk_prep_tiled_kernel(const TIN* __restri
     const size_t in_row_bytes = (size_t)d * sizeof(TIN);
     const size_t out_row_bytes = (size_t)dp * OES;
     float acc = 0.0f;
+    u32 mbits = 0u;
 
     u32x4 v[SEGS];
     auto fetch = [&](int k0) {
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(256) void nwk_prep_tiled_kernel(const TIN* __restri
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < KS; ++j) acc = __fmaf_rn(x[j], x[j], acc);
+                for (int j = 0; j < KS; ++j) { acc = __fmaf_rn(x[j], x[j], acc); const u32 b = __float_as_uint(x[j]) & 0x7FFFFFFFu; mbits = b > mbits ? b : mbits; }
 #pragma unroll
                 for (int g = 0; g < KS / 8; ++g) {            // [0 2 4 6 | 1 3 5 7] inside every group of 8
                     *(f32x4*)(tile_out + tid * PITCH + g * 32) = (f32x4){x[8 * g], x[8 * g + 2], x[8 * g + 4], x[8 * g + 6]};
@@ -180,6 +194,7 @@ __global__ __launch_bounds__(256) void nwk_prep_tiled_kernel(const TIN* __restri
 #endif
     }
     if (r0 + tid < rows_pad) norms[r0 + tid] = acc;
+    if (!OUT16) prep_fold_maxabs(mbits, maxabs_bits);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -192,10 +207,12 @@ __global__ __launch_bounds__(256) void nwk_prep_tiled_kernel(const TIN* __restri
 // ------------------------------------------------------------------------------------------------
 template <typename TIN, bool OUT16>
 __global__ __launch_bounds__(256) void nwk_prep_strided_kernel(const TIN* __restrict__ raw, long long rs, long long ks, long long rows, int d,
-                                                                long long rows_pad, int dp, void* __restrict__ prepared, float* __restrict__ norms)
+                                                                long long rows_pad, int dp, void* __restrict__ prepared, float* __restrict__ norms,
+                                                                u32* __restrict__ maxabs_bits)
 {
     const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows_pad) return;
+    u32 mbits = 0u;
+    if (r < rows_pad) {
     const bool live = r < rows;
     const TIN* src = raw + r * rs;
     float acc = 0.0f;
@@ -214,13 +231,15 @@ __global__ __launch_bounds__(256) void nwk_prep_strided_kernel(const TIN* __rest
             *(f16x8*)((_Float16*)prepared + r * dp + k0) = hv;
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc = __fmaf_rn(x[j], x[j], acc);
+            for (int j = 0; j < 8; ++j) { acc = __fmaf_rn(x[j], x[j], acc); const u32 b = __float_as_uint(x[j]) & 0x7FFFFFFFu; mbits = b > mbits ? b : mbits; }
             float* dst = (float*)prepared + r * dp + k0;
             *(f32x4*)(dst) = (f32x4){x[0], x[2], x[4], x[6]};
             *(f32x4*)(dst + 4) = (f32x4){x[1], x[3], x[5], x[7]};
         }
     }
     norms[r] = acc;
+    }
+    if (!OUT16) prep_fold_maxabs(mbits, maxabs_bits);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -406,9 +425,9 @@ hipError_t nwk_launch_prep_f16(hipStream_t st, const void* raw, int raw_is_f16, 
     const unsigned blocks = (unsigned)((rows_pad + 255) / 256);
     if ((((uintptr_t)raw) & 15) == 0 && (raw_is_f16 ? (d % 8 == 0) : (d % 4 == 0))) {          // tiled fast path
         if (raw_is_f16)
-            hipLaunchKernelGGL((nwk_prep_tiled_kernel<_Float16, true>), dim3(blocks), dim3(256), 0, st, (const _Float16*)raw, rows, d, rows_pad, dp, prepared, norms);
+            hipLaunchKernelGGL((nwk_prep_tiled_kernel<_Float16, true>), dim3(blocks), dim3(256), 0, st, (const _Float16*)raw, rows, d, rows_pad, dp, prepared, norms, (u32*)nullptr);
         else
-            hipLaunchKernelGGL((nwk_prep_tiled_kernel<float, true>), dim3(blocks), dim3(256), 0, st, (const float*)raw, rows, d, rows_pad, dp, prepared, norms);
+            hipLaunchKernelGGL((nwk_prep_tiled_kernel<float, true>), dim3(blocks), dim3(256), 0, st, (const float*)raw, rows, d, rows_pad, dp, prepared, norms, (u32*)nullptr);
         return hipGetLastError();
     }
     if (raw_is_f16)
@@ -420,11 +439,11 @@ hipError_t nwk_launch_prep_f16(hipStream_t st, const void* raw, int raw_is_f16, 
 
 // in_dtype: 0 f32, 1 f16, 2 f64 (NWKNN_DTYPE_*)
 hipError_t nwk_launch_prep_strided(hipStream_t st, const void* raw, int in_dtype, long long rs, long long ks, long long rows, int d,
-                                   long long rows_pad, int dp, int out_f16, void* prepared, float* norms)
+                                   long long rows_pad, int dp, int out_f16, void* prepared, float* norms, unsigned int* maxabs_bits)
 {
     if (rows_pad <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((rows_pad + 255) / 256);
-#define NWK_PS(T, O) hipLaunchKernelGGL((nwk_prep_strided_kernel<T, O>), dim3(blocks), dim3(256), 0, st, (const T*)raw, rs, ks, rows, d, rows_pad, dp, prepared, norms)
+#define NWK_PS(T, O) hipLaunchKernelGGL((nwk_prep_strided_kernel<T, O>), dim3(blocks), dim3(256), 0, st, (const T*)raw, rs, ks, rows, d, rows_pad, dp, prepared, norms, maxabs_bits)
     if (in_dtype == 0) { if (out_f16) NWK_PS(float, true); else NWK_PS(float, false); }
     else if (in_dtype == 1) { if (out_f16) NWK_PS(_Float16, true); else return hipErrorInvalidValue; }
     else if (in_dtype == 2) { if (out_f16) NWK_PS(double, true); else NWK_PS(double, false); }
@@ -434,15 +453,15 @@ hipError_t nwk_launch_prep_strided(hipStream_t st, const void* raw, int in_dtype
 }
 
 hipError_t nwk_launch_prep(hipStream_t st, const float* raw, long long rows, int d, long long rows_pad, int dp, float* prepared,
-                           float* norms)
+                           float* norms, unsigned int* maxabs_bits)
 {
     if (rows_pad <= 0) return hipSuccess;
     const long long blocks = (rows_pad + 255) / 256;
     if ((((uintptr_t)raw) & 15) == 0 && d % 4 == 0) {                                           // tiled fast path
-        hipLaunchKernelGGL((nwk_prep_tiled_kernel<float, false>), dim3((unsigned)blocks), dim3(256), 0, st, raw, rows, d, rows_pad, dp, (void*)prepared, norms);
+        hipLaunchKernelGGL((nwk_prep_tiled_kernel<float, false>), dim3((unsigned)blocks), dim3(256), 0, st, raw, rows, d, rows_pad, dp, (void*)prepared, norms, maxabs_bits);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(nwk_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, st, raw, rows, d, rows_pad, dp, prepared, norms);
+    hipLaunchKernelGGL(nwk_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, st, raw, rows, d, rows_pad, dp, prepared, norms, maxabs_bits);
     return hipGetLastError();
 }
 

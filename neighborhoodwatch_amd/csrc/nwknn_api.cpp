@@ -129,7 +129,8 @@ struct nwknn_ctx {
     hipEvent_t ev_fw_ready = nullptr, ev_fw_done = nullptr;
     long long up_seq = 0;           // slabs the column upload pipeline has sent so far (never reset: the two pinned / device slabs alternate across calls)
     // base shard
-    DevBuf bp, bn, braw;
+    DevBuf bp, bn, braw, bmax;      // bmax: float bits of max |x| of the base being laid out (folded into the layout pass when the pre-screen is on)
+    int bmax_fused = 0;             // 1: the layout launches of the current base feed bmax
     // a base that is being handed over in pieces (nwknn_base_begin / _append* / _end): rows expected, rows laid out so far; 0 = none
     long long sb_rows = 0, sb_done = 0, sb_rows_pad = 0;
     int sb_d = 0, sb_dp = 0, sb_f16 = 0, sb_pre = 0;
@@ -428,12 +429,12 @@ extern "C" int nwknn_synchronize(nwknn_handle h)
 // Stages a caller matrix onto the device (if it is on the host) and runs the prep kernel into dst/norms.
 // in_f16: element type of the caller's matrix; out_f16: element type of the prepared layout (the compute path).
 static int stage_and_prep(nwknn_ctx* h, const void* src, int location, int in_f16, int out_f16, long long rows, int d, long long rows_pad,
-                          int dp, DevBuf& raw, void* dst, float* norms)
+                          int dp, DevBuf& raw, void* dst, float* norms, unsigned int* maxabs_bits = nullptr)
 {
     const size_t in_es = in_f16 ? 2 : 4, out_es = out_f16 ? 2 : 4;
     auto launch = [&](const void* dsrc, long long real, long long pad, void* ddst, float* dn) -> hipError_t {
         if (out_f16) return nwk_launch_prep_f16(h->stream, dsrc, in_f16, real, d, pad, dp, ddst, dn);
-        return nwk_launch_prep(h->stream, (const float*)dsrc, real, d, pad, dp, (float*)ddst, dn);
+        return nwk_launch_prep(h->stream, (const float*)dsrc, real, d, pad, dp, (float*)ddst, dn, maxabs_bits);
     };
     if (in_f16 && !out_f16) return fail(NWKNN_EINVAL, "fp16 input needs the fp16 compute path (set option compute_dtype=1 or pass an fp16 base)");
     if (location == NWKNN_HOST) {
@@ -497,7 +498,7 @@ static int ensure_upload_pipeline(nwknn_ctx* h, size_t slab_bytes)
 // gathered into the pinned slabs -- the H2D copy and the layout kernel of the last slab(s) are still in flight on the copy / compute
 // streams, ordered against the next call's by the same events that order slab s against slab s+2 inside one call.
 static int stage_and_prep_columns(nwknn_ctx* h, const ColumnSource& src, int in_dtype, int out_f16, long long rows, int d, long long rows_pad,
-                                  int dp, DevBuf& raw, void* dst, float* norms, bool finish = true)
+                                  int dp, DevBuf& raw, void* dst, float* norms, bool finish = true, unsigned int* maxabs_bits = nullptr)
 {
     const size_t in_es = in_dtype == NWKNN_DTYPE_F64 ? 8 : (in_dtype == NWKNN_DTYPE_F16 ? 2 : 4), out_es = out_f16 ? 2 : 4;
     if (in_dtype == NWKNN_DTYPE_F16 && !out_f16) return fail(NWKNN_EINVAL, "fp16 columns need the fp16 compute path");
@@ -579,7 +580,7 @@ static int stage_and_prep_columns(nwknn_ctx* h, const ColumnSource& src, int in_
         }
         EvPair* e = ev_begin(h, 2);
         HIPCHK(nwk_launch_prep_strided(h->stream, dev_slab, in_dtype, 1, stage_rows, real_here, d, pad_here, dp, out_f16,
-                                       (char*)dst + (size_t)r0 * dp * out_es, norms + r0));
+                                       (char*)dst + (size_t)r0 * dp * out_es, norms + r0, maxabs_bits));
         ev_end(h, e);
         HIPCHK(hipEventRecord(h->ev_prepped[b], h->stream));
     }
@@ -663,6 +664,12 @@ static int base_plan(nwknn_ctx* h, int64_t rows, int32_t d, int dtype, bool cols
     RCCHK(h->bp.ensure((size_t)bp->rows_pad * bp->dp * (bp->f16 ? 2 : 4)));
     RCCHK(h->bn.ensure((size_t)bp->rows_pad * 4));
     h->ev_used = 0;
+    h->bmax_fused = 0;
+    if (bp->pre) {                                                  // max |x| rides the layout launches of this base (base_finish reads it)
+        RCCHK(h->bmax.ensure(16));
+        HIPCHK(hipMemsetAsync(h->bmax.p, 0, 4, h->stream));
+        h->bmax_fused = 1;
+    }
     return NWKNN_OK;
 }
 
@@ -682,7 +689,16 @@ static int base_finish(nwknn_ctx* h, const BasePlan& b)
     }
     if (b.pre) {
         bool usable = false;
-        RCCHK(matrix_maxabs(h, h->bp.as<float>(), rows_pad * (long long)dp, &h->b_maxabs, &usable));
+        if (h->bmax_fused) {                                        // folded into the layout launches: no pass over the prepared base
+            u32 bits = 0;
+            HIPCHK(hipMemcpyAsync(&bits, h->bmax.p, 4, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            memcpy(&h->b_maxabs, &bits, 4);
+            usable = bits < 0x7F800000u && h->b_maxabs >= 0x1p-40f && h->b_maxabs <= 0x1p40f;
+            h->bmax_fused = 0;
+        } else {
+            RCCHK(matrix_maxabs(h, h->bp.as<float>(), rows_pad * (long long)dp, &h->b_maxabs, &usable));
+        }
         h->nb_pad_for_copy = rows_pad; h->dp_for_copy = dp;
         if (usable) {       // else (NaN/Inf/extreme magnitudes/all zero): searches on this base run the direct fp32 kernel
             h->dp16 = (int)round_up(d, NWK_K_ALIGN_F16);
@@ -710,8 +726,9 @@ static int set_base_common(nwknn_ctx* h, const void* base, const ColumnSource* c
     if (!cols && location != NWKNN_HOST && location != NWKNN_DEVICE) return fail(NWKNN_EINVAL, "bad location %d", location);
     BasePlan b;
     RCCHK(base_plan(h, rows, d, dtype, cols, &b));
-    if (cols) RCCHK(stage_and_prep_columns(h, *columns, dtype, b.f16, rows, d, b.rows_pad, b.dp, h->braw, h->bp.p, h->bn.as<float>()));
-    else RCCHK(stage_and_prep(h, base, location, dtype == NWKNN_DTYPE_F16, b.f16, rows, d, b.rows_pad, b.dp, h->braw, h->bp.p, h->bn.as<float>()));
+    unsigned int* const mx = h->bmax_fused ? h->bmax.as<u32>() : nullptr;
+    if (cols) RCCHK(stage_and_prep_columns(h, *columns, dtype, b.f16, rows, d, b.rows_pad, b.dp, h->braw, h->bp.p, h->bn.as<float>(), true, mx));
+    else RCCHK(stage_and_prep(h, base, location, dtype == NWKNN_DTYPE_F16, b.f16, rows, d, b.rows_pad, b.dp, h->braw, h->bp.p, h->bn.as<float>(), mx));
     return base_finish(h, b);
 }
 
@@ -748,7 +765,7 @@ static int base_append_columns_common(nwknn_ctx* h, const ColumnSource& src, int
     if (dtype != NWKNN_DTYPE_F32 && dtype != NWKNN_DTYPE_F16 && dtype != NWKNN_DTYPE_F64) return fail(NWKNN_EINVAL, "nwknn_base_append_column_chunks: unsupported dtype %d", dtype);
     const size_t out_es = h->sb_f16 ? 2 : 4;
     const int rc = stage_and_prep_columns(h, src, dtype, h->sb_f16, n, h->sb_d, n, h->sb_dp, h->braw, (char*)h->bp.p + (size_t)h->sb_done * h->sb_dp * out_es,
-                                          h->bn.as<float>() + h->sb_done, false);
+                                          h->bn.as<float>() + h->sb_done, false, h->bmax_fused ? h->bmax.as<u32>() : nullptr);
     if (rc != NWKNN_OK) { h->sb_rows = 0; return rc; }              // a failed piece abandons the base (streams may hold half of it)
     h->sb_done += n;
     return follow_advance(h, false);
@@ -761,7 +778,8 @@ static int base_append_rows_common(nwknn_ctx* h, const void* rows_ptr, int64_t n
     if (location != NWKNN_HOST && location != NWKNN_DEVICE) return fail(NWKNN_EINVAL, "bad location %d", location);
     const size_t out_es = h->sb_f16 ? 2 : 4;
     const int rc = stage_and_prep(h, rows_ptr, location, dtype == NWKNN_DTYPE_F16, h->sb_f16, n, h->sb_d, n, h->sb_dp, h->braw,
-                                  (char*)h->bp.p + (size_t)h->sb_done * h->sb_dp * out_es, h->bn.as<float>() + h->sb_done);
+                                  (char*)h->bp.p + (size_t)h->sb_done * h->sb_dp * out_es, h->bn.as<float>() + h->sb_done,
+                                  h->bmax_fused ? h->bmax.as<u32>() : nullptr);
     if (rc != NWKNN_OK) { h->sb_rows = 0; return rc; }
     h->sb_done += n;
     return follow_advance(h, false);

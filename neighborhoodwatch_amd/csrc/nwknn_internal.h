@@ -117,8 +117,10 @@ hipError_t nwk_launch_tile_f16x_raw(hipStream_t st, const NwkTileParams& p, int 
 hipError_t nwk_launch_tile_f16y_pre(hipStream_t st, const NwkTileParams& p, int metric, unsigned grid);          // two-issuing-waves form (f16_mfma = 5), pre-screen
 hipError_t nwk_launch_tile_f16y_raw(hipStream_t st, const NwkTileParams& p, int metric, unsigned grid);          // ... raw fp16 sums
 hipError_t nwk_launch_prep_strided(hipStream_t st, const void* raw, int in_dtype, long long rs, long long ks, long long rows, int d,
-                                   long long rows_pad, int dp, int out_f16, void* prepared, float* norms);
-hipError_t nwk_launch_prep(hipStream_t st, const float* raw, long long rows, int d, long long rows_pad, int dp, float* prepared, float* norms);
+                                   long long rows_pad, int dp, int out_f16, void* prepared, float* norms, unsigned int* maxabs_bits = nullptr);
+// maxabs_bits (fp32 layouts only, may be null): atomicMax of the float bits of the largest |x| laid out -- the pre-screen's scale without a pass of its own
+hipError_t nwk_launch_prep(hipStream_t st, const float* raw, long long rows, int d, long long rows_pad, int dp, float* prepared, float* norms,
+                           unsigned int* maxabs_bits = nullptr);
 hipError_t nwk_launch_tile(hipStream_t st, NwkTileParams p, int metric, bool dense, int tile_rows, int diag, int occ);   // occ: workgroups per CU of the 256-row shape (2 or 3)
 hipError_t nwk_launch_half_copy16(hipStream_t st, const void* rows16, long long rows_pad, int dp, float scale, const float* norms, void* out16);
 hipError_t nwk_launch_maxabs_f16(hipStream_t st, const void* x, long long n, unsigned int* out_bits);
