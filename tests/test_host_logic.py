@@ -427,3 +427,55 @@ def test_bench_does_not_start_ranks_from_under_a_profiler(env):
     r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--workload", "dev"], env={**os.environ, **env},
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 4 and "refusing to start 2 ranks from under a profiler" in r.stderr and r.stdout == ""
+
+
+def test_effective_cpus_honours_the_cgroup_quota_and_sizes_pyarrows_pool(monkeypatch, tmp_path):
+    """hostinfo.effective_cpus: the affinity mask capped by the cgroup CPU quota (cgroup v2 ``cpu.max``: "<quota> <period>" or "max <period>"),
+    and size_arrow_pool only ever SHRINKS pyarrow's CPU pool (NWKNN_ARROW_THREADS sets it outright, 0 leaves it alone)."""
+    import builtins
+    import pyarrow as pa
+    from neighborhoodwatch_amd import hostinfo
+    real_open = builtins.open
+
+    def fake(content):
+        def _open(path, *a, **kw):
+            if str(path) == "/sys/fs/cgroup/cpu.max":
+                if content is None:
+                    raise FileNotFoundError(path)
+                f = tmp_path / "cpu.max"
+                f.write_text(content)
+                return real_open(f, *a, **kw)
+            if str(path).startswith("/sys/fs/cgroup/cpu/"):
+                raise FileNotFoundError(path)
+            return real_open(path, *a, **kw)
+        return _open
+
+    monkeypatch.setattr(hostinfo.os, "sched_getaffinity", lambda pid: set(range(256)), raising=False)
+    monkeypatch.setattr(builtins, "open", fake("1600000 100000"))
+    assert hostinfo.effective_cpus() == 16
+    monkeypatch.setattr(builtins, "open", fake("150000 100000"))
+    assert hostinfo.effective_cpus() == 2                               # a quota of 1.5 CPUs: rounded up
+    monkeypatch.setattr(builtins, "open", fake("max 100000"))
+    assert hostinfo.effective_cpus() == 256
+    monkeypatch.setattr(builtins, "open", fake(None))
+    assert hostinfo.effective_cpus() == 256
+
+    before = pa.cpu_count()
+    try:
+        monkeypatch.setattr(builtins, "open", fake("200000 100000"))
+        pa.set_cpu_count(8)
+        monkeypatch.setattr(hostinfo, "_arrow_sized", False)
+        monkeypatch.delenv("NWKNN_ARROW_THREADS", raising=False)
+        assert hostinfo.size_arrow_pool() == 2                          # shrunk to the quota
+        pa.set_cpu_count(1)
+        monkeypatch.setattr(hostinfo, "_arrow_sized", False)
+        assert hostinfo.size_arrow_pool() == 1                          # never grown
+        monkeypatch.setattr(hostinfo, "_arrow_sized", False)
+        monkeypatch.setenv("NWKNN_ARROW_THREADS", "3")
+        assert hostinfo.size_arrow_pool() == 3                          # set outright
+        pa.set_cpu_count(5)
+        monkeypatch.setattr(hostinfo, "_arrow_sized", False)
+        monkeypatch.setenv("NWKNN_ARROW_THREADS", "0")
+        assert hostinfo.size_arrow_pool() == 5                          # left alone
+    finally:
+        pa.set_cpu_count(before)
