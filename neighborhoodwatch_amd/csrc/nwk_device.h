@@ -179,6 +179,7 @@ __device__ __forceinline__ TileCoord tile_from_block(const NwkTileParams& p)
 // branch per element: ~60k cycles per tile; this form: a few thousand).
 // ------------------------------------------------------------------------------------------------
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Pre-filter.  key < tau requires dist <= tau_d (tau_d = distance part of tau).  For the two additive metrics that is a
 // lower bound on the raw dot product that splits into a row part and a column part:
@@ -251,6 +252,22 @@ __device__ __forceinline__ float prescreen_col(float bn, const NwkTileParams& p)
     return c * p.pre_scale;
 }
 
+// one register of survivors (a half-wave's lanes hold 32 columns of ONE query row): one list-length atomic per half-wave, positions by rank
+__device__ __forceinline__ void append_half_wave(const NwkTileParams& p, bool pass, u64 key, long long qrow, int h, int c32)
+{
+    const u64 mk = __ballot(pass);
+    if (!mk) return;                                                 // wave-uniform
+    const u32 mh = h ? (u32)(mk >> 32) : (u32)mk;
+    const int leader = mh ? (__ffs(mh) - 1) : 0;
+    u32 base = 0;
+    if (mh && c32 == leader) base = atomicAdd(p.cnt + qrow, (u32)__popc(mh));
+    base = __shfl(base, leader + (h << 5));
+    if (pass) {
+        const u32 pos = base + __popc(mh & ((1u << c32) - 1u));
+        if (pos < (u32)p.cap) p.buf[qrow * p.cap + pos] = key;
+    }
+}
+
 template <int METRIC, bool DENSE, int MT, int PRE = 0>
 __device__ __forceinline__ void tile_epilogue(const NwkTileParams& p, const f32x16 (&acc)[MT][2], const float* s_qn, const u64* s_tau,
                                               const float* s_pre, const float (&bnv)[2], const u32 (&colv)[2], const bool (&colok)[2],
@@ -306,6 +323,27 @@ __device__ __forceinline__ void tile_epilogue(const NwkTileParams& p, const f32x
             // reach the atomics
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                if constexpr (METRIC == NWKNN_METRIC_COSINE && !PRE) {
+                    // cosine: two rows at a time -- the correctly rounded division's temporaries come on top of the 128 accumulators, and four
+                    // keys + four thresholds beside them were what the three-per-CU build spilled (10 -> see tests/test_isa_budget.py)
+                    const float bsn = sqrtf(bnv[n]);                 // a flagged block is rare: the root is taken here, not held through the tile
+#pragma unroll
+                    for (int i0 = 0; i0 < 4; i0 += 2) {
+                        const f32x2 qn2 = *(const f32x2*)(s_qn + rb + 8 * j + i0);
+                        const u64x2 t2 = *(const u64x2*)(s_tau + rb + 8 * j + i0);
+                        u64 key[2];
+                        bool pass[2];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const float dist = distance_from_staged<METRIC>(acc[m][n][4 * j + i0 + i], qn2[i], bsn);
+                            key[i] = ((u64)sortable_u32(dist) << 32) | colv[n];
+                            pass[i] = (key[i] < t2[i]) & colok[n];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) append_half_wave(p, pass[i], key[i], q0 + rb + i0 + i + 8 * j, h, c32);
+                    }
+                    continue;
+                }
                 const f32x4 qn4 = *(const f32x4*)(s_qn + rb + 8 * j);
                 const u64x2 tl = *(const u64x2*)(s_tau + rb + 8 * j);
                 const u64x2 th = *(const u64x2*)(s_tau + rb + 8 * j + 2);

@@ -25,9 +25,10 @@ def metadata():
 def test_fp32_tile_kernel_keeps_three_workgroups_per_cu(metadata):
     md = metadata["f32"]
     # cosine pre-tested on the distance until round 5 -- two correctly rounded roots and a division per accumulator, 38 spilled registers;
-    # now a multiplicative split (row term x column term) with the roots staged once per tile: 10, every one of them stored in the prologue or
-    # the epilogue.  What the speed depends on is asserted directly: NO scratch access inside the loop that issues the MFMAs.
-    for metric, max_spill in ((0, 7), (1, 7), (2, 12)):
+    # then a multiplicative split (row term x column term) with the roots staged once per tile: 10; the exact pass of a flagged block taken two
+    # rows at a time (two keys + two thresholds beside the division's temporaries instead of four + four): 4, the other metrics' budget.
+    # What the speed depends on is asserted directly: NO scratch access inside the loop that issues the MFMAs.
+    for metric, max_spill in ((0, 7), (1, 7), (2, 7)):
         k = md[f"nwk_tile_kernel<{metric}, false, 256, 16, 0, 3>"]
         assert k["vgpr"] <= 168 and k["agpr"] == 0, k          # 3 x 168 <= 512 registers per SIMD lane
         assert k["lds"] <= 160 * 1024 // 3, k                  # three 48 KiB workgroups share a CU's 160 KiB
