@@ -42,8 +42,9 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
     const float qn = p.qn[q];
     u64* list = p.buf + q * p.cap;
 
-    u32 nsurv = 0;
+    u32 nsurv = 0, U = 0xFFFFFFFFu;
     const float row_err = p.eps_half * qn + p.ab * __builtin_amdgcn_sqrtf(qn) + p.cst;
+    if (p.defer && !(p.prune && end >= (u32)p.k)) return;   // deferred rescoring, fewer than k entries: nothing can be dropped, the threshold stays open
     if (p.prune && end >= (u32)p.k) {
         for (u32 e0 = 0; e0 < end; e0 += 64) {
             const u32 e = e0 + lane;
@@ -77,7 +78,11 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
             }
             if (c >= (u32)p.k) hi = mid; else lo = mid + 1u;
         }
-        const u32 U = lo;
+        U = lo;
+        if (p.defer && over) {                              // the list is full: only the threshold moves (the last chunk's compaction flags the query for repair)
+            if (lane == 0) p.tau[q] = ((u64)U << 32) | 0xFFFFFFFFull;
+            return;
+        }
         __builtin_amdgcn_wave_barrier();
         for (u32 e0 = start; e0 < end; e0 += 64) {
             const u32 e = e0 + lane;
@@ -87,10 +92,35 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
             const u32 pos = nsurv + (u32)__popcll(mk & ((1ull << lane) - 1ull));
             __builtin_amdgcn_wave_barrier();
             if (keep) s_ub[pos] = e;                        // s_ub is free after the bisection: it now holds the packed survivor slots
-            else if (live) list[e] = ~0ull;
+            else if (live && !p.defer) list[e] = ~0ull;
             nsurv += (u32)__popcll(mk);
         }
         __builtin_amdgcn_wave_barrier();
+        if (p.defer) {
+            // Deferred rescoring (every pre-screened chunk but the last of a walk).  Rescoring each chunk's survivors at once costs 4 KiB
+            // of row per pair, ~90 pairs per query and chunk, of which only ~k (1 - 1/(1 + growth)) end up among the k nearest of that
+            // chunk and far fewer at the end of the walk: on small bases that was 11 % of the search, at the Infinity Cache's / HBM's rate.
+            // Here the survivors keep their ESTIMATES: they are packed behind the exact prefix [0, start) as they are, the list is cut to
+            // them, and the threshold of the next chunk becomes U -- an upper bound of the k-th smallest canonical distance among the rows
+            // seen so far (k listed entries lie at or below it), so every pair that can still be among the k nearest passes the tile
+            // kernel's test (conservative for "canonical distance <= threshold") and, its lower bound being <= its distance <= every later
+            // U (they only fall: the k entries that defined one U are kept and bound the next), is kept by every later pruning.  The last
+            // chunk of the walk rescores what is left -- entries of all chunks, estimates every one -- and the compaction orders exact keys
+            // as before: same bits, a third of the rescoring.  No sort is needed in between either (the pruning packs the list).
+            // (slot start + i <= the slot entry i came from, and a round's stores wait for its loads: see the packed write-back below)
+            for (u32 i0 = 0; i0 < nsurv; i0 += 64) {
+                const u32 i = i0 + lane;
+                const bool live = i < nsurv;
+                const u64 key = live ? list[s_ub[i]] : 0ull;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (live) list[start + i] = key;
+            }
+            if (lane == 0) {
+                p.cnt[q] = start + nsurv;
+                p.tau[q] = ((u64)U << 32) | 0xFFFFFFFFull;
+            }
+            return;
+        }
     } else {
         nsurv = end - start;
     }

@@ -154,7 +154,7 @@ struct nwknn_ctx {
     // running top-k state
     DevBuf tau, cnt, buf, ovf, ovf_any, qtiles, out_d, out_i, mrg_d, mrg_i, ctab, chk, calib;
     // options
-    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 0, opt_f16_agg = -1, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_waves = 8, opt_ms_form = 3, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128, opt_pre_check_ppm = 1000000, opt_pre_direct_rows = -1, opt_rescore_coop = 1;
+    long long opt_capacity = 0, opt_first_chunk = 0, opt_max_chunk = 1 << 20, opt_profile = 0, opt_tile_rows = 0, opt_diag = 0, opt_dbg_ptr = 0, opt_compute_f16 = 0, opt_sq_shift = -1, opt_walk_q = -1, opt_prescreen = 0, opt_pre_prune = 1, opt_f16_shape = -1, opt_pre_eps_pct = 100, opt_f16_strip = 0, opt_f16_agg = -1, opt_f16_exact = 1, opt_tile_occ = 3, opt_chunk_growth = 0, opt_upload_threads = NWK_UPLOAD_THREADS, opt_ms_strip = 0, opt_ms_waves = 8, opt_ms_form = 3, opt_ms_rescore_valu = 0, opt_upload_slab_mib = 128, opt_pre_check_ppm = 1000000, opt_pre_direct_rows = -1, opt_rescore_coop = 1, opt_pre_defer = 1;
     int num_cu = 256;
     // profiling
     std::vector<EvPair> ev_pool;
@@ -338,6 +338,8 @@ extern "C" int nwknn_set_option(nwknn_handle h, const char* name, int64_t value)
         h->opt_f16_agg = value;             // which chunks run the row-aggregating build of the streaming fp16 kernel (auto: the loose-threshold ones)
     } else if (!strcmp(name, "rescore_coop")) {
         h->opt_rescore_coop = value ? 1 : 0; // rescoring kernel: 1 (default) a wave fetches the rows of its 64 pairs together through LDS, 0 every lane its own row
+    } else if (!strcmp(name, "pre_defer")) {
+        h->opt_pre_defer = value ? 1 : 0;    // pre-screened walk: 1 (default) only the last chunk rescores, the chunks before it prune on the estimates' bounds (run_chunk); 0 every chunk rescores
     } else if (!strcmp(name, "pre_direct_rows")) {
         if (value < -1) return fail(NWKNN_EINVAL, "pre_direct_rows must be -1 (auto) or a row count >= 0");
         h->opt_pre_direct_rows = value;     // pre-screened search of fp32 data: filtered chunks that START below this many rows run the direct fp32 kernel (run_chunk)
@@ -917,7 +919,7 @@ static NwkCompactParams compact_params(nwknn_ctx* h, const SearchPlan& pl, int k
 
 #define NWK_DEV_BUILD_DIAG(h) (NWK_DEV_BUILD && (h)->opt_diag != 0)
 static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long long nq_pad, long long lo, long long rows, bool dense,
-                     const int* qtile_list, int n_list_tiles, bool dedupe, bool rescan)
+                     const int* qtile_list, int n_list_tiles, bool dedupe, bool rescan, bool last = true)
 {
     NwkTileParams tp = tile_params(h, pl, nq_pad);
     // fp32 data: the dense first chunk runs the fp32 kernel -- and so do the filtered chunks that start below pre_direct_rows.  Right behind the
@@ -998,6 +1000,7 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         else if (f16_shape == 5) snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel_f16y<%d,%d>", metric, prescreen ? 1 : 0);
         else snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_tile_kernel_f16s<%d,false,%d>", metric, prescreen ? 1 : 0);
     }
+    bool deferred = false;
     if (prescreen) {                                       // listed pairs -> canonical fp32 keys, in place
         if (dense) {                                       // (exact fp16 mode) every slot of the dense chunk is a candidate: [0, rows)
             HIPCHK(hipMemsetD32Async((hipDeviceptr_t)h->cnt.p, (int)rows, (size_t)nq_pad, h->stream));
@@ -1012,6 +1015,13 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         // its cap/2 slots carry estimates, and only the ~k of them whose lower bound reaches the k-th smallest upper bound can be among
         // the k nearest: 512 -> ~110 rescored pairs per query, a third of a C4 search's rescoring.)
         rp.prune = (h->opt_pre_prune && !dedupe) ? 1 : 0;
+        // Deferred rescoring (round 5): a chunk that is not the last of its walk only PRUNES -- bounds of the listed estimates, the k-th
+        // smallest upper bound U, entries whose lower bound exceeds it dropped, the rest packed as they are, tau = U -- and neither
+        // rescores nor sorts; the walk's last chunk rescores what is left of all of them (nwk_rescore_kernel, `defer`).  Not for the
+        // dense chunk of exact fp16 mode (it builds the exact prefix the pruning counts on), repair passes, or with pruning off.
+        deferred = rp.prune && h->opt_pre_defer && !last && !dense && !rescan && !qtile_list;
+        rp.defer = deferred ? 1 : 0;
+        rp.tau = h->tau.as<u64>();
         rp.rows16 = pl.native16 ? 1 : 0;
         rp.coop = h->opt_rescore_coop ? 1 : 0;
         rp.eps_half = pl.pre_eps_half; rp.aq = pl.pre_aq; rp.ab = pl.pre_ab; rp.cst = pl.pre_cst;
@@ -1027,6 +1037,7 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         h->stats.tile_flops += 2.0 * q_rows * (double)real_rows * (double)h->d;
     }
 
+    if (deferred) return NWKNN_OK;                          // the pruning pass packed the list and set the threshold: nothing to sort
     NwkCompactParams cp = compact_params(h, pl, k);
     cp.dense_count = (dense && !prescreen) ? (int)rows : 0;      // (a rescored dense chunk -- exact fp16 mode -- has its length in cnt: rows, or what the rescoring kernel kept)
     cp.dedupe = dedupe ? 1 : 0;
@@ -1278,6 +1289,9 @@ static int search_attempt(nwknn_ctx* h, const void* queries, const ColumnSource*
     // quadruple -- fewer launches, -1.6 % on a 1.25M-row shard, +3 % on C2 pre-screened, nothing on C3; k >= 200 at capacity 1024: 1).
     long long growth = h->opt_chunk_growth;
     if (growth <= 0) growth = std::max<long long>(1, std::min<long long>(3, (long long)((0.8 * pl.cap / k - 1.0) / 1.5)));
+    // (deferred rescoring keeps ~0.4 k estimates beside the k exact entries between chunks and its threshold admits ~1.15 x as many)
+    if (h->opt_chunk_growth <= 0 && pl.pre && h->opt_pre_defer && h->opt_pre_prune)
+        growth = std::max<long long>(1, std::min<long long>(3, (long long)((0.8 * pl.cap / k - 1.4) / 1.6)));
     long long seen = std::min(h->nb_pad, pl.first);
     h->walk_auto_q = 0; h->walk_auto_sq = 3;
     RCCHK(run_chunk(h, pl, metric, k, nq_pad, 0, seen, true, nullptr, 0, false, false));
@@ -1310,7 +1324,7 @@ static int search_attempt(nwknn_ctx* h, const void* queries, const ColumnSource*
             seen += 2 * m;
             continue;
         }
-        RCCHK(run_chunk(h, pl, metric, k, nq_pad, seen, m, false, nullptr, 0, false, false));
+        RCCHK(run_chunk(h, pl, metric, k, nq_pad, seen, m, false, nullptr, 0, false, false, seen + m >= h->nb_pad));
         seen += m;
     }
     h->walk_auto_q = 0; h->walk_auto_sq = 3;                       // repairs and later searches start from the default again

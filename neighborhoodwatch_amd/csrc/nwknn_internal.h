@@ -68,6 +68,8 @@ struct NwkRescoreParams {
     int rows16;                    // 1: qp / bp hold fp16 rows in natural k order (exact fp16 mode); 0: prepared fp32 rows
     int prune;                     // 1: derive bounds from the fp16 estimates and skip pairs that cannot reach the top k
     int coop;                      // 1: the wave fetches the 64 rows of a round together through LDS (nwk_select.hip); 0: a lane fetches its own row
+    int defer;                     // 1: prune only -- survivors keep their estimates, the list is cut to them, tau becomes the k-th smallest upper bound (needs prune = 1; nwk_select.hip)
+    unsigned long long* tau;       // thresholds (written when defer = 1)
     float eps_half, aq, ab, cst;   // the constants of the pre-screen error bound (as in NwkTileParams)
     float chk_scale;               // the invariant |estimate - exact| <= bound is checked against chk_scale x the bound (1: the bound itself; option "pre_check_ppm")
     unsigned long long* chk;       // [0] += pairs checked, [1] += pairs outside the bound, [2] (low word) max= float bits of the worst |estimate - exact| / bound

@@ -359,6 +359,47 @@ def test_the_invariant_is_counted_on_every_rescored_pair(pre_engine, oracle):
         assert 0.0 < st["prescreen_worst"] < 0.9, (metric, st["prescreen_worst"])
 
 
+@pytest.mark.parametrize("metric", ADDITIVE)
+def test_deferred_rescoring_gives_the_bits_of_rescoring_every_chunk(pre_engine, oracle, metric):
+    """Option "pre_defer" (default 1): only the LAST chunk of a pre-screened walk rescores; the chunks before it keep the estimates, prune on
+    their bounds and filter the next chunk with the k-th smallest upper bound.  Same bits as rescoring after every chunk (and as the oracle),
+    far fewer rescored pairs, no compaction between the pre-screened chunks."""
+    base, queries = oracle.gen(0x93, 0, 200000, 128), oracle.gen(0x94, 0, 600, 128)
+    pre_engine.set_base(base)
+    rd, ri = oracle.knn_canonical(base, queries, 100, metric)
+    seen = {}
+    for defer in (0, 1):
+        pre_engine.set_option("pre_defer", defer)
+        dist, idx = pre_engine.search(queries, 100, metric)
+        st = pre_engine.stats()
+        assert st["prescreen"] == 1 and st["prescreen_violations"] == 0 and st["overflowed_queries"] == 0
+        assert np.array_equal(idx, ri) and _bitwise(dist, rd), (metric, defer)
+        seen[defer] = st
+    assert seen[1]["tile_launches"] == seen[0]["tile_launches"]                          # the same walk ...
+    assert seen[1]["compact_launches"] < seen[0]["compact_launches"]                     # ... without the sorts in between ...
+    assert 600 * 90 < seen[1]["prescreen_checked"] < 0.7 * seen[0]["prescreen_checked"]  # ... and a fraction of the rescoring
+
+
+def test_deferred_rescoring_with_many_candidates_inside_the_bound(oracle):
+    """Rows the fp16 estimates cannot tell apart pile up between the chunks of a deferred walk (nothing is rescored until the end): lists
+    overflow earlier than they would with per-chunk rescoring and are repaired; the result is the canonical one either way."""
+    from neighborhoodwatch_amd import KnnEngine
+    rng = np.random.default_rng(23)
+    centre = rng.standard_normal(96).astype(np.float32)
+    base = (centre[None, :] + 3e-4 * rng.standard_normal((30000, 96))).astype(np.float32)
+    base[::7] = rng.standard_normal((len(base[::7]), 96)).astype(np.float32)             # and rows far away in between
+    queries = (centre[None, :] + 3e-4 * rng.standard_normal((60, 96))).astype(np.float32)
+    rd, ri = oracle.knn_canonical(base, queries, 50, "sqeuclidean")
+    with KnnEngine(0) as eng:
+        eng.set_prescreen(True)
+        eng.set_base(base)
+        for defer in (1, 0):
+            eng.set_option("pre_defer", defer)
+            dist, idx = eng.search(queries, 50, "sqeuclidean")
+            assert eng.stats()["prescreen"] == 1
+            assert np.array_equal(idx, ri) and _bitwise(dist, rd), defer
+
+
 @pytest.mark.drives_fallback
 @pytest.mark.parametrize("metric", ADDITIVE)
 def test_a_failed_invariant_sends_the_search_to_the_direct_kernel_same_bits(oracle, metric, capfd):
