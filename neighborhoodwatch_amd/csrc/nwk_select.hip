@@ -69,19 +69,49 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
         }
         __builtin_amdgcn_wave_barrier();
         u32 lo = 0u, hi = 0xFFFFFFFFu;
-        while (lo < hi) {                                   // smallest x with  #{ub <= x} >= k   (wave-uniform)
-            const u32 mid = lo + ((hi - lo) >> 1);
-            u32 c = 0;
-            for (u32 e0 = 0; e0 < end; e0 += 64) {
-                const u32 e = e0 + lane;
-                c += (u32)__popcll(__ballot(e < end && s_ub[e] <= mid));
+        if (p.cap <= 1024) {
+            // lists of up to 1024 entries: a lane keeps its (at most) sixteen upper bounds in registers, so a bisection step is sixteen
+            // compares and scalar bit counts with no LDS round trip in it -- the 32 steps x 9 rounds of ds_read + wait were most of a
+            // pruning pass, which the deferred walk runs once per chunk (slots past `end` hold the largest value: mid never reaches it)
+            u32 r[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const u32 e = (u32)(j * 64 + lane);
+                r[j] = e < end ? s_ub[e] : 0xFFFFFFFFu;
             }
-            if (c >= (u32)p.k) hi = mid; else lo = mid + 1u;
+            while (lo < hi) {                               // smallest x with  #{ub <= x} >= k   (wave-uniform)
+                const u32 mid = lo + ((hi - lo) >> 1);
+                u32 c = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) c += (u32)__popcll(__ballot(r[j] <= mid));
+                if (c >= (u32)p.k) hi = mid; else lo = mid + 1u;
+            }
+        } else {
+            while (lo < hi) {
+                const u32 mid = lo + ((hi - lo) >> 1);
+                u32 c = 0;
+                for (u32 e0 = 0; e0 < end; e0 += 64) {
+                    const u32 e = e0 + lane;
+                    c += (u32)__popcll(__ballot(e < end && s_ub[e] <= mid));
+                }
+                if (c >= (u32)p.k) hi = mid; else lo = mid + 1u;
+            }
         }
         U = lo;
         if (p.defer && over) {                              // the list is full: only the threshold moves (the last chunk's compaction flags the query for repair)
             if (lane == 0) p.tau[q] = ((u64)U << 32) | 0xFFFFFFFFull;
             return;
+        }
+        // (deferred) the exact prefix is sorted: its entries at or below U are a leading run, the others can no longer be among the k nearest
+        // (exact value > U >= the k-th smallest distance) and are dropped with the estimates that cannot -- otherwise the prefix turns into
+        // dead weight as the walk displaces its members, and the list fills up with k entries nobody needs
+        u32 nstart = start;
+        if (p.defer) {
+            nstart = 0;
+            for (u32 e0 = 0; e0 < start; e0 += 64) {
+                const u32 e = e0 + lane;
+                nstart += (u32)__popcll(__ballot(e < start && s_ub[e] <= U));
+            }
         }
         __builtin_amdgcn_wave_barrier();
         for (u32 e0 = start; e0 < end; e0 += 64) {
@@ -107,16 +137,17 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
             // U (they only fall: the k entries that defined one U are kept and bound the next), is kept by every later pruning.  The last
             // chunk of the walk rescores what is left -- entries of all chunks, estimates every one -- and the compaction orders exact keys
             // as before: same bits, a third of the rescoring.  No sort is needed in between either (the pruning packs the list).
-            // (slot start + i <= the slot entry i came from, and a round's stores wait for its loads: see the packed write-back below)
+            // (slot nstart + i <= start + i <= the slot entry i came from, and a round's stores wait for its loads: see the packed write-back below)
             for (u32 i0 = 0; i0 < nsurv; i0 += 64) {
                 const u32 i = i0 + lane;
                 const bool live = i < nsurv;
                 const u64 key = live ? list[s_ub[i]] : 0ull;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (live) list[start + i] = key;
+                if (live) list[nstart + i] = key;
             }
             if (lane == 0) {
-                p.cnt[q] = start + nsurv;
+                p.cnt0_w[q] = nstart;
+                p.cnt[q] = nstart + nsurv;                  // >= k: the k entries that define U are all kept
                 p.tau[q] = ((u64)U << 32) | 0xFFFFFFFFull;
             }
             return;
@@ -330,7 +361,9 @@ __global__ __launch_bounds__(256) void nwk_compact_kernel(const NwkCompactParams
     const bool overflow = n > (u32)p.cap;
     if (overflow) n = p.cap;
     // nothing appended since the last compaction: the list is already the sorted top-k
-    if (!overflow && !p.dedupe && p.dense_count == 0 && n <= (u32)p.k && p.tau[q] != ~0ull) return;
+    // (pre-screened walks: ... and nothing behind the sorted exact prefix -- a deferred pruning pass can leave exactly k entries, some of them
+    // rescored a moment ago and in no order)
+    if (!overflow && !p.dedupe && p.dense_count == 0 && n <= (u32)p.k && p.tau[q] != ~0ull && (!p.cnt0 || p.cnt0[q] >= n)) return;
 
     u32 np2 = 2;
     while (np2 < n) np2 <<= 1;

@@ -1021,7 +1021,7 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         // dense chunk of exact fp16 mode (it builds the exact prefix the pruning counts on), repair passes, or with pruning off.
         deferred = rp.prune && h->opt_pre_defer && !last && !dense && !rescan && !qtile_list;
         rp.defer = deferred ? 1 : 0;
-        rp.tau = h->tau.as<u64>();
+        rp.tau = h->tau.as<u64>(); rp.cnt0_w = h->cnt0.as<u32>();
         rp.rows16 = pl.native16 ? 1 : 0;
         rp.coop = h->opt_rescore_coop ? 1 : 0;
         rp.eps_half = pl.pre_eps_half; rp.aq = pl.pre_aq; rp.ab = pl.pre_ab; rp.cst = pl.pre_cst;
@@ -1567,7 +1567,7 @@ extern "C" int nwknn_maxsim_set_docs(nwknn_handle h, const void* doc_tokens, int
 }
 
 static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq_pad, long long doc_lo, long long docs, bool dense, bool dedupe,
-                        bool pre)
+                        bool pre, bool last = true)
 {
     NwkTileParams tp;
     memset(&tp, 0, sizeof tp);
@@ -1600,6 +1600,7 @@ static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq
         if (!dense) snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_maxsim_kernel<false>");
     }
     ev_end(h, e);
+    bool deferred = false;
     if (prescreen) {
         NwkMsRescoreParams rp;
         rp.qp = h->qp.as<float>(); rp.bp = h->bp.as<float>(); rp.buf = h->buf.as<u64>(); rp.cnt = h->cnt.as<u32>(); rp.cnt0 = h->cnt0.as<u32>();
@@ -1608,6 +1609,9 @@ static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq
         rp.dbg = h->opt_dbg_ptr ? (unsigned long long*)(uintptr_t)h->opt_dbg_ptr : nullptr;
         rp.surv = h->ms_surv.as<u32>(); rp.nsurv = h->ms_nsurv.as<u32>(); rp.rescore_valu = (int)h->opt_ms_rescore_valu;
         rp.chk_scale = (float)((double)h->opt_pre_check_ppm * 1e-6); rp.chk = h->chk.as<u64>();
+        // deferred rescoring (see run_chunk): a chunk that is not the last of its walk prunes on the estimates' bounds and neither rescores nor sorts
+        deferred = rp.prune && h->opt_pre_defer && !last;
+        rp.defer = deferred ? 1 : 0; rp.cnt_w = h->cnt.as<u32>(); rp.cnt0_w = h->cnt0.as<u32>(); rp.tau = h->tau.as<u64>();
         // enough (query, slice) waves to fill the chip a few times over
         const int slices = (int)std::max<long long>(1, std::min<long long>(32, (8ll * h->num_cu * 4 + nq_pad - 1) / nq_pad));
         e = ev_begin(h, 3);
@@ -1617,6 +1621,7 @@ static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq
     h->stats.tile_launches += 1;
     const long long real_docs = std::max<long long>(0, std::min<long long>(doc_lo + docs, h->ms_docs) - doc_lo);
     h->stats.tile_flops += 2.0 * (double)nq * NWK_MS_TOKENS_PER_QUERY * (double)real_docs * NWK_MS_TOKENS_PER_DOC * (double)h->d;
+    if (deferred) return NWKNN_OK;
     NwkCompactParams cp;
     memset(&cp, 0, sizeof cp);
     cp.buf = h->buf.as<u64>(); cp.cnt = h->cnt.as<u32>(); cp.tau = h->tau.as<u64>(); cp.ovf = h->ovf.as<u32>(); cp.ovf_any = h->ovf_any.as<u32>();
@@ -1714,7 +1719,7 @@ static int maxsim_search_attempt(nwknn_handle h, const void* query_tokens, int64
     RCCHK(maxsim_chunk(h, (int)cap, k, nq, nq_pad, 0, seen, true, false, pre));
     while (seen < docs_pad) {
         const long long m = std::min(std::min(max_chunk, seen), docs_pad - seen);
-        RCCHK(maxsim_chunk(h, (int)cap, k, nq, nq_pad, seen, m, false, false, pre));
+        RCCHK(maxsim_chunk(h, (int)cap, k, nq, nq_pad, seen, m, false, false, pre, seen + m >= docs_pad));
         seen += m;
     }
     u32 any = 0;

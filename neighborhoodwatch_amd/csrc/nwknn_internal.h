@@ -70,6 +70,7 @@ struct NwkRescoreParams {
     int coop;                      // 1: the wave fetches the 64 rows of a round together through LDS (nwk_select.hip); 0: a lane fetches its own row
     int defer;                     // 1: prune only -- survivors keep their estimates, the list is cut to them, tau becomes the k-th smallest upper bound (needs prune = 1; nwk_select.hip)
     unsigned long long* tau;       // thresholds (written when defer = 1)
+    unsigned int* cnt0_w;          // == cnt0, writable: a deferred pass also drops the exact entries above the bound (defer = 1)
     float eps_half, aq, ab, cst;   // the constants of the pre-screen error bound (as in NwkTileParams)
     float chk_scale;               // the invariant |estimate - exact| <= bound is checked against chk_scale x the bound (1: the bound itself; option "pre_check_ppm")
     unsigned long long* chk;       // [0] += pairs checked, [1] += pairs outside the bound, [2] (low word) max= float bits of the worst |estimate - exact| / bound
@@ -91,6 +92,10 @@ struct NwkMsRescoreParams {
     int rescore_valu;              // 1: the vector-pipe rescoring kernel even where the MFMA one applies (option "ms_rescore_valu")
     float chk_scale;               // the invariant |estimate - exact score| <= R(query) + C(doc), checked as for kNN (NwkRescoreParams::chk)
     unsigned long long* chk;
+    int defer;                     // 1: the prune kernel only -- survivors keep their estimates, packed behind the exact prefix; the list is cut to them, tau = k-th smallest upper bound (NwkRescoreParams::defer)
+    unsigned int* cnt_w;           // == cnt, writable (defer)
+    unsigned int* cnt0_w;          // == cnt0, writable (defer)
+    unsigned long long* tau;       // thresholds (defer)
 };
 
 struct NwkCompactParams {
