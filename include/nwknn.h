@@ -127,7 +127,9 @@ int nwknn_set_stream(nwknn_handle h, void* hip_stream);
  * segments through LDS, or every lane its own row; same bits),
  * "pre_defer" (1 default | 0: in a pre-screened walk only the LAST chunk rescores listed pairs with the canonical chain; the chunks before it
  * keep the fp16 estimates, drop entries whose lower bound exceeds the k-th smallest upper bound and filter the next chunk with that bound --
- * a third of the rescoring traffic, no sort between chunks; 0 = every chunk rescores and sorts, as before round 5; same bits either way),
+ * a third of the rescoring traffic; a query whose pruned list grows past a limit sized from the list capacity -- candidates the bound cannot
+ * tell apart -- is rescored and sorted in that chunk after all, so nothing piles up until a list overflows; kNN searches only (MaxSim's
+ * bound is too loose for it); 0 = every chunk rescores and sorts, as before round 5; same bits either way),
  * "pre_direct_rows" (-1 auto | rows: in a pre-screened search of fp32 data the filtered chunks that start below this many base rows run the
  * direct fp32 kernel -- right behind the dense chunk a quarter of all pairs pass the loose threshold, and rescoring them one by one costs more
  * than computing the exact keys on the MFMA; auto = only the chunk that follows the dense one; same bits whatever the value),

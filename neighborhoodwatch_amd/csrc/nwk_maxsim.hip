@@ -767,13 +767,11 @@ __global__ __launch_bounds__(256) void nwk_maxsim_prune_kernel(const NwkMsRescor
     u32* s_lb = s_ub + p.cap;
     const u32 start = p.cnt0[q];
     u32 end = p.cnt[q];
-    const bool over = end > (u32)p.cap;
-    if (over) end = (u32)p.cap;
+    if (end > (u32)p.cap) end = (u32)p.cap;
     u32* surv = p.surv + q * p.cap;
     if (start >= end) { if (lane == 0) p.nsurv[q] = 0; return; }
     u64* list = p.buf + q * p.cap;
     u32 nsurv = 0;
-    if (p.defer && !(p.prune && end >= (u32)p.k)) { if (lane == 0) p.nsurv[q] = 0; return; }   // deferred, fewer than k entries: nothing to drop, the threshold stays open
     if (p.prune && end >= (u32)p.k) {
         const float rq = p.rq[q];
         for (u32 e0 = 0; e0 < end; e0 += 64) {
@@ -801,42 +799,6 @@ __global__ __launch_bounds__(256) void nwk_maxsim_prune_kernel(const NwkMsRescor
             if (c >= (u32)p.k) hi = mid; else lo = mid + 1u;
         }
         const u32 U = lo;
-        if (p.defer) {
-            // Deferred rescoring, as in nwk_rescore_kernel (nwk_select.hip): every chunk of a walk but the last keeps the estimates of the pairs
-            // that can still reach the top k, packed behind the exact prefix, and hands U -- the k-th smallest upper bound, i.e. an upper
-            // bound of the k-th best canonical -score among the documents seen -- to the next chunk as its threshold.  No rescoring, no sort.
-            u32 nstart = 0;                                     // the sorted exact prefix keeps its leading run at or below U (see nwk_rescore_kernel)
-            if (!over) {
-                for (u32 e0 = 0; e0 < start; e0 += 64) {
-                    const u32 e = e0 + lane;
-                    nstart += (u32)__popcll(__ballot(e < start && s_ub[e] <= U));
-                }
-                __builtin_amdgcn_wave_barrier();
-                for (u32 e0 = start; e0 < end; e0 += 64) {
-                    const u32 e = e0 + lane;
-                    const bool keep = e < end && s_lb[e] <= U;
-                    const u64 mk = __ballot(keep);
-                    const u32 pos = nsurv + (u32)__popcll(mk & ((1ull << lane) - 1ull));
-                    __builtin_amdgcn_wave_barrier();
-                    if (keep) s_ub[pos] = e;                    // s_ub is free after the bisection: the packed survivor slots
-                    nsurv += (u32)__popcll(mk);
-                }
-                __builtin_amdgcn_wave_barrier();
-                for (u32 i0 = 0; i0 < nsurv; i0 += 64) {       // slot nstart + i <= start + i <= the slot entry i came from; a round's stores wait for its loads
-                    const u32 i = i0 + lane;
-                    const bool live = i < nsurv;
-                    const u64 key = live ? list[s_ub[i]] : 0ull;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (live) list[nstart + i] = key;
-                }
-            }
-            if (lane == 0) {
-                if (!over) { p.cnt0_w[q] = nstart; p.cnt_w[q] = nstart + nsurv; }   // (a full list keeps its length: the last chunk's compaction flags the query for repair)
-                p.tau[q] = ((u64)U << 32) | 0xFFFFFFFFull;
-                p.nsurv[q] = 0;
-            }
-            return;
-        }
         for (u32 e0 = start; e0 < end; e0 += 64) {
             const u32 e = e0 + lane;
             const bool live = e < end;
@@ -1120,7 +1082,6 @@ hipError_t nwk_launch_maxsim_rescore(hipStream_t st, NwkMsRescoreParams p, long 
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    if (p.defer) return hipSuccess;                                          // the pruning pass was all there is to do for this chunk
     // (2) rescore.  On the matrix pipes when the query's padded token rows fit LDS comfortably (d <= 256): workgroups of four
     //     waves per (query, slice)
     const size_t mfma_lds = (size_t)NWK_MS_TOKENS_PER_QUERY * ((size_t)p.dp * 4 + 16);

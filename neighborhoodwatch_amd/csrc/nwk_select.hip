@@ -44,7 +44,10 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
 
     u32 nsurv = 0, U = 0xFFFFFFFFu;
     const float row_err = p.eps_half * qn + p.ab * __builtin_amdgcn_sqrtf(qn) + p.cst;
-    if (p.defer && !(p.prune && end >= (u32)p.k)) return;   // deferred rescoring, fewer than k entries: nothing can be dropped, the threshold stays open
+    if (p.defer && !(p.prune && end >= (u32)p.k)) {         // deferred rescoring, fewer than k entries: nothing can be dropped, the threshold stays open
+        if (lane == 0) p.skip[q] = 1u;
+        return;
+    }
     if (p.prune && end >= (u32)p.k) {
         for (u32 e0 = 0; e0 < end; e0 += 64) {
             const u32 e = e0 + lane;
@@ -98,10 +101,6 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
             }
         }
         U = lo;
-        if (p.defer && over) {                              // the list is full: only the threshold moves (the last chunk's compaction flags the query for repair)
-            if (lane == 0) p.tau[q] = ((u64)U << 32) | 0xFFFFFFFFull;
-            return;
-        }
         // (deferred) the exact prefix is sorted: its entries at or below U are a leading run, the others can no longer be among the k nearest
         // (exact value > U >= the k-th smallest distance) and are dropped with the estimates that cannot -- otherwise the prefix turns into
         // dead weight as the walk displaces its members, and the list fills up with k entries nobody needs
@@ -122,11 +121,18 @@ __global__ __launch_bounds__(256) void nwk_rescore_kernel(const NwkRescoreParams
             const u32 pos = nsurv + (u32)__popcll(mk & ((1ull << lane) - 1ull));
             __builtin_amdgcn_wave_barrier();
             if (keep) s_ub[pos] = e;                        // s_ub is free after the bisection: it now holds the packed survivor slots
-            else if (live && !p.defer) list[e] = ~0ull;
+            else if (live && (!p.defer || over)) list[e] = ~0ull;
             nsurv += (u32)__popcll(mk);
         }
         __builtin_amdgcn_wave_barrier();
-        if (p.defer) {
+        // A deferred pass leaves a query alone only while its pruned list stays short.  Where the bound cannot tell many candidates apart
+        // (near-duplicates, scores closer than the fp16 error: MaxSim's 32-term bound is such a case and keeps per-chunk rescoring) the
+        // estimates would pile up until the list overflows and the query goes through overflow repair -- a re-walk of the whole base.
+        // Such a query -- and one whose list is full already -- is rescored NOW, as before round 5: skip[q] = 0 sends it through the
+        // compaction that follows every chunk (the others return from it at once), which sorts its exact keys and resets its list to k.
+        const bool stay = p.defer && !over && nstart + nsurv <= (u32)p.defer_limit;
+        if (p.defer && lane == 0) p.skip[q] = stay ? 1u : 0u;
+        if (stay) {
             // Deferred rescoring (every pre-screened chunk but the last of a walk).  Rescoring each chunk's survivors at once costs 4 KiB
             // of row per pair, ~90 pairs per query and chunk, of which only ~k (1 - 1/(1 + growth)) end up among the k nearest of that
             // chunk and far fewer at the end of the walk: on small bases that was 11 % of the search, at the Infinity Cache's / HBM's rate.
@@ -357,6 +363,7 @@ __global__ __launch_bounds__(256) void nwk_compact_kernel(const NwkCompactParams
     if (p.qtile_list) q = (long long)p.qtile_list[blockIdx.x / p.qtile_rows] * p.qtile_rows + (blockIdx.x % p.qtile_rows);
     else q = blockIdx.x;
 
+    if (p.skip && p.skip[q]) return;                      // deferred rescoring: estimates behind the prefix, pruned and packed by nwk_rescore_kernel
     u32 n = p.dense_count > 0 ? (u32)p.dense_count : p.cnt[q];
     const bool overflow = n > (u32)p.cap;
     if (overflow) n = p.cap;

@@ -123,6 +123,7 @@ struct nwknn_ctx {
     size_t pin_bytes = 0;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_prepped[2] = {nullptr, nullptr};
     hipEvent_t ev_cal[3] = {nullptr, nullptr, nullptr};      // walk calibration of the direct fp32 kernel (search_attempt)
+    long long walk_growth = 3;                               // chunk growth of the current walk (the deferred pass sizes its per-query limit by it)
     int walk_auto_q = 0, walk_auto_sq = 3;                   // what "auto" means for the fp32 kernel's super-tile walk in the current search
     FollowState fw;
     hipStream_t fw_stream = nullptr;                         // the attached search's chunks run here, beside the layout kernels of later pieces
@@ -141,7 +142,7 @@ struct nwknn_ctx {
     // query side
     DevBuf qraw, qp, qn;
     // fp16 pre-screen of the exact fp32 search (option "prescreen"): scaled fp16 copies of bp / qp
-    DevBuf bp16, qp16, cnt0, scal, ms_rq, ms_cd, ms_surv, ms_nsurv;
+    DevBuf bp16, qp16, cnt0, scal, ms_rq, ms_cd, ms_surv, ms_nsurv, dskip;
     int ms_pre = 0;                 // MaxSim: the documents have a usable fp16 copy (option "prescreen" at nwknn_maxsim_set_docs)
     float ms_eps_half = 0.f, ms_aq = 0.f, ms_ab = 0.f, ms_cst = 0.f, ms_scale = 1.f;   // constants of the current MaxSim search
     int pre_ok = 0;                 // the current base can be pre-screened (finite, sane magnitudes); bp16 holds a copy of kind pre_kind
@@ -281,7 +282,7 @@ extern "C" int nwknn_destroy(nwknn_handle h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->bp, &h->bn, &h->braw, &h->qraw, &h->qp, &h->qn, &h->tau, &h->cnt, &h->buf, &h->ovf, &h->ovf_any, &h->qtiles,
-                      &h->out_d, &h->out_i, &h->mrg_d, &h->mrg_i, &h->ctab, &h->chk, &h->calib, &h->bp16, &h->qp16, &h->cnt0, &h->scal, &h->ms_rq, &h->ms_cd, &h->ms_surv, &h->ms_nsurv})
+                      &h->out_d, &h->out_i, &h->mrg_d, &h->mrg_i, &h->ctab, &h->chk, &h->calib, &h->bp16, &h->qp16, &h->cnt0, &h->scal, &h->ms_rq, &h->ms_cd, &h->ms_surv, &h->ms_nsurv, &h->dskip})
         b->release();
     for (EvPair& e : h->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (int i = 0; i < 2; ++i) {
@@ -1022,6 +1023,14 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         deferred = rp.prune && h->opt_pre_defer && !last && !dense && !rescan && !qtile_list;
         rp.defer = deferred ? 1 : 0;
         rp.tau = h->tau.as<u64>(); rp.cnt0_w = h->cnt0.as<u32>();
+        rp.skip = nullptr; rp.defer_limit = 0;
+        if (deferred) {
+            // a query is left in the deferred state only while the next chunk's candidates (~1.6 k per unit of growth, the spread on top) still
+            // fit behind what it keeps; otherwise it is rescored and sorted now (nwk_rescore_kernel, `stay`)
+            RCCHK(h->dskip.ensure((size_t)nq_pad * 4));
+            rp.skip = h->dskip.as<u32>();
+            rp.defer_limit = (int)std::max<long long>(0, pl.cap - (long long)(1.8 * (double)h->walk_growth * k) - 32);
+        }
         rp.rows16 = pl.native16 ? 1 : 0;
         rp.coop = h->opt_rescore_coop ? 1 : 0;
         rp.eps_half = pl.pre_eps_half; rp.aq = pl.pre_aq; rp.ab = pl.pre_ab; rp.cst = pl.pre_cst;
@@ -1037,8 +1046,8 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         h->stats.tile_flops += 2.0 * q_rows * (double)real_rows * (double)h->d;
     }
 
-    if (deferred) return NWKNN_OK;                          // the pruning pass packed the list and set the threshold: nothing to sort
     NwkCompactParams cp = compact_params(h, pl, k);
+    if (deferred) cp.skip = h->dskip.as<u32>();           // the pruning pass packed the lists and set the thresholds: only queries it rescored after all are sorted
     cp.dense_count = (dense && !prescreen) ? (int)rows : 0;      // (a rescored dense chunk -- exact fp16 mode -- has its length in cnt: rows, or what the rescoring kernel kept)
     cp.dedupe = dedupe ? 1 : 0;
     cp.qtile_list = qtile_list;
@@ -1292,6 +1301,7 @@ static int search_attempt(nwknn_ctx* h, const void* queries, const ColumnSource*
     // (deferred rescoring keeps ~0.4 k estimates beside the k exact entries between chunks and its threshold admits ~1.15 x as many)
     if (h->opt_chunk_growth <= 0 && pl.pre && h->opt_pre_defer && h->opt_pre_prune)
         growth = std::max<long long>(1, std::min<long long>(3, (long long)((0.8 * pl.cap / k - 1.4) / 1.6)));
+    h->walk_growth = growth;
     long long seen = std::min(h->nb_pad, pl.first);
     h->walk_auto_q = 0; h->walk_auto_sq = 3;
     RCCHK(run_chunk(h, pl, metric, k, nq_pad, 0, seen, true, nullptr, 0, false, false));
@@ -1567,7 +1577,7 @@ extern "C" int nwknn_maxsim_set_docs(nwknn_handle h, const void* doc_tokens, int
 }
 
 static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq_pad, long long doc_lo, long long docs, bool dense, bool dedupe,
-                        bool pre, bool last = true)
+                        bool pre)
 {
     NwkTileParams tp;
     memset(&tp, 0, sizeof tp);
@@ -1600,7 +1610,6 @@ static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq
         if (!dense) snprintf(h->tile_kernel, sizeof h->tile_kernel, "nwk_maxsim_kernel<false>");
     }
     ev_end(h, e);
-    bool deferred = false;
     if (prescreen) {
         NwkMsRescoreParams rp;
         rp.qp = h->qp.as<float>(); rp.bp = h->bp.as<float>(); rp.buf = h->buf.as<u64>(); rp.cnt = h->cnt.as<u32>(); rp.cnt0 = h->cnt0.as<u32>();
@@ -1609,9 +1618,6 @@ static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq
         rp.dbg = h->opt_dbg_ptr ? (unsigned long long*)(uintptr_t)h->opt_dbg_ptr : nullptr;
         rp.surv = h->ms_surv.as<u32>(); rp.nsurv = h->ms_nsurv.as<u32>(); rp.rescore_valu = (int)h->opt_ms_rescore_valu;
         rp.chk_scale = (float)((double)h->opt_pre_check_ppm * 1e-6); rp.chk = h->chk.as<u64>();
-        // deferred rescoring (see run_chunk): a chunk that is not the last of its walk prunes on the estimates' bounds and neither rescores nor sorts
-        deferred = rp.prune && h->opt_pre_defer && !last;
-        rp.defer = deferred ? 1 : 0; rp.cnt_w = h->cnt.as<u32>(); rp.cnt0_w = h->cnt0.as<u32>(); rp.tau = h->tau.as<u64>();
         // enough (query, slice) waves to fill the chip a few times over
         const int slices = (int)std::max<long long>(1, std::min<long long>(32, (8ll * h->num_cu * 4 + nq_pad - 1) / nq_pad));
         e = ev_begin(h, 3);
@@ -1621,7 +1627,6 @@ static int maxsim_chunk(nwknn_ctx* h, int cap, int k, long long nq, long long nq
     h->stats.tile_launches += 1;
     const long long real_docs = std::max<long long>(0, std::min<long long>(doc_lo + docs, h->ms_docs) - doc_lo);
     h->stats.tile_flops += 2.0 * (double)nq * NWK_MS_TOKENS_PER_QUERY * (double)real_docs * NWK_MS_TOKENS_PER_DOC * (double)h->d;
-    if (deferred) return NWKNN_OK;
     NwkCompactParams cp;
     memset(&cp, 0, sizeof cp);
     cp.buf = h->buf.as<u64>(); cp.cnt = h->cnt.as<u32>(); cp.tau = h->tau.as<u64>(); cp.ovf = h->ovf.as<u32>(); cp.ovf_any = h->ovf_any.as<u32>();
@@ -1719,7 +1724,7 @@ static int maxsim_search_attempt(nwknn_handle h, const void* query_tokens, int64
     RCCHK(maxsim_chunk(h, (int)cap, k, nq, nq_pad, 0, seen, true, false, pre));
     while (seen < docs_pad) {
         const long long m = std::min(std::min(max_chunk, seen), docs_pad - seen);
-        RCCHK(maxsim_chunk(h, (int)cap, k, nq, nq_pad, seen, m, false, false, pre, seen + m >= docs_pad));
+        RCCHK(maxsim_chunk(h, (int)cap, k, nq, nq_pad, seen, m, false, false, pre));
         seen += m;
     }
     u32 any = 0;

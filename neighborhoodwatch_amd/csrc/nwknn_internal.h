@@ -71,6 +71,9 @@ struct NwkRescoreParams {
     int defer;                     // 1: prune only -- survivors keep their estimates, the list is cut to them, tau becomes the k-th smallest upper bound (needs prune = 1; nwk_select.hip)
     unsigned long long* tau;       // thresholds (written when defer = 1)
     unsigned int* cnt0_w;          // == cnt0, writable: a deferred pass also drops the exact entries above the bound (defer = 1)
+    unsigned int* skip;            // [nq_pad], written when defer = 1: 1 = this query's list is in the deferred state (estimates behind the prefix: the compaction
+                                   // that follows must leave it alone), 0 = the query was rescored in this launch after all (see defer_limit) and is to be sorted
+    int defer_limit;               // a query whose pruned list would hold more entries than this is rescored now: candidates the bound cannot tell apart must not pile up until the list overflows
     float eps_half, aq, ab, cst;   // the constants of the pre-screen error bound (as in NwkTileParams)
     float chk_scale;               // the invariant |estimate - exact| <= bound is checked against chk_scale x the bound (1: the bound itself; option "pre_check_ppm")
     unsigned long long* chk;       // [0] += pairs checked, [1] += pairs outside the bound, [2] (low word) max= float bits of the worst |estimate - exact| / bound
@@ -92,10 +95,6 @@ struct NwkMsRescoreParams {
     int rescore_valu;              // 1: the vector-pipe rescoring kernel even where the MFMA one applies (option "ms_rescore_valu")
     float chk_scale;               // the invariant |estimate - exact score| <= R(query) + C(doc), checked as for kNN (NwkRescoreParams::chk)
     unsigned long long* chk;
-    int defer;                     // 1: the prune kernel only -- survivors keep their estimates, packed behind the exact prefix; the list is cut to them, tau = k-th smallest upper bound (NwkRescoreParams::defer)
-    unsigned int* cnt_w;           // == cnt, writable (defer)
-    unsigned int* cnt0_w;          // == cnt0, writable (defer)
-    unsigned long long* tau;       // thresholds (defer)
 };
 
 struct NwkCompactParams {
@@ -111,6 +110,7 @@ struct NwkCompactParams {
     int qtile_rows;                // rows per entry of qtile_list (128 or 256)
     int dense_count;               // > 0: every list holds exactly this many entries (first chunk)
     int dedupe;
+    const unsigned int* skip;      // optional (deferred rescoring): queries flagged 1 are left as they are
 };
 
 hipError_t nwk_launch_gen(hipStream_t st, uint64_t seed, long long row0, long long rows, int d, float* out);

@@ -376,13 +376,13 @@ def test_deferred_rescoring_gives_the_bits_of_rescoring_every_chunk(pre_engine, 
         assert np.array_equal(idx, ri) and _bitwise(dist, rd), (metric, defer)
         seen[defer] = st
     assert seen[1]["tile_launches"] == seen[0]["tile_launches"]                          # the same walk ...
-    assert seen[1]["compact_launches"] < seen[0]["compact_launches"]                     # ... without the sorts in between ...
-    assert 600 * 90 < seen[1]["prescreen_checked"] < 0.7 * seen[0]["prescreen_checked"]  # ... and a fraction of the rescoring
+    assert 600 * 90 < seen[1]["prescreen_checked"] < 0.7 * seen[0]["prescreen_checked"]  # ... with a fraction of the rescoring
 
 
 def test_deferred_rescoring_with_many_candidates_inside_the_bound(oracle):
-    """Rows the fp16 estimates cannot tell apart pile up between the chunks of a deferred walk (nothing is rescored until the end): lists
-    overflow earlier than they would with per-chunk rescoring and are repaired; the result is the canonical one either way."""
+    """Rows the fp16 estimates cannot tell apart would pile up between the chunks of a deferred walk until the lists overflow: a query whose
+    pruned list grows past the pass's limit is rescored and sorted at once, as with pre_defer = 0 -- no more overflow repairs than that, and
+    the canonical result either way."""
     from neighborhoodwatch_amd import KnnEngine
     rng = np.random.default_rng(23)
     centre = rng.standard_normal(96).astype(np.float32)
@@ -393,11 +393,15 @@ def test_deferred_rescoring_with_many_candidates_inside_the_bound(oracle):
     with KnnEngine(0) as eng:
         eng.set_prescreen(True)
         eng.set_base(base)
+        repaired = {}
         for defer in (1, 0):
             eng.set_option("pre_defer", defer)
             dist, idx = eng.search(queries, 50, "sqeuclidean")
-            assert eng.stats()["prescreen"] == 1
+            st = eng.stats()
+            assert st["prescreen"] == 1
             assert np.array_equal(idx, ri) and _bitwise(dist, rd), defer
+            repaired[defer] = st["overflowed_queries"]
+        assert repaired[1] <= repaired[0] + 2, repaired
 
 
 @pytest.mark.drives_fallback

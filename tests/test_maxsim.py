@@ -77,30 +77,6 @@ def test_hip_maxsim_prescreened_matches_oracle_bit_exact(oracle, shape):
 
 
 @pytest.mark.gpu
-def test_hip_maxsim_deferred_rescoring_gives_the_bits_of_rescoring_every_chunk(oracle):
-    """Option pre_defer (default 1): only the last chunk of a pre-screened MaxSim walk rescores (and sorts); the chunks before it prune on
-    the estimates' bounds.  Same doc ids and score bits as rescoring after every chunk and as the oracle; a fraction of the rescored pairs."""
-    from neighborhoodwatch_amd import KnnEngine
-    nd, nq, k = 20000, 12, 200
-    docs, qs = _tokens(oracle, 0xD3, nd, 64, 128), _tokens(oracle, 0xD4, nq, 32, 128)
-    rs, ri = oracle.maxsim_canonical(docs, qs, k)
-    seen = {}
-    with KnnEngine(0, profile=True) as eng:
-        eng.set_prescreen(True)
-        eng.set_option("max_chunk", 4096 * 16)               # 4096-document chunks: several of them behind the doubling start of the walk
-        eng.maxsim_set_docs(docs)
-        for defer in (0, 1):
-            eng.set_option("pre_defer", defer)
-            s, i = eng.maxsim_search(qs, k)
-            st = eng.stats()
-            assert st["prescreen"] == 1 and st["prescreen_violations"] == 0 and st["overflowed_queries"] == 0, st
-            assert np.array_equal(i, ri) and np.array_equal(s.view(np.uint32), rs.view(np.uint32)), defer
-            seen[defer] = st
-    assert seen[1]["tile_launches"] == seen[0]["tile_launches"] and seen[1]["compact_launches"] < seen[0]["compact_launches"]
-    assert nq * k * 0.5 < seen[1]["prescreen_checked"] < 0.7 * seen[0]["prescreen_checked"]
-
-
-@pytest.mark.gpu
 def test_hip_maxsim_prescreened_overflow_repair_unit_tokens_and_offsets(oracle):
     from neighborhoodwatch_amd import KnnEngine
     rng = np.random.default_rng(3)
