@@ -78,6 +78,12 @@ SEED_BASE, SEED_QUERY = 0x6E770001, 0x6E770002
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0}      # MI355X_MICROARCH.md: dense f32 / f16 MFMA peaks
 
 
+def progress(msg: str) -> None:
+    """One line on stderr (stdout carries the JSON line only): a harness that takes a silent process for a hung one sees the run move."""
+    if os.environ.get("RANK", "0") == "0":
+        print(f"bench.py [{time.perf_counter() - T_PROCESS_START:6.0f} s] {msg}", file=sys.stderr, flush=True)
+
+
 def profiler_preload() -> str:
     """Non-empty when this process runs under rocprofv3 / rocprofiler-sdk: the tool's preloaded library initialises the GPU before main(),
     so starting the ranks from here would be an exec from a process that has touched the GPU (forbidden on this pool: it takes the
@@ -503,9 +509,14 @@ class Bench:
             for _ in range(n_warmup):                                  # (a warm-up on a slice of the queries, where the caller asks for one, is said so in the line)
                 step(False, queries[:warm_queries] if warm_queries else queries)
             fence()
+            progress(f"{name}: {n_warmup} warm-up step(s) done, timing {n_steps}")
             t0 = time.perf_counter()
-            for _ in range(n_steps):
+            t_said = t0
+            for i_step in range(n_steps):
                 last = step(True, queries)
+                if time.perf_counter() - t_said > 45.0:                # (host clock only: nothing is added to the stream)
+                    t_said = time.perf_counter()
+                    progress(f"{name}: step {i_step + 1} of {n_steps}")
             fence()
             agg["prescreen_worst"] = worst[0]
             elapsed = time.perf_counter() - t0
@@ -828,10 +839,12 @@ def main():
                     if ref_files is not None:
                         ref_files.thread.join()
                     t0 = time.perf_counter()
+                progress(f"secondary leg {name}")
                 s_out, _ = b.run(name, s_steps, 1, 0 if args.no_prescreen else s_pre, warm_queries=s_warm_q)
                 if name == "refcli":
                     s_out["vs_reference_published"] = ref_published_block(s_out["value"], s_out.get("exact_prescreen"))
                     if ref_files is not None and time.perf_counter() - T_PROCESS_START + REF_FILES_EST_S <= SECONDARY_BUDGET_S:
+                        progress("secondary leg refcli: through files")
                         s_out["through_files"] = ref_files.run(b.eng)
                         ref_files = None
                     else:
