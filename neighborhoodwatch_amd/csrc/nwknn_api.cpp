@@ -1025,11 +1025,16 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         rp.tau = h->tau.as<u64>(); rp.cnt0_w = h->cnt0.as<u32>();
         rp.skip = nullptr; rp.defer_limit = 0;
         if (deferred) {
-            // a query is left in the deferred state only while the next chunk's candidates (~1.6 k per unit of growth, the spread on top) still
-            // fit behind what it keeps; otherwise it is rescored and sorted now (nwk_rescore_kernel, `stay`)
+            // a query is left in the deferred state only while the next chunk's candidates still fit behind what it keeps; otherwise it is
+            // rescored and sorted now (nwk_rescore_kernel, `stay`).  Two estimates of "the next chunk's candidates": ~1.6 k per unit of growth
+            // (what a threshold at the k-th distance admits, the spread on top), and growth x 1.3 x what the query keeps NOW -- the kept entries
+            // are the rows seen so far that lie under the bound, and a chunk `growth` times as long brings that many times as many (a query
+            // sitting in a cloud of near-ties keeps hundreds: it must go back to exact thresholds before the cloud fills its list)
             RCCHK(h->dskip.ensure((size_t)nq_pad * 4));
             rp.skip = h->dskip.as<u32>();
-            rp.defer_limit = (int)std::max<long long>(0, pl.cap - (long long)(1.8 * (double)h->walk_growth * k) - 32);
+            const long long by_k = pl.cap - (long long)(1.8 * (double)h->walk_growth * k) - 32;
+            const long long by_kept = (long long)((double)pl.cap / (1.0 + 1.3 * (double)h->walk_growth));
+            rp.defer_limit = (int)std::max<long long>(0, std::min(by_k, by_kept));
         }
         rp.rows16 = pl.native16 ? 1 : 0;
         rp.coop = h->opt_rescore_coop ? 1 : 0;
