@@ -479,3 +479,20 @@ def test_effective_cpus_honours_the_cgroup_quota_and_sizes_pyarrows_pool(monkeyp
         assert hostinfo.size_arrow_pool() == 5                          # left alone
     finally:
         pa.set_cpu_count(before)
+
+
+def test_bench_progress_lines_go_to_stderr_of_rank_0_only(capsys, monkeypatch):
+    """bench.py's stdout is ONE JSON line (the driver parses it); what a long run says while it works -- warm-ups done, a step count every
+    ~45 s, every secondary leg -- goes to stderr, from rank 0 only.  (A default run is ~425 s long: silent, it was taken for a hang.)"""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import bench
+    monkeypatch.delenv("RANK", raising=False)
+    bench.progress("c3: step 4 of 20")
+    out = capsys.readouterr()
+    assert out.out == "" and out.err.startswith("bench.py [") and out.err.endswith("c3: step 4 of 20\n")
+    monkeypatch.setenv("RANK", "3")
+    bench.progress("never printed")
+    out = capsys.readouterr()
+    assert out.out == "" and out.err == ""
