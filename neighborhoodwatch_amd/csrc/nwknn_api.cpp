@@ -1018,8 +1018,9 @@ static int run_chunk(nwknn_ctx* h, const SearchPlan& pl, int metric, int k, long
         rp.prune = (h->opt_pre_prune && !dedupe) ? 1 : 0;
         // Deferred rescoring (round 5): a chunk that is not the last of its walk only PRUNES -- bounds of the listed estimates, the k-th
         // smallest upper bound U, entries whose lower bound exceeds it dropped, the rest packed as they are, tau = U -- and neither
-        // rescores nor sorts; the walk's last chunk rescores what is left of all of them (nwk_rescore_kernel, `defer`).  Not for the
-        // dense chunk of exact fp16 mode (it builds the exact prefix the pruning counts on), repair passes, or with pruning off.
+        // rescores nor sorts (but for the queries the pass hands back, see defer_limit below: the compaction launch stays, its blocks
+        // return at once for everyone else); the walk's last chunk rescores what is left of all of them (nwk_rescore_kernel, `defer`).
+        // Not for the dense chunk of exact fp16 mode (it builds the exact prefix the pruning counts on), repair passes, or with pruning off.
         deferred = rp.prune && h->opt_pre_defer && !last && !dense && !rescan && !qtile_list;
         rp.defer = deferred ? 1 : 0;
         rp.tau = h->tau.as<u64>(); rp.cnt0_w = h->cnt0.as<u32>();
